@@ -1,0 +1,422 @@
+/*
+ * mm_oracle.c — CPU restatement of the simd-minimizers hot path (plain C).
+ *
+ * TEST INFRASTRUCTURE ONLY (see mm_oracle.h).  Never linked into the product.
+ *
+ * The reference is rust-seq/simd-minimizers v3.0.0; citations are
+ * path:line relative to /root/reference.  The hash arithmetic (seq-hash
+ * 0.2.0) and the PackedSeq layout (packed-seq 5.0.0) are third-party crates
+ * that are NOT in the reference tree: their published behaviour is restated
+ * here and anchored on the reference's doctest / unit-test vectors.
+ */
+#include "mm_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+static inline uint32_t rotl32(uint32_t x, uint32_t r) {
+    r &= 31u;
+    return r ? (x << r) | (x >> (32u - r)) : x;
+}
+static inline uint32_t rotr32(uint32_t x, uint32_t r) { return rotl32(x, 32u - (r & 31u)); }
+
+/* seq-hash 0.2.0 NtHasher::new(k): low 32 bits of the classic ntHash seeds
+ * (constants: bench/src/nthash.rs:24-32), indexed by the packed 2-bit code
+ * in the order the classic table lists them; 7 bits of rotation per base;
+ * complement = code ^ 2; canonical combine = wrapping add. */
+void mmo_default_hasher(mmo_hasher *h, int canonical) {
+    static const uint32_t F[4] = {0x95c60474u, 0x62a02b4cu, 0x82572324u, 0x4be24456u};
+    for (int c = 0; c < 4; ++c) {
+        h->fw[c] = F[c];
+        h->rc[c] = F[c ^ 2];
+    }
+    h->rot = 7;
+    h->canonical = canonical ? 1u : 0u;
+}
+
+void mmo_pack_ascii(const uint8_t *ascii, uint64_t n, uint8_t *packed) {
+    memset(packed, 0, (size_t)((n + 3) / 4));
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t code = (ascii[i] >> 1) & 3u;
+        packed[i >> 2] |= (uint8_t)(code << (2 * (i & 3)));
+    }
+}
+
+void mmo_revcomp_packed(const uint8_t *packed, uint64_t base_offset, uint64_t n, uint8_t *out) {
+    memset(out, 0, (size_t)((n + 3) / 4));
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t code = mmo_base(packed, base_offset + (n - 1 - i)) ^ 2u;
+        out[i >> 2] |= (uint8_t)(code << (2 * (i & 3)));
+    }
+}
+
+static inline uint64_t splitmix_final(uint64_t z) {
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+void mmo_gen_packed(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *packed) {
+    const uint64_t g = 0x9E3779B97F4A7C15ull;
+    memset(packed, 0, (size_t)((n + 3) / 4));
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t z = splitmix_final((first_base + i) + seed * g + g);
+        uint32_t code = (uint32_t)(z >> 62);
+        packed[i >> 2] |= (uint8_t)(code << (2 * (i & 3)));
+    }
+}
+
+/* ------------------------------------------------------------------ hash */
+
+int64_t mmo_hash_kmers_naive(const uint8_t *packed, uint64_t off, uint64_t n, uint32_t k,
+                             const mmo_hasher *h, uint32_t *out) {
+    if (k == 0) return MMO_ERR_K_ZERO;
+    if (n < k) return 0;
+    uint64_t nk = n - k + 1;
+    for (uint64_t i = 0; i < nk; ++i) {
+        uint32_t fw = 0, rc = 0;
+        for (uint32_t j = 0; j < k; ++j) {
+            uint32_t c = mmo_base(packed, off + i + j);
+            fw ^= rotl32(h->fw[c], h->rot * (k - 1 - j));
+            rc ^= rotl32(h->rc[c], h->rot * j);
+        }
+        out[i] = h->canonical ? fw + rc : fw;
+    }
+    return (int64_t)nk;
+}
+
+typedef struct {
+    uint32_t fw, rc;
+    uint32_t fw_out[4]; /* rotl(fw[c], rot*k)       : leaving base, forward strand */
+    uint32_t rc_in[4];  /* rotl(rc[c], rot*(k-1))   : entering base, reverse strand */
+    const mmo_hasher *h;
+} roll_state;
+
+static void roll_init(roll_state *st, const mmo_hasher *h, uint32_t k) {
+    st->fw = st->rc = 0;
+    st->h = h;
+    for (int c = 0; c < 4; ++c) {
+        st->fw_out[c] = rotl32(h->fw[c], h->rot * k);
+        st->rc_in[c] = rotl32(h->rc[c], h->rot * (k - 1));
+    }
+}
+/* add-only step used while the first k-1 bases are consumed
+ * (the `take(delay1)` / `take(k-1-delay1)` warm-ups of src/minimizers.rs:97-108) */
+static inline void roll_push(roll_state *st, uint32_t in) {
+    st->fw = rotl32(st->fw, st->h->rot) ^ st->h->fw[in];
+    st->rc = rotr32(st->rc, st->h->rot) ^ st->rc_in[in];
+}
+/* in/out step = hasher.in_out_mapper_scalar (call site src/minimizers.rs:85,110,121) */
+static inline void roll_step(roll_state *st, uint32_t in, uint32_t out) {
+    st->fw = rotl32(st->fw, st->h->rot) ^ st->fw_out[out] ^ st->h->fw[in];
+    st->rc = rotr32(st->rc ^ st->h->rc[out], st->h->rot) ^ st->rc_in[in];
+}
+static inline uint32_t roll_value(const roll_state *st) {
+    return st->h->canonical ? st->fw + st->rc : st->fw;
+}
+
+int64_t mmo_hash_kmers_rolling(const uint8_t *packed, uint64_t off, uint64_t n, uint32_t k,
+                               const mmo_hasher *h, uint32_t *out) {
+    if (k == 0) return MMO_ERR_K_ZERO;
+    if (n < k) return 0;
+    roll_state st;
+    roll_init(&st, h, k);
+    for (uint32_t j = 0; j < k; ++j) roll_push(&st, mmo_base(packed, off + j));
+    uint64_t nk = n - k + 1;
+    out[0] = roll_value(&st);
+    for (uint64_t i = 1; i < nk; ++i) {
+        roll_step(&st, mmo_base(packed, off + i + k - 1), mmo_base(packed, off + i - 1));
+        out[i] = roll_value(&st);
+    }
+    return (int64_t)nk;
+}
+
+/* --------------------------------------------------- per-window positions */
+
+static int check_params(uint64_t n, uint32_t k, uint32_t w, const mmo_hasher *h, int canonical) {
+    if (k == 0) return MMO_ERR_K_ZERO;
+    if (w == 0) return MMO_ERR_W_ZERO;
+    if (w >= (1u << 15)) return MMO_ERR_W_TOO_LARGE;
+    if (n >= (1ull << 32)) return MMO_ERR_LEN_TOO_LARGE;
+    if (canonical) {
+        if (!h->canonical) return MMO_ERR_HASHER_NOT_CANONICAL;
+        if (((uint64_t)k + w - 1) % 2 == 0) return MMO_ERR_EVEN_L;
+    }
+    return MMO_OK;
+}
+
+/* Definition: src/minimizers.rs:22-28 (leftmost argmin of hash & 0xffff0000) and, for canonical
+ * windows, src/canonical.rs:18-29 (#TG > l/2 -> leftmost, else rightmost: src/minimizers.rs:125). */
+static int64_t positions_naive(const uint8_t *packed, uint64_t off, uint64_t n, uint32_t k,
+                               uint32_t w, const mmo_hasher *h, int canonical, uint32_t *out) {
+    uint64_t l = (uint64_t)k + w - 1;
+    if (n < l) return 0;
+    uint64_t nw = n - l + 1, nk = n - k + 1;
+    uint32_t *hash = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nk);
+    if (!hash) return MMO_ERR_CAPACITY;
+    mmo_hash_kmers_naive(packed, off, n, k, h, hash);
+    for (uint64_t i = 0; i < nw; ++i) {
+        uint32_t best = hash[i] & 0xffff0000u;
+        uint64_t left = i, right = i;
+        for (uint64_t j = i + 1; j < i + w; ++j) {
+            uint32_t v = hash[j] & 0xffff0000u;
+            if (v < best) {
+                best = v;
+                left = right = j;
+            } else if (v == best) {
+                right = j;
+            }
+        }
+        uint64_t pos = left;
+        if (canonical) {
+            uint64_t tg = 0;
+            for (uint64_t j = i; j < i + l; ++j) tg += (mmo_base(packed, off + j) >> 1) & 1u;
+            pos = (2 * tg > l) ? left : right;
+        }
+        out[i] = (uint32_t)pos;
+    }
+    free(hash);
+    return (int64_t)nw;
+}
+
+/* Two-stacks sliding minimum, src/sliding_min.rs:86-142 (LEFT) and :145-212 (left+right).
+ * Elements are (hash & 0xffff0000) | pos16; the 16-bit position is rebased by
+ * delta = 65534 - w whenever it reaches 65535 (:117-125, :184-194). */
+typedef struct {
+    uint32_t w, idx, pos, pos_offset;
+    uint32_t pl, pr;   /* prefix minima (left: min, right: max of !hash) */
+    uint32_t *rl, *rr; /* ring buffers of suffix minima */
+} lrmin_state;
+
+static int lrmin_init(lrmin_state *s, uint32_t w) {
+    s->w = w;
+    s->idx = 0;
+    s->pos = 0;
+    s->pos_offset = 0;
+    s->pl = s->pr = 0xffffffffu;
+    s->rl = (uint32_t *)malloc(sizeof(uint32_t) * w);
+    s->rr = (uint32_t *)malloc(sizeof(uint32_t) * w);
+    if (!s->rl || !s->rr) return -1;
+    for (uint32_t i = 0; i < w; ++i) s->rl[i] = s->rr[i] = 0xffffffffu;
+    return 0;
+}
+static void lrmin_free(lrmin_state *s) {
+    free(s->rl);
+    free(s->rr);
+}
+static inline void lrmin_push(lrmin_state *s, uint32_t val, uint32_t *left, uint32_t *right) {
+    const uint32_t w = s->w;
+    if (s->pos == 0xffffu) {
+        uint32_t delta = (1u << 16) - 2u - w;
+        s->pos -= delta;
+        s->pl -= delta;
+        s->pr -= delta;
+        s->pos_offset += delta;
+        for (uint32_t i = 0; i < w; ++i) {
+            s->rl[i] -= delta;
+            s->rr[i] -= delta;
+        }
+    }
+    uint32_t le = (val & 0xffff0000u) | s->pos;
+    uint32_t re = (~val & 0xffff0000u) | s->pos;
+    s->pos += 1;
+    s->rl[s->idx] = le;
+    s->rr[s->idx] = re;
+    if (++s->idx == w) s->idx = 0;
+    if (le < s->pl) s->pl = le;
+    if (re > s->pr) s->pr = re;
+    if (s->idx == 0) {
+        uint32_t sl = s->rl[w - 1], sr = s->rr[w - 1];
+        for (uint32_t i = w - 1; i-- > 0;) {
+            if (s->rl[i] < sl) sl = s->rl[i];
+            if (s->rr[i] > sr) sr = s->rr[i];
+            s->rl[i] = sl;
+            s->rr[i] = sr;
+        }
+        s->pl = le;
+        s->pr = re;
+    }
+    uint32_t ml = s->pl < s->rl[s->idx] ? s->pl : s->rl[s->idx];
+    uint32_t mr = s->pr > s->rr[s->idx] ? s->pr : s->rr[s->idx];
+    *left = (ml & 0xffffu) + s->pos_offset;
+    *right = (mr & 0xffffu) + s->pos_offset;
+}
+
+/* src/minimizers.rs:38-49 (forward) and :74-129 (canonical), scalar flavour. */
+static int64_t positions_streaming(const uint8_t *packed, uint64_t off, uint64_t n, uint32_t k,
+                                   uint32_t w, const mmo_hasher *h, int canonical, uint32_t *out) {
+    uint64_t l = (uint64_t)k + w - 1;
+    if (n < l) return 0;
+    uint64_t nw = n - l + 1;
+    roll_state st;
+    roll_init(&st, h, k);
+    lrmin_state lr;
+    if (lrmin_init(&lr, w)) return MMO_ERR_CAPACITY;
+    /* strand counter of src/canonical.rs:12-31: cnt = -l; cnt += a&2; out = cnt>0; cnt -= r&2 */
+    int64_t cnt = -(int64_t)l;
+    uint64_t a = 0;
+    /* first k-1 bases: hash warm-up only (src/minimizers.rs:97-108) */
+    for (; a + 1 < k; ++a) {
+        uint32_t c = mmo_base(packed, off + a);
+        roll_push(&st, c);
+        cnt += c & 2u;
+    }
+    uint32_t left, right;
+    /* next w-1 bases: k-mers enter the sliding min, no complete window yet (:110-115) */
+    for (; a + 1 < l; ++a) {
+        uint32_t c = mmo_base(packed, off + a);
+        if (a + 1 == k) roll_push(&st, c);
+        else roll_step(&st, c, mmo_base(packed, off + a - k));
+        cnt += c & 2u;
+        lrmin_push(&lr, roll_value(&st), &left, &right);
+    }
+    /* one window per remaining base (:117-128) */
+    for (uint64_t i = 0; i < nw; ++i, ++a) {
+        uint32_t c = mmo_base(packed, off + a);
+        if (a + 1 == k) roll_push(&st, c);
+        else roll_step(&st, c, mmo_base(packed, off + a - k));
+        cnt += c & 2u;
+        int is_canonical = cnt > 0;
+        cnt -= mmo_base(packed, off + a - (l - 1)) & 2u;
+        lrmin_push(&lr, roll_value(&st), &left, &right);
+        out[i] = canonical ? (is_canonical ? left : right) : left;
+    }
+    lrmin_free(&lr);
+    return (int64_t)nw;
+}
+
+int64_t mmo_window_positions(const uint8_t *packed, uint64_t off, uint64_t n, uint32_t k,
+                             uint32_t w, const mmo_hasher *h, int canonical, int flavour,
+                             uint32_t *out) {
+    int e = check_params(n, k, w, h, canonical);
+    if (e) return e;
+    return flavour == MMO_NAIVE ? positions_naive(packed, off, n, k, w, h, canonical, out)
+                                : positions_streaming(packed, off, n, k, w, h, canonical, out);
+}
+
+/* ------------------------------------------------------------ collectors */
+
+/* src/collect.rs:15-37: drop ADJACENT duplicates only. */
+uint64_t mmo_collect_and_dedup(const uint32_t *in, uint64_t n, uint32_t *out) {
+    if (n == 0) return 0;
+    uint64_t m = 0;
+    out[m++] = in[0];
+    for (uint64_t i = 1; i < n; ++i)
+        if (in[i] != in[i - 1]) out[m++] = in[i];
+    return m;
+}
+
+/* src/collect.rs:39-76: idx[j] = index of the first window that selected out[j]. */
+uint64_t mmo_collect_and_dedup_with_index(const uint32_t *in, uint64_t n, uint32_t *out,
+                                          uint32_t *idx) {
+    if (n == 0) return 0;
+    uint64_t m = 0;
+    out[0] = in[0];
+    idx[0] = 0;
+    m = 1;
+    for (uint64_t i = 1; i < n; ++i)
+        if (in[i] != in[i - 1]) {
+            out[m] = in[i];
+            idx[m] = (uint32_t)i;
+            ++m;
+        }
+    return m;
+}
+
+/* src/syncmers.rs:19-48: emits WINDOW indices, no dedup. */
+int64_t mmo_collect_syncmers(const uint32_t *in, uint64_t n, uint32_t w, int open, uint32_t *out) {
+    if (open && (w % 2 == 0)) return MMO_ERR_OPEN_EVEN_W;
+    uint64_t m = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t p = in[i];
+        int keep = open ? (p == i + w / 2) : (p == i || p == i + w - 1);
+        if (keep) out[m++] = (uint32_t)i;
+    }
+    return (int64_t)m;
+}
+
+/* ------------------------------------------------------------ whole path */
+
+int64_t mmo_run(const uint8_t *packed, uint64_t off, uint64_t n, uint32_t k, uint32_t w,
+                const mmo_hasher *h, int canonical, int mode, int flavour, uint32_t *out_pos,
+                uint32_t *out_sk, uint64_t cap) {
+    int e = check_params(n, k, w, h, canonical);
+    if (e) return e;
+    if (mode < 0 || mode > 2) return MMO_ERR_BAD_MODE;
+    if (mode == MMO_OPEN_SYNCMERS && w % 2 == 0) return MMO_ERR_OPEN_EVEN_W;
+    if (out_sk && mode != MMO_MINIMIZERS) return MMO_ERR_BAD_MODE; /* src/lib.rs:339,498-503 */
+    uint64_t l = (uint64_t)k + w - 1;
+    if (n < l) return 0;
+    uint64_t nw = n - l + 1;
+    uint32_t *win = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nw);
+    uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nw);
+    uint32_t *tmp2 = out_sk ? (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nw) : NULL;
+    if (!win || !tmp || (out_sk && !tmp2)) {
+        free(win);
+        free(tmp);
+        free(tmp2);
+        return MMO_ERR_CAPACITY;
+    }
+    int64_t r = mmo_window_positions(packed, off, n, k, w, h, canonical, flavour, win);
+    int64_t m = r;
+    if (r >= 0) {
+        if (mode == MMO_MINIMIZERS)
+            m = out_sk ? (int64_t)mmo_collect_and_dedup_with_index(win, nw, tmp, tmp2)
+                       : (int64_t)mmo_collect_and_dedup(win, nw, tmp);
+        else
+            m = mmo_collect_syncmers(win, nw, w, mode == MMO_OPEN_SYNCMERS, tmp);
+        if (m >= 0) {
+            if ((uint64_t)m > cap) m = MMO_ERR_CAPACITY;
+            else {
+                memcpy(out_pos, tmp, sizeof(uint32_t) * (size_t)m);
+                if (out_sk) memcpy(out_sk, tmp2, sizeof(uint32_t) * (size_t)m);
+            }
+        }
+    }
+    free(win);
+    free(tmp);
+    free(tmp2);
+    return m;
+}
+
+/* ---------------------------------------------------------------- values */
+
+/* packed-seq Seq::read_kmer: base j of the k-mer at bits 2j (little-endian), len <= 32. */
+uint64_t mmo_read_kmer_u64(const uint8_t *packed, uint64_t off, uint32_t len, uint64_t pos) {
+    uint64_t v = 0;
+    for (uint32_t j = 0; j < len; ++j) v |= (uint64_t)mmo_base(packed, off + pos + j) << (2 * j);
+    return v;
+}
+/* packed-seq Seq::read_revcomp_kmer: reversed order, code ^ 2. */
+uint64_t mmo_read_revcomp_kmer_u64(const uint8_t *packed, uint64_t off, uint32_t len,
+                                   uint64_t pos) {
+    uint64_t v = 0;
+    for (uint32_t j = 0; j < len; ++j)
+        v |= (uint64_t)(mmo_base(packed, off + pos + (len - 1 - j)) ^ 2u) << (2 * j);
+    return v;
+}
+/* src/lib.rs:598-611 */
+void mmo_values_u64(const uint8_t *packed, uint64_t off, uint32_t len, int canonical,
+                    const uint32_t *pos, uint64_t n_pos, uint64_t *out) {
+    for (uint64_t i = 0; i < n_pos; ++i) {
+        uint64_t a = mmo_read_kmer_u64(packed, off, len, pos[i]);
+        if (canonical) {
+            uint64_t b = mmo_read_revcomp_kmer_u64(packed, off, len, pos[i]);
+            if (b < a) a = b;
+        }
+        out[i] = a;
+    }
+}
+
+void mmo_checksum(const uint32_t *v, uint64_t n, uint64_t *weighted, uint64_t *plain) {
+    uint64_t a = 0, b = 0;
+    for (uint64_t j = 0; j < n; ++j) {
+        a += (j + 1) * (uint64_t)v[j];
+        b += v[j];
+    }
+    *weighted = a;
+    *plain = b;
+}

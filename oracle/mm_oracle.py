@@ -1,0 +1,167 @@
+"""ctypes loader for the CPU oracle (oracle/mm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: may be imported by tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg, never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+MINIMIZERS, CLOSED_SYNCMERS, OPEN_SYNCMERS = 0, 1, 2
+NAIVE, STREAMING = 0, 1
+
+
+class Hasher(C.Structure):
+    _fields_ = [("fw", C.c_uint32 * 4), ("rc", C.c_uint32 * 4), ("rot", C.c_uint32),
+                ("canonical", C.c_uint32)]
+
+
+def build(native: bool = False, out_dir: str | None = None) -> str:
+    """Compile the oracle with gcc (a few hundred ms). Returns the .so path."""
+    if native:
+        out_dir = out_dir or _HERE
+        subprocess.run(["make", "-C", _HERE, "native", f"OUT={out_dir}"], check=True,
+                       capture_output=True)
+        return os.path.join(out_dir, "libmm_oracle_native.so")
+    subprocess.run(["make", "-C", _HERE, "all"], check=True, capture_output=True)
+    return os.path.join(_HERE, "libmm_oracle.so")
+
+
+def _bind(lib):
+    u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    hp = C.POINTER(Hasher)
+    lib.mmo_default_hasher.argtypes = [hp, C.c_int]
+    lib.mmo_default_hasher.restype = None
+    lib.mmo_pack_ascii.argtypes = [u8p, C.c_uint64, u8p]
+    lib.mmo_pack_ascii.restype = None
+    lib.mmo_revcomp_packed.argtypes = [u8p, C.c_uint64, C.c_uint64, u8p]
+    lib.mmo_revcomp_packed.restype = None
+    lib.mmo_gen_packed.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, u8p]
+    lib.mmo_gen_packed.restype = None
+    for name in ("mmo_hash_kmers_naive", "mmo_hash_kmers_rolling"):
+        f = getattr(lib, name)
+        f.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, hp, u32p]
+        f.restype = C.c_int64
+    lib.mmo_window_positions.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, hp,
+                                         C.c_int, C.c_int, u32p]
+    lib.mmo_window_positions.restype = C.c_int64
+    lib.mmo_collect_and_dedup.argtypes = [u32p, C.c_uint64, u32p]
+    lib.mmo_collect_and_dedup.restype = C.c_uint64
+    lib.mmo_collect_and_dedup_with_index.argtypes = [u32p, C.c_uint64, u32p, u32p]
+    lib.mmo_collect_and_dedup_with_index.restype = C.c_uint64
+    lib.mmo_collect_syncmers.argtypes = [u32p, C.c_uint64, C.c_uint32, C.c_int, u32p]
+    lib.mmo_collect_syncmers.restype = C.c_int64
+    lib.mmo_run.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, hp, C.c_int,
+                            C.c_int, C.c_int, u32p, u32p, C.c_uint64]
+    lib.mmo_run.restype = C.c_int64
+    lib.mmo_values_u64.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_int, u32p, C.c_uint64, u64p]
+    lib.mmo_values_u64.restype = None
+    lib.mmo_checksum.argtypes = [u32p, C.c_uint64, u64p, u64p]
+    lib.mmo_checksum.restype = None
+    return lib
+
+
+_LIB = None
+
+
+def lib(path: str | None = None):
+    global _LIB
+    if path is not None:
+        return _bind(C.CDLL(path))
+    if _LIB is None:
+        so = os.path.join(_HERE, "libmm_oracle.so")
+        src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("mm_oracle.c", "mm_oracle.h"))
+        if not os.path.exists(so) or os.path.getmtime(so) < src_m:
+            build()
+        _LIB = _bind(C.CDLL(so))
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def default_hasher(canonical: bool) -> Hasher:
+    h = Hasher()
+    lib().mmo_default_hasher(C.byref(h), int(canonical))
+    return h
+
+
+def pack_ascii(seq: bytes) -> np.ndarray:
+    a = np.frombuffer(bytes(seq), dtype=np.uint8)
+    out = np.zeros((len(a) + 3) // 4 + 16, dtype=np.uint8)
+    if len(a):
+        lib().mmo_pack_ascii(_p(a, C.c_uint8), len(a), _p(out, C.c_uint8))
+    return out
+
+
+def gen_packed(seed: int, n: int, first_base: int = 0) -> np.ndarray:
+    out = np.zeros((n + 3) // 4 + 16, dtype=np.uint8)
+    if n:
+        lib().mmo_gen_packed(seed, first_base, n, _p(out, C.c_uint8))
+    return out
+
+
+def revcomp_packed(packed: np.ndarray, n: int, base_offset: int = 0) -> np.ndarray:
+    out = np.zeros((n + 3) // 4 + 16, dtype=np.uint8)
+    if n:
+        lib().mmo_revcomp_packed(_p(packed, C.c_uint8), base_offset, n, _p(out, C.c_uint8))
+    return out
+
+
+def hash_kmers(packed, n, k, hasher, base_offset=0, rolling=False) -> np.ndarray:
+    nk = max(0, n - k + 1)
+    out = np.zeros(max(nk, 1), dtype=np.uint32)
+    f = lib().mmo_hash_kmers_rolling if rolling else lib().mmo_hash_kmers_naive
+    r = f(_p(packed, C.c_uint8), base_offset, n, k, C.byref(hasher), _p(out, C.c_uint32))
+    assert r == nk, r
+    return out[:nk]
+
+
+def window_positions(packed, n, k, w, hasher, canonical, flavour=STREAMING, base_offset=0):
+    nw = max(0, n - (k + w - 1) + 1)
+    out = np.zeros(max(nw, 1), dtype=np.uint32)
+    r = lib().mmo_window_positions(_p(packed, C.c_uint8), base_offset, n, k, w, C.byref(hasher),
+                                   int(canonical), flavour, _p(out, C.c_uint32))
+    if r < 0:
+        raise ValueError(f"oracle error {r}")
+    return out[:r]
+
+
+def run(packed, n, k, w, hasher=None, canonical=False, mode=MINIMIZERS, flavour=STREAMING,
+        base_offset=0, super_kmers=False):
+    """Whole path. Returns positions (and super-k-mer indices if requested)."""
+    if hasher is None:
+        hasher = default_hasher(canonical)
+    cap = max(1, n)
+    pos = np.zeros(cap, dtype=np.uint32)
+    sk = np.zeros(cap, dtype=np.uint32) if super_kmers else None
+    r = lib().mmo_run(_p(packed, C.c_uint8), base_offset, n, k, w, C.byref(hasher), int(canonical),
+                      mode, flavour, _p(pos, C.c_uint32),
+                      _p(sk, C.c_uint32) if super_kmers else None, cap)
+    if r < 0:
+        raise ValueError(f"oracle error {r}")
+    if super_kmers:
+        return pos[:r].copy(), sk[:r].copy()
+    return pos[:r].copy()
+
+
+def values_u64(packed, length, positions, canonical, base_offset=0) -> np.ndarray:
+    positions = np.ascontiguousarray(positions, dtype=np.uint32)
+    out = np.zeros(max(1, len(positions)), dtype=np.uint64)
+    lib().mmo_values_u64(_p(packed, C.c_uint8), base_offset, length, int(canonical),
+                         _p(positions, C.c_uint32), len(positions), _p(out, C.c_uint64))
+    return out[:len(positions)]
+
+
+def checksum(v) -> tuple[int, int]:
+    v = np.ascontiguousarray(v, dtype=np.uint32)
+    a, b = C.c_uint64(), C.c_uint64()
+    lib().mmo_checksum(_p(v, C.c_uint32), len(v), C.byref(a), C.byref(b))
+    return a.value, b.value
