@@ -1,0 +1,177 @@
+/*
+ * simd_minimizers_amd.h — C ABI of the MI355X (gfx950) minimizer engine.
+ *
+ * This is the drop-in boundary for the hot path of rust-seq/simd-minimizers
+ * v3.0.0 (packed-seq decode -> ntHash -> sliding-window min -> dedup/collect,
+ * the canonical variant, the syncmer filter, super-k-mer indices and k-mer
+ * values).  The reference has no FFI of its own: the path sits behind its
+ * Rust builder API (src/lib.rs:225-577).  Each entry point below names the
+ * reference item it replaces; INTEGRATION.md shows the Rust `extern "C"`
+ * binding a maintainer would add.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function
+ * returns 0 (MM_OK) or a negative MM_ERR_* code and never aborts.  The HIP
+ * kernels are the only compute path: there is no CPU fallback.
+ */
+#ifndef SIMD_MINIMIZERS_AMD_H
+#define SIMD_MINIMIZERS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ types */
+
+/* seq-hash NtHasher<CANONICAL> (call sites src/minimizers.rs:24,44,61,85,143; src/lib.rs:391).
+ *   h_fw(i) = XOR_j rotl(fw[s[i+j]], rot*(k-1-j));  h_rc(i) = XOR_j rotl(rc[s[i+j]], rot*j)
+ *   h = canonical ? h_fw + h_rc (wrapping) : h_fw
+ * The tables cross the ABI as data, so a seeded hasher (`new_with_seed`, src/lib.rs:157)
+ * is a parameter and not a rebuild. */
+typedef struct mm_hasher {
+    uint32_t fw[4];
+    uint32_t rc[4];
+    uint32_t rot;
+    uint32_t canonical;
+} mm_hasher_t;
+
+/* Builder<_, _, _, SYNCMER> (src/lib.rs:221-225): 0 minimizers, 1 closed, 2 open syncmers */
+typedef enum mm_mode { MM_MINIMIZERS = 0, MM_CLOSED_SYNCMERS = 1, MM_OPEN_SYNCMERS = 2 } mm_mode_t;
+
+/* Which kernel family a run used (diagnostics; both are HIP kernels). */
+typedef enum mm_path { MM_PATH_FUSED = 1, MM_PATH_GENERIC = 2 } mm_path_t;
+
+typedef struct mm_plan mm_plan_t;           /* immutable (k, w, hasher, mode): the Builder     */
+typedef struct mm_workspace mm_workspace_t; /* per-stream device scratch: the thread-local CACHE
+                                               of src/lib.rs:217-219, src/collect.rs:124-126   */
+
+/* One entry per assert!/panic! on the reference path. */
+enum {
+    MM_OK = 0,
+    MM_ERR_W_ZERO = -1,               /* src/sliding_min.rs:91,227 */
+    MM_ERR_W_TOO_LARGE = -2,          /* src/sliding_min.rs:92-95,228 */
+    MM_ERR_LEN_TOO_LARGE = -3,        /* src/sliding_min.rs:96-99,229 */
+    MM_ERR_EVEN_L = -4,               /* src/canonical.rs:13-16,43-46 */
+    MM_ERR_HASHER_NOT_CANONICAL = -5, /* src/minimizers.rs:81,139 */
+    MM_ERR_OPEN_EVEN_W = -6,          /* src/syncmers.rs:24-29 */
+    MM_ERR_K_ZERO = -7,
+    MM_ERR_CAPACITY = -8,             /* caller's output buffer too small; *out_count holds the need */
+    MM_ERR_BAD_MODE = -9,             /* src/lib.rs:437; super-k-mers with syncmers, src/lib.rs:339 */
+    MM_ERR_NULL = -10,
+    MM_ERR_VALUE_LEN = -11,           /* values_u64 needs len <= 32 (packed-seq read_kmer) */
+    MM_ERR_NO_DEVICE = -20,           /* no HIP device: the engine has no CPU fallback */
+    MM_ERR_HIP = -21,                 /* a HIP call failed; see mm_last_error() */
+    MM_ERR_ALLOC = -22
+};
+
+const char *mm_strerror(int code);
+/* Text of the last HIP failure seen by this thread ("" if none). */
+const char *mm_last_error(void);
+/* Number of visible HIP devices (0 if none; never initialises a device context). */
+int mm_device_count(void);
+
+/* ----------------------------------------------------------------- hasher */
+
+/* NtHasher::<CANONICAL>::new(k) (seq-hash 0.2.0; src/lib.rs:391). */
+int mm_default_hasher(mm_hasher_t *out, int canonical);
+
+/* ------------------------------------------------------------------- plan */
+
+/* minimizers / canonical_minimizers / closed_syncmers / canonical_closed_syncmers /
+ * open_syncmers / canonical_open_syncmers (src/lib.rs:240-321) + .hasher() (:327).
+ * `canonical_windows` selects the strand-vote tie-break (src/minimizers.rs:74-166);
+ * `hasher == NULL` means H::new(k) with the matching CANONICAL (src/lib.rs:391-394).
+ * Validates every precondition the reference asserts and returns the matching error. */
+int mm_plan_create(mm_plan_t **out, uint32_t k, uint32_t w, int canonical_windows, mm_mode_t mode,
+                   const mm_hasher_t *hasher);
+void mm_plan_destroy(mm_plan_t *plan);
+/* len of the values: k for minimizers, k+w-1 for syncmers (src/lib.rs:439-447) */
+uint32_t mm_plan_value_len(const mm_plan_t *plan);
+
+/* -------------------------------------------------------------- workspace */
+
+/* Device scratch bound to one HIP device and one stream.  `hip_stream` may be NULL
+ * (a private stream is created) or a hipStream_t owned by the caller. */
+int mm_workspace_create(mm_workspace_t **out, int device, void *hip_stream);
+void mm_workspace_destroy(mm_workspace_t *ws);
+int mm_workspace_sync(mm_workspace_t *ws);
+/* Force the generic (any k, any w) kernel family instead of the fused one (testing). */
+int mm_workspace_force_generic(mm_workspace_t *ws, int on);
+/* Windows per lane of the fused kernel, in units of w (0 = built-in default). Tuning knob. */
+int mm_workspace_set_blocks_per_lane(mm_workspace_t *ws, uint32_t nblk);
+/* HIP-event timing of the dominant kernel: when enabled every launch of the hot kernel is
+ * bracketed by events on the workspace stream; read back the sum and the launch count. */
+int mm_workspace_enable_timing(mm_workspace_t *ws, int on);
+int mm_workspace_kernel_time(mm_workspace_t *ws, double *total_ms, uint64_t *launches,
+                             int reset);
+/* Family used by the last run (mm_path_t). */
+int mm_workspace_last_path(const mm_workspace_t *ws);
+
+/* -------------------------------------------------------------------- run */
+
+/* Builder::run on a device-resident PackedSeq (src/lib.rs:378-448, :545-576).
+ *
+ *  d_packed      device pointer to 2-bit bases, 4 per byte, base i at bits 2(i%4) of byte i/4
+ *                (packed-seq PackedSeq), codes A0 C1 T2 G3; any byte alignment
+ *  packed_bytes  readable bytes at d_packed (>= ceil((base_offset + n_bases)/4))
+ *  base_offset   index of the sequence's first base inside the buffer (PackedSeq slices may
+ *                start inside a byte: src/test.rs:42-45)
+ *  win_begin/end half-open range of WINDOW indices to produce (0 .. n_bases-l+1); the range
+ *                form lets one long sequence be sharded across GPUs with absolute positions and
+ *                an exact dedup at the seam (src/collect.rs:265-271).  win_end = UINT64_MAX
+ *                means "to the last window".
+ *  d_out_pos     device buffer for positions (minimizer modes) / window indices (syncmer modes)
+ *  d_out_sk      optional device buffer for super-k-mer start indices (.super_kmers(), :341)
+ *  capacity      elements available in d_out_pos (and d_out_sk)
+ *  d_count       optional device uint64 receiving the number of outputs
+ *
+ * Asynchronous on the workspace stream.  Output order equals window order. */
+int mm_run_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                        uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
+                        uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
+                        uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_count);
+
+/* Same, then waits and returns the count; MM_ERR_CAPACITY if it exceeded `capacity`. */
+int mm_run_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                  uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
+                  uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos, uint32_t *d_out_sk,
+                  uint64_t capacity, uint64_t *out_count);
+
+/* Builder::run on host memory: H2D copy, kernels, D2H copy (what a Rust caller holding a
+ * PackedSeqVec / Vec<u32> binds).  `out_pos == NULL` only counts. */
+int mm_run_host(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed,
+                uint64_t base_offset, uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk,
+                uint64_t capacity, uint64_t *out_count);
+
+/* AsciiSeq input (src/lib.rs:92-98): packs (c >> 1) & 3 on the device, then runs. */
+int mm_run_host_ascii(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *ascii,
+                      uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk, uint64_t capacity,
+                      uint64_t *out_count);
+
+/* ----------------------------------------------------------------- values */
+
+/* Output::values_u64 (src/lib.rs:584-612): k-mer (minimizers) or l-mer (syncmers) at each
+ * position, min(fwd, revcomp) when `canonical`.  Device-resident positions and values. */
+int mm_values_u64_device_async(mm_workspace_t *ws, const void *d_packed, uint64_t packed_bytes,
+                               uint64_t base_offset, uint64_t n_bases, uint32_t len,
+                               int canonical, const uint32_t *d_pos, uint64_t n_pos,
+                               uint64_t *d_values);
+int mm_values_u64_host(mm_workspace_t *ws, const uint8_t *packed, uint64_t base_offset,
+                       uint64_t n_bases, uint32_t len, int canonical, const uint32_t *pos,
+                       uint64_t n_pos, uint64_t *values);
+
+/* ------------------------------------------------------------------ input */
+
+/* PackedSeqVec::from_ascii on the device: out byte i/4 |= ((c>>1)&3) << 2(i%4). */
+int mm_pack_ascii_device_async(mm_workspace_t *ws, const uint8_t *d_ascii, uint64_t n_bases,
+                               uint8_t *d_packed /* ceil(n/4) bytes */);
+/* Deterministic synthetic PackedSeq generator G of BASELINE.md §4, written on the device. */
+int mm_generate_device_async(mm_workspace_t *ws, uint64_t seed, uint64_t first_base,
+                             uint64_t n_bases, uint8_t *d_packed /* ceil(n/4) bytes */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

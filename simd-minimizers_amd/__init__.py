@@ -1,0 +1,446 @@
+"""simd_minimizers_amd — Python harness over the C ABI of the MI355X minimizer engine.
+
+The product is the HIP library ``libsimd_minimizers_amd.so`` (``csrc/``, C ABI in
+``include/simd_minimizers_amd.h``).  This module is the thin host-side mirror of the
+reference's builder API (rust-seq/simd-minimizers ``src/lib.rs:225-654``): same constructor
+names, same argument meaning, same error conditions (the reference's ``assert!``s surface as
+``MinimizerError``).  It never computes on the CPU: without the HIP library or without a GPU
+every ``run`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsimd_minimizers_amd.so")
+
+MM_MINIMIZERS, MM_CLOSED_SYNCMERS, MM_OPEN_SYNCMERS = 0, 1, 2
+PATH_FUSED, PATH_GENERIC = 1, 2
+U64_MAX = (1 << 64) - 1
+
+ERR = {
+    "W_ZERO": -1, "W_TOO_LARGE": -2, "LEN_TOO_LARGE": -3, "EVEN_L": -4,
+    "HASHER_NOT_CANONICAL": -5, "OPEN_EVEN_W": -6, "K_ZERO": -7, "CAPACITY": -8, "BAD_MODE": -9,
+    "NULL": -10, "VALUE_LEN": -11, "NO_DEVICE": -20, "HIP": -21, "ALLOC": -22,
+}
+
+
+class MinimizerError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+class Hasher(C.Structure):
+    """seq-hash NtHasher tables (see include/simd_minimizers_amd.h: mm_hasher_t)."""
+    _fields_ = [("fw", C.c_uint32 * 4), ("rc", C.c_uint32 * 4), ("rot", C.c_uint32),
+                ("canonical", C.c_uint32)]
+
+    @staticmethod
+    def from_tables(fw, rc, rot=7, canonical=True) -> "Hasher":
+        h = Hasher()
+        for i in range(4):
+            h.fw[i] = int(fw[i]) & 0xFFFFFFFF
+            h.rc[i] = int(rc[i]) & 0xFFFFFFFF
+        h.rot = rot
+        h.canonical = 1 if canonical else 0
+        return h
+
+    def is_canonical(self) -> bool:
+        return bool(self.canonical)
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; fail loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        u8p, u32p, u64p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p
+        L.mm_strerror.restype = C.c_char_p
+        L.mm_strerror.argtypes = [C.c_int]
+        L.mm_last_error.restype = C.c_char_p
+        L.mm_device_count.restype = C.c_int
+        L.mm_default_hasher.argtypes = [C.POINTER(Hasher), C.c_int]
+        L.mm_plan_create.argtypes = [C.POINTER(vp), C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                     C.POINTER(Hasher)]
+        L.mm_plan_destroy.argtypes = [vp]
+        L.mm_plan_destroy.restype = None
+        L.mm_plan_value_len.argtypes = [vp]
+        L.mm_plan_value_len.restype = C.c_uint32
+        L.mm_workspace_create.argtypes = [C.POINTER(vp), C.c_int, vp]
+        L.mm_workspace_destroy.argtypes = [vp]
+        L.mm_workspace_destroy.restype = None
+        L.mm_workspace_sync.argtypes = [vp]
+        L.mm_workspace_force_generic.argtypes = [vp, C.c_int]
+        L.mm_workspace_set_blocks_per_lane.argtypes = [vp, C.c_uint32]
+        L.mm_workspace_enable_timing.argtypes = [vp, C.c_int]
+        L.mm_workspace_kernel_time.argtypes = [vp, C.POINTER(C.c_double), u64p, C.c_int]
+        L.mm_workspace_last_path.argtypes = [vp]
+        L.mm_run_device_async.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                          C.c_uint64, vp, vp, C.c_uint64, vp]
+        L.mm_run_device.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                    C.c_uint64, vp, vp, C.c_uint64, u64p]
+        L.mm_run_host.argtypes = [vp, vp, u8p, C.c_uint64, C.c_uint64, u32p, u32p, C.c_uint64, u64p]
+        L.mm_run_host_ascii.argtypes = [vp, vp, u8p, C.c_uint64, u32p, u32p, C.c_uint64, u64p]
+        L.mm_values_u64_device_async.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64,
+                                                 C.c_uint32, C.c_int, vp, C.c_uint64, vp]
+        L.mm_values_u64_host.argtypes = [vp, u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, u32p,
+                                         C.c_uint64, u64p]
+        L.mm_pack_ascii_device_async.argtypes = [vp, vp, C.c_uint64, vp]
+        L.mm_generate_device_async.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "mm_strerror", "mm_last_error", "mm_device_count", "mm_default_hasher", "mm_plan_create",
+    "mm_plan_destroy", "mm_plan_value_len", "mm_workspace_create", "mm_workspace_destroy",
+    "mm_workspace_sync", "mm_workspace_force_generic", "mm_workspace_set_blocks_per_lane",
+    "mm_workspace_enable_timing", "mm_workspace_kernel_time", "mm_workspace_last_path",
+    "mm_run_device_async", "mm_run_device", "mm_run_host", "mm_run_host_ascii",
+    "mm_values_u64_device_async", "mm_values_u64_host", "mm_pack_ascii_device_async",
+    "mm_generate_device_async",
+]
+
+
+def _check(code: int):
+    if code != 0:
+        L = lib()
+        msg = L.mm_strerror(code).decode()
+        if code in (ERR["HIP"], ERR["ALLOC"], ERR["NO_DEVICE"]):
+            msg += ": " + L.mm_last_error().decode()
+        raise MinimizerError(code, msg)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+# ------------------------------------------------------------------ sequences
+
+
+class PackedSeq:
+    """packed-seq ``PackedSeq``: a borrowed view (bytes, base offset, length)."""
+
+    def __init__(self, data: np.ndarray, offset: int, length: int):
+        self.data, self.offset, self.length = data, offset, length
+
+    def __len__(self):
+        return self.length
+
+    def slice(self, start: int, end: int) -> "PackedSeq":
+        assert 0 <= start <= end <= self.length
+        return PackedSeq(self.data, self.offset + start, end - start)
+
+    def as_slice(self) -> "PackedSeq":
+        return self
+
+    def codes(self) -> np.ndarray:
+        i = np.arange(self.offset, self.offset + self.length, dtype=np.int64)
+        return ((self.data[i >> 2] >> (2 * (i & 3)).astype(np.uint8)) & 3).astype(np.uint8)
+
+    def to_revcomp(self) -> "PackedSeqVec":
+        return PackedSeqVec.from_codes((self.codes()[::-1] ^ 2).astype(np.uint8))
+
+
+class PackedSeqVec(PackedSeq):
+    """packed-seq ``PackedSeqVec``: owns 2-bit packed bases (A0 C1 T2 G3, 4 per byte)."""
+
+    def __init__(self, data: np.ndarray, length: int):
+        super().__init__(data, 0, length)
+
+    @staticmethod
+    def from_codes(codes: np.ndarray) -> "PackedSeqVec":
+        n = len(codes)
+        pad = np.zeros((n + 3) // 4 * 4, dtype=np.uint8)
+        pad[:n] = codes
+        q = pad.reshape(-1, 4)
+        data = (q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8)
+        return PackedSeqVec(np.concatenate([data, np.zeros(16, dtype=np.uint8)]), n)
+
+    @staticmethod
+    def from_ascii(seq: bytes) -> "PackedSeqVec":
+        a = np.frombuffer(bytes(seq), dtype=np.uint8)
+        return PackedSeqVec.from_codes(((a >> 1) & 3).astype(np.uint8))
+
+    @staticmethod
+    def random(n: int, seed: int = 0) -> "PackedSeqVec":
+        rng = np.random.default_rng(seed)
+        return PackedSeqVec.from_codes(rng.integers(0, 4, size=n, dtype=np.uint8))
+
+
+class AsciiSeq:
+    """packed-seq ``AsciiSeq``: ACTG/actg characters, mapped with (c >> 1) & 3."""
+
+    def __init__(self, seq: bytes):
+        self.seq = bytes(seq)
+
+    def __len__(self):
+        return len(self.seq)
+
+    def slice(self, start: int, end: int) -> "AsciiSeq":
+        return AsciiSeq(self.seq[start:end])
+
+
+# ------------------------------------------------------------------ workspace
+
+
+class Workspace:
+    """Device scratch + stream (the reference's thread-local CACHE, src/lib.rs:217-219)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        L = lib()
+        if L.mm_device_count() <= 0:
+            raise MinimizerError(ERR["NO_DEVICE"], "no HIP device (this engine has no CPU fallback)")
+        h = C.c_void_p()
+        _check(L.mm_workspace_create(C.byref(h), device, C.c_void_p(stream)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mm_workspace_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(lib().mm_workspace_sync(self.h))
+
+    def force_generic(self, on: bool):
+        _check(lib().mm_workspace_force_generic(self.h, int(on)))
+
+    def set_blocks_per_lane(self, nblk: int):
+        _check(lib().mm_workspace_set_blocks_per_lane(self.h, nblk))
+
+    def enable_timing(self, on: bool):
+        _check(lib().mm_workspace_enable_timing(self.h, int(on)))
+
+    def kernel_time(self, reset: bool = True) -> tuple[float, int]:
+        ms, n = C.c_double(), C.c_uint64()
+        _check(lib().mm_workspace_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def last_path(self) -> int:
+        return lib().mm_workspace_last_path(self.h)
+
+
+_default_ws: dict[int, Workspace] = {}
+
+
+def default_workspace(device: int = 0) -> Workspace:
+    if device not in _default_ws:
+        _default_ws[device] = Workspace(device)
+    return _default_ws[device]
+
+
+# -------------------------------------------------------------------- builder
+
+
+def NtHasher(k: int | None = None, canonical: bool = True) -> Hasher:
+    """seq-hash ``NtHasher::<CANONICAL>::new(k)`` (k only rotates tables inside the plan)."""
+    h = Hasher()
+    _check(lib().mm_default_hasher(C.byref(h), int(canonical)))
+    return h
+
+
+class Plan:
+    def __init__(self, k, w, canonical, mode, hasher):
+        h = C.c_void_p()
+        hp = C.byref(hasher) if hasher is not None else None
+        _check(lib().mm_plan_create(C.byref(h), k, w, int(canonical), mode, hp))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().mm_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def value_len(self) -> int:
+        return lib().mm_plan_value_len(self.h)
+
+
+class Output:
+    """``Output`` of src/lib.rs:232-237: positions + lazily computed k-mer values."""
+
+    def __init__(self, builder, seq, min_pos):
+        self.len = builder.k if builder.mode == MM_MINIMIZERS else builder.k + builder.w - 1
+        self.canonical = builder.canonical
+        self.seq = seq
+        self.min_pos = min_pos
+        self._ws = builder._ws()
+
+    def values_u64(self) -> np.ndarray:
+        return self.pos_and_values_u64()[1]
+
+    def pos_and_values_u64(self):
+        pos = np.ascontiguousarray(self.min_pos, dtype=np.uint32)
+        vals = np.zeros(len(pos), dtype=np.uint64)
+        seq = self.seq
+        if isinstance(seq, AsciiSeq):
+            seq = PackedSeqVec.from_ascii(seq.seq)
+        if len(pos):
+            _check(lib().mm_values_u64_host(self._ws.h, _p(seq.data, C.c_uint8), seq.offset, seq.length,
+                                            self.len, int(self.canonical), _p(pos, C.c_uint32),
+                                            len(pos), _p(vals, C.c_uint64)))
+        return pos, vals
+
+
+class Builder:
+    """``Builder<CANONICAL, H, SkPos, SYNCMER>`` (src/lib.rs:225-230)."""
+
+    def __init__(self, k, w, canonical, mode, hasher=None, sk_pos=None, workspace=None):
+        self.k, self.w, self.canonical, self.mode = k, w, canonical, mode
+        self._hasher, self._sk, self._workspace = hasher, sk_pos, workspace
+        self._plan = None
+
+    def hasher(self, hasher: Hasher) -> "Builder":  # src/lib.rs:327
+        return Builder(self.k, self.w, self.canonical, self.mode, hasher, self._sk, self._workspace)
+
+    def super_kmers(self, sk_pos: list) -> "Builder":  # src/lib.rs:341 (minimizers only)
+        if self.mode != MM_MINIMIZERS:
+            raise MinimizerError(ERR["BAD_MODE"], "super_kmers() is only defined for minimizers")
+        return Builder(self.k, self.w, self.canonical, self.mode, self._hasher, sk_pos, self._workspace)
+
+    def workspace(self, ws: Workspace) -> "Builder":
+        return Builder(self.k, self.w, self.canonical, self.mode, self._hasher, self._sk, ws)
+
+    def _ws(self) -> Workspace:
+        return self._workspace or default_workspace()
+
+    def plan(self) -> Plan:
+        if self._plan is None:
+            self._plan = Plan(self.k, self.w, self.canonical, self.mode, self._hasher)
+        return self._plan
+
+    # -- host sequences -------------------------------------------------
+    def run(self, seq, min_pos: list) -> Output:
+        """``Builder::run``: positions are APPENDED to ``min_pos`` (src/lib.rs:80-81); like the
+        reference's SIMD collector a leading result equal to ``min_pos[-1]`` is dropped
+        (src/collect.rs:265-271)."""
+        pos, sk = self._run_arrays(seq)
+        pos, sk = list(map(int, pos)), (list(map(int, sk)) if sk is not None else None)
+        if self.mode == MM_MINIMIZERS:
+            while pos and min_pos and pos[0] == min_pos[-1]:
+                pos = pos[1:]
+                sk = sk[1:] if sk is not None else None
+        min_pos.extend(pos)
+        if self._sk is not None:
+            self._sk.extend(sk)
+        return Output(self, seq, min_pos)
+
+    def run_once(self, seq) -> list:
+        out: list = []
+        self.run(seq, out)
+        return out
+
+    def _run_arrays(self, seq):
+        L = lib()
+        ws = self._ws()
+        plan = self.plan()
+        n = len(seq)
+        lwin = self.k + self.w - 1
+        cap = max(1, n - lwin + 1) if n >= lwin else 1
+        pos = np.zeros(cap, dtype=np.uint32)
+        want_sk = self._sk is not None
+        sk = np.zeros(cap, dtype=np.uint32) if want_sk else None
+        cnt = C.c_uint64()
+        skp = _p(sk, C.c_uint32) if want_sk else None
+        if isinstance(seq, AsciiSeq):
+            a = np.frombuffer(seq.seq, dtype=np.uint8)
+            _check(L.mm_run_host_ascii(plan.h, ws.h, _p(a, C.c_uint8) if n else None, n,
+                                       _p(pos, C.c_uint32), skp, cap, C.byref(cnt)))
+        else:
+            _check(L.mm_run_host(plan.h, ws.h, _p(seq.data, C.c_uint8), seq.offset, seq.length,
+                                 _p(pos, C.c_uint32), skp, cap, C.byref(cnt)))
+        m = cnt.value
+        return pos[:m], (sk[:m] if want_sk else None)
+
+    # -- device-resident sequences (torch uint8 CUDA tensors) -----------
+    def run_device(self, d_packed, n_bases: int, out_pos, out_sk=None, base_offset: int = 0,
+                   win_begin: int = 0, win_end: int = U64_MAX, sync: bool = True, d_count=None):
+        """Run on a device-resident PackedSeq. ``d_packed``/``out_pos``/``out_sk``/``d_count`` are
+        torch CUDA tensors (uint8 / int32-or-uint32 / int64). Returns the count if ``sync``."""
+        L = lib()
+        ws = self._ws()
+        plan = self.plan()
+        cap = out_pos.numel() if out_pos is not None else 0
+        args = [plan.h, ws.h, C.c_void_p(d_packed.data_ptr()), d_packed.numel(), base_offset, n_bases,
+                win_begin, win_end, C.c_void_p(out_pos.data_ptr()) if out_pos is not None else None,
+                C.c_void_p(out_sk.data_ptr()) if out_sk is not None else None, cap]
+        if sync:
+            cnt = C.c_uint64()
+            code = L.mm_run_device(*args, C.byref(cnt))
+            if code == ERR["CAPACITY"]:
+                raise MinimizerError(code, f"output capacity {cap} < {cnt.value}")
+            _check(code)
+            return cnt.value
+        _check(L.mm_run_device_async(*args, C.c_void_p(d_count.data_ptr()) if d_count is not None else None))
+        return None
+
+
+def minimizers(k, w):  # src/lib.rs:240
+    return Builder(k, w, False, MM_MINIMIZERS)
+
+
+def canonical_minimizers(k, w):  # src/lib.rs:250
+    return Builder(k, w, True, MM_MINIMIZERS)
+
+
+def closed_syncmers(k, w):  # src/lib.rs:269
+    return Builder(k, w, False, MM_CLOSED_SYNCMERS)
+
+
+def canonical_closed_syncmers(k, w):  # src/lib.rs:282
+    return Builder(k, w, True, MM_CLOSED_SYNCMERS)
+
+
+def open_syncmers(k, w):  # src/lib.rs:301
+    return Builder(k, w, False, MM_OPEN_SYNCMERS)
+
+
+def canonical_open_syncmers(k, w):  # src/lib.rs:311
+    return Builder(k, w, True, MM_OPEN_SYNCMERS)
+
+
+# README.md:65 uses this older name for canonical closed syncmers
+canonical_syncmers = canonical_closed_syncmers
+syncmers = closed_syncmers
+
+
+def minimizer_positions(seq, k, w):  # src/lib.rs:639
+    return minimizers(k, w).run_once(seq)
+
+
+def canonical_minimizer_positions(seq, k, w):  # src/lib.rs:652
+    return canonical_minimizers(k, w).run_once(seq)
+
+
+def generate_device(n_bases: int, seed: int, device: int = 0, first_base: int = 0):
+    """Synthetic PackedSeq (generator G) written directly into HBM.
+    Returns a torch uint8 CUDA tensor of ceil(n/4)+64 bytes."""
+    import torch
+
+    ws = default_workspace(device)
+    t = torch.zeros((n_bases + 3) // 4 + 64, dtype=torch.uint8, device=f"cuda:{device}")
+    torch.cuda.synchronize(device)
+    _check(lib().mm_generate_device_async(ws.h, seed, first_base, n_bases, C.c_void_p(t.data_ptr())))
+    ws.sync()
+    return t

@@ -1,0 +1,567 @@
+// mm_api.hip — the C ABI (include/simd_minimizers_amd.h): plan, workspace and run entry points.
+//
+// Mirrors the reference's builder (src/lib.rs:225-577): a plan is the immutable Builder
+// {k, w, hasher, CANONICAL, SYNCMER}; a workspace is the reusable scratch the reference keeps
+// in thread-locals (src/lib.rs:217-219, src/collect.rs:124-126), here device buffers + a stream.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/simd_minimizers_amd.h"
+#include "mm_launch.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int hip_fail(hipError_t e, const char *what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return MM_ERR_HIP;
+}
+#define MM_HIP(call)                                   \
+    do {                                               \
+        hipError_t e_ = (call);                        \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+uint32_t rotl32(uint32_t x, uint32_t r) {
+    r &= 31u;
+    return r ? (x << r) | (x >> (32u - r)) : x;
+}
+uint32_t rotr32(uint32_t x, uint32_t r) { return rotl32(x, 32u - (r & 31u)); }
+
+// seq-hash 0.2.0 NtHasher (not in the reference tree): low halves of the classic ntHash
+// seeds (values: bench/src/nthash.rs:24-32) indexed by the packed 2-bit code, 7 bits of
+// rotation per base, complement = code ^ 2.  Pinned by the doctests src/lib.rs:92-140.
+const uint32_t kNtSeeds[4] = {0x95c60474u, 0x62a02b4cu, 0x82572324u, 0x4be24456u};
+
+mm::HashTables make_tables(const mm_hasher_t &h, uint32_t k) {
+    mm::HashTables t;
+    const uint32_t R = h.rot & 31u;
+    uint32_t fw_out[4], rc_in[4], rc_out[4];
+    for (int c = 0; c < 4; ++c) {
+        fw_out[c] = rotl32(h.fw[c], (uint32_t)(((uint64_t)R * k) & 31u));
+        rc_in[c] = rotl32(h.rc[c], (uint32_t)(((uint64_t)R * (k - 1)) & 31u));
+        rc_out[c] = rotr32(h.rc[c], R);
+    }
+    for (int out = 0; out < 4; ++out)
+        for (int in = 0; in < 4; ++in) {
+            t.t_in_out[(out << 2) | in].x = h.fw[in] ^ fw_out[out];
+            t.t_in_out[(out << 2) | in].y = rc_in[in] ^ rc_out[out];
+        }
+    for (int in = 0; in < 4; ++in) {
+        t.t_in[in].x = h.fw[in];
+        t.t_in[in].y = rc_in[in];
+    }
+    t.rot = R;
+    t.canonical = h.canonical ? 1u : 0u;
+    return t;
+}
+
+}  // namespace
+
+struct mm_plan {
+    uint32_t k, w;
+    int canonical_windows;
+    uint32_t mode;
+    mm_hasher_t hasher;
+    mm::HashTables ht;
+};
+
+struct mm_workspace {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // scan state
+    unsigned long long *status = nullptr;
+    uint64_t status_words = 0;
+    uint32_t *ticket = nullptr;
+    unsigned long long *total = nullptr;
+    unsigned long long *h_total = nullptr;  // pinned
+    // generic-path scratch
+    void *scratch = nullptr;
+    uint64_t scratch_bytes = 0;
+    // staging for the host entry points
+    void *d_in = nullptr;
+    uint64_t d_in_bytes = 0;
+    void *d_ascii = nullptr;
+    uint64_t d_ascii_bytes = 0;
+    uint32_t *d_out = nullptr;
+    uint64_t d_out_elems = 0;
+    uint32_t *d_sk = nullptr;
+    uint64_t d_sk_elems = 0;
+    unsigned long long *d_vals = nullptr;
+    uint64_t d_vals_elems = 0;
+    // knobs / diagnostics
+    bool force_generic = false;
+    uint32_t nblk = 0;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double total_ms = 0.0;
+    uint64_t launches = 0;
+    int last_path = 0;
+};
+
+namespace {
+
+template <class T>
+int grow(T *&ptr, uint64_t &have, uint64_t need, size_t elem) {
+    if (need <= have && ptr) return MM_OK;
+    if (ptr) MM_HIP(hipFree(ptr));
+    ptr = nullptr;
+    have = 0;
+    uint64_t want = need + need / 8 + 64;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want * elem);
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return MM_ERR_ALLOC;
+    }
+    ptr = reinterpret_cast<T *>(p);
+    have = want;
+    return MM_OK;
+}
+
+int make_view(const void *d_packed, uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
+              mm::SeqView *v) {
+    uintptr_t a = reinterpret_cast<uintptr_t>(d_packed);
+    uint64_t byte_shift = a & 3u;
+    uint64_t base0 = base_offset + 4 * byte_shift;
+    uint64_t n_dwords = (byte_shift + packed_bytes + 3) / 4;
+    if (n_dwords == 0 || n_dwords >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    if ((base0 + n_bases + 15) / 16 > n_dwords) return MM_ERR_CAPACITY;
+    if (base0 >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    v->d = reinterpret_cast<const uint32_t *>(a - byte_shift);
+    v->n_dwords = (uint32_t)n_dwords;
+    v->base0 = (uint32_t)base0;
+    v->n_bases = (uint32_t)n_bases;
+    return MM_OK;
+}
+
+int collect_timing(mm_workspace *ws) {
+    for (auto &ev : ws->events) {
+        MM_HIP(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        MM_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+        ws->total_ms += ms;
+        ws->launches += 1;
+        hipEventDestroy(ev.first);
+        hipEventDestroy(ev.second);
+    }
+    ws->events.clear();
+    return MM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mm_strerror(int code) {
+    switch (code) {
+        case MM_OK: return "ok";
+        case MM_ERR_W_ZERO: return "w must be > 0";
+        case MM_ERR_W_TOO_LARGE: return "w must be < 2^15";
+        case MM_ERR_LEN_TOO_LARGE: return "sequence must be shorter than 2^32 bases";
+        case MM_ERR_EVEN_L: return "canonical windows need odd l = k + w - 1";
+        case MM_ERR_HASHER_NOT_CANONICAL: return "canonical windows need a canonical hasher";
+        case MM_ERR_OPEN_EVEN_W: return "open syncmers need odd w";
+        case MM_ERR_K_ZERO: return "k must be > 0";
+        case MM_ERR_CAPACITY: return "buffer too small";
+        case MM_ERR_BAD_MODE: return "bad mode (or super-k-mers requested with syncmers)";
+        case MM_ERR_NULL: return "null argument";
+        case MM_ERR_VALUE_LEN: return "values_u64 needs 1 <= len <= 32";
+        case MM_ERR_NO_DEVICE: return "no HIP device (this engine has no CPU fallback)";
+        case MM_ERR_HIP: return "HIP call failed";
+        case MM_ERR_ALLOC: return "device allocation failed";
+        default: return "unknown error";
+    }
+}
+
+const char *mm_last_error(void) { return g_last_error.c_str(); }
+
+int mm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mm_default_hasher(mm_hasher_t *out, int canonical) {
+    if (!out) return MM_ERR_NULL;
+    for (int c = 0; c < 4; ++c) {
+        out->fw[c] = kNtSeeds[c];
+        out->rc[c] = kNtSeeds[c ^ 2];
+    }
+    out->rot = 7;
+    out->canonical = canonical ? 1u : 0u;
+    return MM_OK;
+}
+
+int mm_plan_create(mm_plan_t **out, uint32_t k, uint32_t w, int canonical_windows, mm_mode_t mode,
+                   const mm_hasher_t *hasher) {
+    if (!out) return MM_ERR_NULL;
+    *out = nullptr;
+    if (k == 0) return MM_ERR_K_ZERO;
+    if (w == 0) return MM_ERR_W_ZERO;
+    if (w >= (1u << 15)) return MM_ERR_W_TOO_LARGE;
+    if ((int)mode < 0 || (int)mode > 2) return MM_ERR_BAD_MODE;
+    if (mode == MM_OPEN_SYNCMERS && w % 2 == 0) return MM_ERR_OPEN_EVEN_W;
+    mm_hasher_t h;
+    if (hasher) h = *hasher;
+    else mm_default_hasher(&h, canonical_windows);
+    if (canonical_windows) {
+        if (!h.canonical) return MM_ERR_HASHER_NOT_CANONICAL;
+        if (((uint64_t)k + w - 1) % 2 == 0) return MM_ERR_EVEN_L;
+    }
+    mm_plan *p = new (std::nothrow) mm_plan;
+    if (!p) return MM_ERR_ALLOC;
+    p->k = k;
+    p->w = w;
+    p->canonical_windows = canonical_windows ? 1 : 0;
+    p->mode = (uint32_t)mode;
+    p->hasher = h;
+    p->ht = make_tables(h, k);
+    *out = p;
+    return MM_OK;
+}
+
+void mm_plan_destroy(mm_plan_t *plan) { delete plan; }
+
+uint32_t mm_plan_value_len(const mm_plan_t *plan) {
+    if (!plan) return 0;
+    return plan->mode == MM_MINIMIZERS ? plan->k : plan->k + plan->w - 1;
+}
+
+int mm_workspace_create(mm_workspace_t **out, int device, void *hip_stream) {
+    if (!out) return MM_ERR_NULL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        g_last_error = "no HIP device visible";
+        return MM_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return MM_ERR_NO_DEVICE;
+    MM_HIP(hipSetDevice(device));
+    mm_workspace *ws = new (std::nothrow) mm_workspace;
+    if (!ws) return MM_ERR_ALLOC;
+    ws->device = device;
+    if (hip_stream) {
+        ws->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ws;
+            return hip_fail(e, "hipStreamCreate");
+        }
+        ws->own_stream = true;
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ws->ticket), 64);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ws->total), 64);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ws->h_total), 64, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        mm_workspace_destroy(ws);
+        return hip_fail(e, "workspace allocation");
+    }
+    *out = ws;
+    return MM_OK;
+}
+
+void mm_workspace_destroy(mm_workspace_t *ws) {
+    if (!ws) return;
+    hipSetDevice(ws->device);
+    if (ws->stream) hipStreamSynchronize(ws->stream);
+    for (auto &ev : ws->events) {
+        hipEventDestroy(ev.first);
+        hipEventDestroy(ev.second);
+    }
+    if (ws->status) hipFree(ws->status);
+    if (ws->ticket) hipFree(ws->ticket);
+    if (ws->total) hipFree(ws->total);
+    if (ws->h_total) hipHostFree(ws->h_total);
+    if (ws->scratch) hipFree(ws->scratch);
+    if (ws->d_in) hipFree(ws->d_in);
+    if (ws->d_ascii) hipFree(ws->d_ascii);
+    if (ws->d_out) hipFree(ws->d_out);
+    if (ws->d_sk) hipFree(ws->d_sk);
+    if (ws->d_vals) hipFree(ws->d_vals);
+    if (ws->own_stream && ws->stream) hipStreamDestroy(ws->stream);
+    delete ws;
+}
+
+int mm_workspace_sync(mm_workspace_t *ws) {
+    if (!ws) return MM_ERR_NULL;
+    MM_HIP(hipStreamSynchronize(ws->stream));
+    return MM_OK;
+}
+
+int mm_workspace_force_generic(mm_workspace_t *ws, int on) {
+    if (!ws) return MM_ERR_NULL;
+    ws->force_generic = on != 0;
+    return MM_OK;
+}
+
+int mm_workspace_set_blocks_per_lane(mm_workspace_t *ws, uint32_t nblk) {
+    if (!ws) return MM_ERR_NULL;
+    ws->nblk = nblk;
+    return MM_OK;
+}
+
+int mm_workspace_enable_timing(mm_workspace_t *ws, int on) {
+    if (!ws) return MM_ERR_NULL;
+    ws->timing = on != 0;
+    return MM_OK;
+}
+
+int mm_workspace_kernel_time(mm_workspace_t *ws, double *total_ms, uint64_t *launches, int reset) {
+    if (!ws) return MM_ERR_NULL;
+    MM_HIP(hipSetDevice(ws->device));
+    int r = collect_timing(ws);
+    if (r) return r;
+    if (total_ms) *total_ms = ws->total_ms;
+    if (launches) *launches = ws->launches;
+    if (reset) {
+        ws->total_ms = 0.0;
+        ws->launches = 0;
+    }
+    return MM_OK;
+}
+
+int mm_workspace_last_path(const mm_workspace_t *ws) { return ws ? ws->last_path : 0; }
+
+int mm_run_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                        uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
+                        uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
+                        uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_count) {
+    if (!plan || !ws) return MM_ERR_NULL;
+    if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    if (d_out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;  // src/lib.rs:339
+    if (!d_out_pos) capacity = 0;
+    MM_HIP(hipSetDevice(ws->device));
+    const uint64_t l = (uint64_t)plan->k + plan->w - 1;
+    const uint64_t n_w = n_bases >= l ? n_bases - l + 1 : 0;
+    if (win_end > n_w) win_end = n_w;
+    MM_HIP(hipMemsetAsync(ws->total, 0, sizeof(unsigned long long), ws->stream));
+    if (win_begin < win_end) {
+        if (!d_packed) return MM_ERR_NULL;
+        mm::RunArgs a;
+        int r = make_view(d_packed, packed_bytes, base_offset, n_bases, &a.seq);
+        if (r) return r;
+        a.ht = plan->ht;
+        a.k = plan->k;
+        a.w = plan->w;
+        a.canonical_windows = plan->canonical_windows;
+        a.mode = plan->mode;
+        a.win_begin = win_begin;
+        a.win_end = win_end;
+        a.out.pos = d_out_pos;
+        a.out.sk = d_out_sk;
+        a.out.cap = capacity;
+        a.out.total = ws->total;
+        a.out.ticket = ws->ticket;
+        a.nblk = ws->nblk;
+        a.scratch = nullptr;
+        a.generic_round_windows = 0;
+        a.timing_start = a.timing_stop = nullptr;
+        const bool fused = !ws->force_generic &&
+                           mm::fused_supported(plan->k, plan->w, plan->canonical_windows,
+                                               (int)plan->ht.canonical);
+        uint64_t need_status;
+        if (fused) {
+            need_status = mm::fused_status_words(a);
+        } else {
+            const uint64_t nwin = win_end - win_begin;
+            a.generic_round_windows = nwin < (1ull << 24) ? nwin : (1ull << 24);
+            need_status = mm::generic_status_words(a.generic_round_windows);
+            uint64_t need_scratch = mm::generic_scratch_bytes(a.generic_round_windows, plan->w);
+            uint8_t *sp = reinterpret_cast<uint8_t *>(ws->scratch);
+            r = grow(sp, ws->scratch_bytes, need_scratch, 1);
+            ws->scratch = sp;
+            if (r) return r;
+            a.scratch = ws->scratch;
+        }
+        r = grow(ws->status, ws->status_words, need_status, sizeof(unsigned long long));
+        if (r) return r;
+        a.out.status = ws->status;
+        if (ws->timing) {
+            hipEvent_t e0, e1;
+            MM_HIP(hipEventCreate(&e0));
+            MM_HIP(hipEventCreate(&e1));
+            ws->events.emplace_back(e0, e1);
+            a.timing_start = e0;
+            a.timing_stop = e1;
+        }
+        int lr = fused ? mm::launch_fused(a, ws->stream) : mm::launch_generic(a, ws->stream);
+        if (lr != 0) {
+            g_last_error = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
+            return MM_ERR_HIP;
+        }
+        ws->last_path = fused ? MM_PATH_FUSED : MM_PATH_GENERIC;
+    }
+    if (d_count)
+        MM_HIP(hipMemcpyAsync(d_count, ws->total, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                              ws->stream));
+    return MM_OK;
+}
+
+int mm_run_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                  uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
+                  uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos, uint32_t *d_out_sk,
+                  uint64_t capacity, uint64_t *out_count) {
+    int r = mm_run_device_async(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin,
+                                win_end, d_out_pos, d_out_sk, capacity, nullptr);
+    if (r) return r;
+    MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                          ws->stream));
+    MM_HIP(hipStreamSynchronize(ws->stream));
+    if (out_count) *out_count = *ws->h_total;
+    if (d_out_pos && *ws->h_total > capacity) return MM_ERR_CAPACITY;
+    return MM_OK;
+}
+
+static int run_host_common(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                           uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
+                           uint32_t *out_pos, uint32_t *out_sk, uint64_t capacity,
+                           uint64_t *out_count) {
+    const uint64_t l = (uint64_t)plan->k + plan->w - 1;
+    const uint64_t n_w = n_bases >= l ? n_bases - l + 1 : 0;
+    uint64_t cap = out_pos ? (capacity < n_w ? capacity : n_w) : 0;
+    int r = grow(ws->d_out, ws->d_out_elems, cap ? cap : 1, sizeof(uint32_t));
+    if (r) return r;
+    if (out_sk) {
+        r = grow(ws->d_sk, ws->d_sk_elems, cap ? cap : 1, sizeof(uint32_t));
+        if (r) return r;
+    }
+    uint64_t count = 0;
+    r = mm_run_device(plan, ws, d_packed, packed_bytes, base_offset, n_bases, 0, UINT64_MAX,
+                      cap ? ws->d_out : nullptr, (out_sk && cap) ? ws->d_sk : nullptr, cap, &count);
+    if (out_count) *out_count = count;
+    if (r == MM_ERR_CAPACITY) return r;
+    if (r) return r;
+    if (out_pos && count) {
+        MM_HIP(hipMemcpyAsync(out_pos, ws->d_out, count * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                              ws->stream));
+        if (out_sk)
+            MM_HIP(hipMemcpyAsync(out_sk, ws->d_sk, count * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                  ws->stream));
+        MM_HIP(hipStreamSynchronize(ws->stream));
+    }
+    return MM_OK;
+}
+
+int mm_run_host(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed,
+                uint64_t base_offset, uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk,
+                uint64_t capacity, uint64_t *out_count) {
+    if (!plan || !ws) return MM_ERR_NULL;
+    if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    if (out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;
+    MM_HIP(hipSetDevice(ws->device));
+    const uint64_t bytes = (base_offset + n_bases + 3) / 4;
+    uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
+    int r = grow(din, ws->d_in_bytes, bytes + 16, 1);
+    ws->d_in = din;
+    if (r) return r;
+    if (bytes) {
+        if (!packed) return MM_ERR_NULL;
+        MM_HIP(hipMemcpyAsync(ws->d_in, packed, bytes, hipMemcpyHostToDevice, ws->stream));
+    }
+    return run_host_common(plan, ws, ws->d_in, bytes + 16, base_offset, n_bases, out_pos, out_sk,
+                           capacity, out_count);
+}
+
+int mm_run_host_ascii(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *ascii,
+                      uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk, uint64_t capacity,
+                      uint64_t *out_count) {
+    if (!plan || !ws) return MM_ERR_NULL;
+    if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    if (out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;
+    MM_HIP(hipSetDevice(ws->device));
+    const uint64_t bytes = (n_bases + 3) / 4;
+    uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
+    int r = grow(din, ws->d_in_bytes, bytes + 16, 1);
+    ws->d_in = din;
+    if (r) return r;
+    uint8_t *dasc = reinterpret_cast<uint8_t *>(ws->d_ascii);
+    r = grow(dasc, ws->d_ascii_bytes, n_bases + 16, 1);
+    ws->d_ascii = dasc;
+    if (r) return r;
+    if (n_bases) {
+        if (!ascii) return MM_ERR_NULL;
+        MM_HIP(hipMemcpyAsync(ws->d_ascii, ascii, n_bases, hipMemcpyHostToDevice, ws->stream));
+        if (mm::launch_pack_ascii(dasc, n_bases, din, ws->stream)) return hip_fail(hipGetLastError(), "pack_ascii");
+    }
+    return run_host_common(plan, ws, ws->d_in, bytes + 16, 0, n_bases, out_pos, out_sk, capacity,
+                           out_count);
+}
+
+int mm_values_u64_device_async(mm_workspace_t *ws, const void *d_packed, uint64_t packed_bytes,
+                               uint64_t base_offset, uint64_t n_bases, uint32_t len,
+                               int canonical, const uint32_t *d_pos, uint64_t n_pos,
+                               uint64_t *d_values) {
+    if (!ws) return MM_ERR_NULL;
+    if (len == 0 || len > 32) return MM_ERR_VALUE_LEN;
+    if (n_pos == 0) return MM_OK;
+    if (!d_packed || !d_pos || !d_values) return MM_ERR_NULL;
+    MM_HIP(hipSetDevice(ws->device));
+    mm::SeqView v;
+    int r = make_view(d_packed, packed_bytes, base_offset, n_bases, &v);
+    if (r) return r;
+    if (mm::launch_values_u64(v, len, canonical, d_pos, n_pos,
+                              reinterpret_cast<unsigned long long *>(d_values), ws->stream))
+        return hip_fail(hipGetLastError(), "values_u64");
+    return MM_OK;
+}
+
+int mm_values_u64_host(mm_workspace_t *ws, const uint8_t *packed, uint64_t base_offset,
+                       uint64_t n_bases, uint32_t len, int canonical, const uint32_t *pos,
+                       uint64_t n_pos, uint64_t *values) {
+    if (!ws) return MM_ERR_NULL;
+    if (len == 0 || len > 32) return MM_ERR_VALUE_LEN;
+    if (n_pos == 0) return MM_OK;
+    if (!packed || !pos || !values) return MM_ERR_NULL;
+    MM_HIP(hipSetDevice(ws->device));
+    const uint64_t bytes = (base_offset + n_bases + 3) / 4;
+    uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
+    int r = grow(din, ws->d_in_bytes, bytes + 16, 1);
+    ws->d_in = din;
+    if (r) return r;
+    r = grow(ws->d_out, ws->d_out_elems, n_pos, sizeof(uint32_t));
+    if (r) return r;
+    r = grow(ws->d_vals, ws->d_vals_elems, n_pos, sizeof(unsigned long long));
+    if (r) return r;
+    MM_HIP(hipMemcpyAsync(ws->d_in, packed, bytes, hipMemcpyHostToDevice, ws->stream));
+    MM_HIP(hipMemcpyAsync(ws->d_out, pos, n_pos * sizeof(uint32_t), hipMemcpyHostToDevice, ws->stream));
+    r = mm_values_u64_device_async(ws, ws->d_in, bytes + 16, base_offset, n_bases, len, canonical,
+                                   ws->d_out, n_pos, reinterpret_cast<uint64_t *>(ws->d_vals));
+    if (r) return r;
+    MM_HIP(hipMemcpyAsync(values, ws->d_vals, n_pos * sizeof(uint64_t), hipMemcpyDeviceToHost, ws->stream));
+    MM_HIP(hipStreamSynchronize(ws->stream));
+    return MM_OK;
+}
+
+int mm_pack_ascii_device_async(mm_workspace_t *ws, const uint8_t *d_ascii, uint64_t n_bases,
+                               uint8_t *d_packed) {
+    if (!ws) return MM_ERR_NULL;
+    if (n_bases == 0) return MM_OK;
+    if (!d_ascii || !d_packed) return MM_ERR_NULL;
+    MM_HIP(hipSetDevice(ws->device));
+    if (mm::launch_pack_ascii(d_ascii, n_bases, d_packed, ws->stream))
+        return hip_fail(hipGetLastError(), "pack_ascii");
+    return MM_OK;
+}
+
+int mm_generate_device_async(mm_workspace_t *ws, uint64_t seed, uint64_t first_base,
+                             uint64_t n_bases, uint8_t *d_packed) {
+    if (!ws) return MM_ERR_NULL;
+    if (n_bases == 0) return MM_OK;
+    if (!d_packed) return MM_ERR_NULL;
+    MM_HIP(hipSetDevice(ws->device));
+    if (mm::launch_generate(seed, first_base, n_bases, d_packed, ws->stream))
+        return hip_fail(hipGetLastError(), "generate");
+    return MM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+// mm_common.h — shared device-side definitions of the gfx950 minimizer engine.
+//
+// Reference semantics (rust-seq/simd-minimizers v3.0.0, paths relative to /root/reference):
+//   key of a k-mer      = (hash & 0xffff0000) | pos16            src/sliding_min.rs:104-127
+//   right-most variant  = (~hash & 0xffff0000) | pos16 with MAX  src/sliding_min.rs:196-197
+//   strand vote         = #(T|G) in the l-base window > l/2      src/canonical.rs:18-29
+//   dedup               = drop ADJACENT equal positions          src/collect.rs:15-37
+//   syncmer filter      = minpos in {i, i+w-1} / == i + w/2      src/syncmers.rs:33-37
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mm {
+
+constexpr int kBlockThreads = 256;
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = kBlockThreads / kWave;
+
+// Rolling ntHash tables prepared on the host for one (hasher, k):
+//   fw' = rotl(fw, rot) ^ t_in_out[out][in].x ;  rc' = rotr(rc, rot) ^ t_in_out[out][in].y
+//   warm-up (no base leaves yet): the same with t_in[in]
+struct HashTables {
+    uint2 t_in_out[16];  // index = (out << 2) | in
+    uint2 t_in[4];
+    uint32_t rot;
+    uint32_t canonical;  // 1: h = fw + rc, 0: h = fw
+};
+
+// A PackedSeq seen as little-endian dwords: base i of the sequence sits at
+// bits 2*((base0 + i) % 16) of dword (base0 + i) / 16.
+struct SeqView {
+    const uint32_t *d;
+    uint32_t n_dwords;  // readable dwords (loads are clamped to [0, n_dwords))
+    uint32_t base0;
+    uint32_t n_bases;
+};
+
+struct OutParams {
+    uint32_t *pos;
+    uint32_t *sk;  // may be null
+    unsigned long long cap;
+    unsigned long long *total;   // device counter: running total of outputs
+    unsigned long long *status;  // decoupled look-back words, one per block, zeroed per launch
+    uint32_t *ticket;            // dynamic block id counter, zeroed per launch
+};
+
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, uint32_t r) {
+    return __builtin_amdgcn_alignbit(x, x, (32u - r) & 31u);
+}
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, uint32_t r) {
+    return __builtin_amdgcn_alignbit(x, x, r & 31u);
+}
+
+__device__ __forceinline__ uint32_t load_dword_clamped(const SeqView &s, long long q) {
+    long long hi = (long long)s.n_dwords - 1;
+    q = q < 0 ? 0 : (q > hi ? hi : q);
+    return s.d[q];
+}
+// 2-bit code of the base at absolute position p (in dword-array coordinates)
+__device__ __forceinline__ uint32_t base_at(const SeqView &s, long long p) {
+    uint32_t wd = load_dword_clamped(s, p >> 4);
+    return (wd >> (2u * (uint32_t)(p & 15))) & 3u;
+}
+
+// ---------------------------------------------------------------- wave scan
+// inclusive prefix sum over the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, kWave);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// ------------------------------------------------- decoupled look-back scan
+// status word: bits 63..62 = flag (1 aggregate, 2 inclusive prefix), low 62 bits = value.
+// One naturally aligned 8-byte word carries flag and value together, so no fence is
+// needed: both sides use relaxed agent-scope atomics (cross-XCD safe on gfx950).
+constexpr unsigned long long kFlagAgg = 1ull << 62;
+constexpr unsigned long long kFlagIncl = 2ull << 62;
+constexpr unsigned long long kValMask = (1ull << 62) - 1;
+
+__device__ __forceinline__ unsigned long long ld_status(unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_status(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by ALL threads of wave 0 of the block (uniformly). `bid` is the dynamic
+// block id, `block_total` this block's output count, `carry_in` the count produced
+// before this launch (only used by block 0). Returns the exclusive prefix.
+__device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long long *status,
+                                                                 uint32_t bid,
+                                                                 unsigned long long block_total,
+                                                                 unsigned long long carry_in) {
+    const int lane = threadIdx.x & (kWave - 1);
+    if (bid == 0) {
+        if (lane == 0) st_status(&status[0], kFlagIncl | ((carry_in + block_total) & kValMask));
+        return carry_in;
+    }
+    if (lane == 0) st_status(&status[bid], kFlagAgg | (block_total & kValMask));
+    unsigned long long excl = 0;
+    long long j = (long long)bid - 1;
+    while (true) {
+        long long idx = j - lane;
+        unsigned long long s;
+        if (idx >= 0) {
+            s = ld_status(&status[idx]);
+            while ((s >> 62) == 0) {
+                __builtin_amdgcn_s_sleep(1);
+                s = ld_status(&status[idx]);
+            }
+        } else {
+            s = kFlagIncl;  // virtual predecessor of block 0 (never reached: block 0 is inclusive)
+        }
+        unsigned long long incl_mask = __ballot((s >> 62) == 2);
+        int first = incl_mask ? __builtin_ctzll(incl_mask) : kWave;
+        unsigned long long v = (lane <= first) ? (s & kValMask) : 0ull;
+        // wave reduce (64-bit)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+        excl += v;
+        if (incl_mask) break;
+        j -= kWave;
+    }
+    if (lane == 0) st_status(&status[bid], kFlagIncl | ((excl + block_total) & kValMask));
+    return excl;
+}
+
+}  // namespace mm

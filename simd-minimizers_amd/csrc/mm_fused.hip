@@ -1,0 +1,110 @@
+// mm_fused.hip — instantiations and launcher of the fused kernel (mm_fused_impl.h).
+//
+// The kernel is specialised per window size w (the sliding-min ring lives in w registers);
+// k and the hasher tables are runtime parameters.  Window sizes without an instance fall
+// back to the generic family (mm_generic.hip) — still HIP, never the CPU.
+#include "mm_fused_impl.h"
+#include "mm_launch.h"
+
+namespace mm {
+
+namespace {
+
+using KernelFn = void (*)(const FusedParams);
+
+struct Instance {
+    uint32_t w;
+    bool canon;
+    bool hash_rc;
+    KernelFn fn;
+};
+
+#define MM_INST(W, C, R) \
+    { W, C, R, &fused_kernel<W, C, R> }
+
+// canonical windows (canonical hasher) and forward windows (forward hasher)
+const Instance kInstances[] = {
+    MM_INST(11, true, true),  MM_INST(51, true, true),  MM_INST(17, true, true),
+    MM_INST(7, true, true),   MM_INST(5, true, true),   MM_INST(19, true, true),
+    MM_INST(11, false, false), MM_INST(7, false, false), MM_INST(5, false, false),
+    MM_INST(19, false, false), MM_INST(17, false, false),
+};
+
+const Instance *find_instance(uint32_t w, int canonical_windows, int hasher_canonical) {
+    for (const Instance &i : kInstances)
+        if (i.w == w && i.canon == (canonical_windows != 0) && i.hash_rc == (hasher_canonical != 0))
+            return &i;
+    return nullptr;
+}
+
+uint32_t default_nblk(uint32_t w) {
+    // about 136 windows per lane: tile bytes + staged input stay near 42 KB (3 workgroups / CU)
+    uint32_t n = (136u + w / 2u) / w;
+    return n ? n : 1u;
+}
+
+struct Geometry {
+    uint32_t nblk, S, NB, n_in_dwords, lds_in_off, lds_tab_off, lds_bytes;
+    uint64_t nblocks;
+};
+
+Geometry geometry(const RunArgs &a) {
+    Geometry g;
+    g.nblk = a.nblk ? a.nblk : default_nblk(a.w);
+    g.S = a.w * g.nblk;
+    g.NB = kBlockThreads * g.S;
+    const uint32_t nsub = (a.w + 15u) / 16u;
+    g.n_in_dwords = (g.NB + a.k + 16u * nsub + 15u) / 16u + 3u;
+    g.lds_in_off = (g.NB + 15u) & ~15u;
+    g.lds_tab_off = g.lds_in_off + ((4u * g.n_in_dwords + 15u) & ~15u);
+    g.lds_bytes = g.lds_tab_off + 20u * (uint32_t)sizeof(uint2);
+    const uint64_t nwin = a.win_end - a.win_begin;
+    g.nblocks = (nwin + g.NB - 1) / g.NB;
+    return g;
+}
+
+}  // namespace
+
+bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_canonical) {
+    (void)k;
+    return find_instance(w, canonical_windows, hasher_canonical) != nullptr;
+}
+
+uint64_t fused_status_words(const RunArgs &a) { return geometry(a).nblocks + 1; }
+
+int launch_fused(const RunArgs &a, hipStream_t stream) {
+    const Instance *inst = find_instance(a.w, a.canonical_windows, (int)a.ht.canonical);
+    if (!inst) return -2;
+    const Geometry g = geometry(a);
+    if (g.nblocks == 0) return 0;
+    if (g.lds_bytes > 160u * 1024u) return -3;
+
+    FusedParams p;
+    p.seq = a.seq;
+    p.ht = a.ht;
+    p.k = a.k;
+    p.nblk = g.nblk;
+    p.win_begin = (uint32_t)a.win_begin;
+    p.win_end = (uint32_t)a.win_end;
+    p.mode = a.mode;
+    p.n_in_dwords = g.n_in_dwords;
+    p.lds_in_off = g.lds_in_off;
+    p.lds_tab_off = g.lds_tab_off;
+    p.out = a.out;
+
+    if (g.lds_bytes > 64u * 1024u) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(inst->fn),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)g.lds_bytes) != hipSuccess)
+            return -1;
+    }
+    if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * g.nblocks, stream) != hipSuccess)
+        return -1;
+    if (hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
+    if (a.timing_start) hipEventRecord(a.timing_start, stream);
+    hipLaunchKernelGGL(inst->fn, dim3((uint32_t)g.nblocks), dim3(kBlockThreads), g.lds_bytes, stream, p);
+    if (a.timing_stop) hipEventRecord(a.timing_stop, stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace mm

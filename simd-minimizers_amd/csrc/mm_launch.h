@@ -1,0 +1,44 @@
+// mm_launch.h — host-side launch interface between the C ABI (mm_api.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mm_common.h"
+
+namespace mm {
+
+struct RunArgs {
+    SeqView seq;
+    HashTables ht;
+    uint32_t k, w;
+    int canonical_windows;
+    uint32_t mode;  // 0 minimizers, 1 closed syncmers, 2 open syncmers
+    uint64_t win_begin, win_end;
+    OutParams out;
+    // fused path
+    uint32_t nblk;  // w-blocks per lane (0 = default)
+    // generic path
+    void *scratch;
+    uint64_t generic_round_windows;
+    // optional HIP events recorded right around the dominant kernel
+    hipEvent_t timing_start, timing_stop;
+};
+
+// ---- fused family (mm_fused_*.hip): one kernel, specialised per w
+bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_canonical);
+uint64_t fused_status_words(const RunArgs &a);
+int launch_fused(const RunArgs &a, hipStream_t stream);
+
+// ---- generic family (mm_generic.hip): any k / w
+uint64_t generic_scratch_bytes(uint64_t round_windows, uint32_t w);
+uint64_t generic_status_words(uint64_t round_windows);
+int launch_generic(const RunArgs &a, hipStream_t stream);
+
+// ---- auxiliary kernels (mm_aux.hip)
+int launch_values_u64(SeqView seq, uint32_t len, int canonical, const uint32_t *d_pos,
+                      uint64_t n_pos, unsigned long long *d_values, hipStream_t stream);
+int launch_pack_ascii(const uint8_t *d_ascii, uint64_t n, uint8_t *d_packed, hipStream_t stream);
+int launch_generate(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d_packed,
+                    hipStream_t stream);
+
+}  // namespace mm

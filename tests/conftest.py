@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import mm_oracle
+    mm_oracle.lib()
+    return mm_oracle
+
+
+@pytest.fixture(scope="session")
+def sm():
+    """The product package; on a GPU box the HIP library must be present and is the only path."""
+    import simd_minimizers_amd
+    simd_minimizers_amd.lib()
+    return simd_minimizers_amd
+
+
+@pytest.fixture(scope="session")
+def gpu(sm):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return sm.default_workspace(0)

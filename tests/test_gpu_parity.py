@@ -1,0 +1,254 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
+
+Mirrors the reference's test strategy (src/test.rs): known-answer vectors, a (k, w, len,
+offset) sweep with naive == product on packed and ASCII input, super-k-mer indices, syncmers,
+the reverse-complement metamorphic test, k-mer values — plus large-size runs and the
+window-range sharding property the multi-GPU path relies on.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _packed(sm, oracle, n, seed):
+    data = oracle.gen_packed(seed, n)
+    return sm.PackedSeq(data, 0, n)
+
+
+def _builder(sm, k, w, canonical, mode):
+    return sm.Builder(k, w, canonical, mode)
+
+
+# ------------------------------------------------------------- known answers
+def test_reference_known_answers(sm, oracle, gpu):
+    ref = json.load(open(os.path.join(GOLD, "reference_vectors.json")))
+    for case in ref["minimizers"]:
+        seq = case["seq"].encode()
+        ps = sm.PackedSeqVec.from_ascii(seq)
+        if case.get("revcomp_input"):
+            ps = ps.to_revcomp()
+        b = _builder(sm, case["k"], case["w"], case["canonical"], case["mode"])
+        for force_generic in (False, True):
+            gpu.force_generic(force_generic)
+            pos: list = []
+            out = b.run(ps, pos)
+            assert pos == case["positions"], (case["source"], force_generic)
+            if "values_u64" in case:
+                assert list(map(int, out.values_u64())) == case["values_u64"]
+            if not case.get("revcomp_input"):
+                assert b.run_once(sm.AsciiSeq(seq)) == case["positions"]
+        gpu.force_generic(False)
+
+
+def test_closed_syncmer_values_all_g(sm, gpu):
+    # src/test.rs:576-597
+    n = 100
+    ps = sm.PackedSeqVec.from_ascii(b"G" * n)
+    for k in range(1, 10):
+        for w in range(1, 10):
+            pos: list = []
+            out = sm.closed_syncmers(k, w).run(ps, pos)
+            vals = out.values_u64()
+            l = k + w - 1
+            assert len(vals) == n - l + 1
+            assert all(int(v) == (1 << (2 * l)) - 1 for v in vals)
+
+
+def test_model_anchors_1mbp(sm, oracle, gpu):
+    anchors = json.load(open(os.path.join(GOLD, "model_anchors.json")))
+    n, seed = anchors["generator"]["n"], anchors["generator"]["seed"]
+    ps = _packed(sm, oracle, n, seed)
+    for c in anchors["cases"]:
+        b = _builder(sm, c["k"], c["w"], c["canonical"], c["mode"])
+        pos, _ = b._run_arrays(ps)
+        assert len(pos) == c["count"], c["name"]
+        assert [int(x) for x in pos[:8]] == c["first8"], c["name"]
+        assert oracle.checksum(pos) == (c["checksum_weighted"], c["checksum_plain"]), c["name"]
+
+
+# ------------------------------------------------------------------- sweeps
+FUSED_W = {True: [5, 7, 11, 17, 19, 51], False: [5, 7, 11, 17, 19]}
+
+
+def _sweep_inputs(rng, oracle, sm):
+    data = oracle.gen_packed(int(rng.integers(1 << 30)), 8192 + 8)
+    lens = list(range(0, 100, 7)) + [int(x) for x in rng.integers(100, 8192, size=4)]
+    for ln in lens:
+        off = int(rng.integers(0, min(3, ln) + 1))
+        yield sm.PackedSeq(data, off, ln - off), data, off, ln - off
+
+
+@pytest.mark.parametrize("canonical", [False, True])
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_sweep_minimizers(sm, oracle, gpu, canonical, force_generic):
+    """src/test.rs:53-110: naive definition == product for every (k, w, len, slice offset)."""
+    rng = np.random.default_rng(1234 + canonical)
+    ks = [1, 2, 3, 4, 5, 21, 31, 32, 33, 63, 64, 65] + [int(x) for x in rng.integers(6, 100, size=3)]
+    ws = [1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65] + [int(x) for x in rng.integers(6, 100, size=3)]
+    if not force_generic:
+        ws = FUSED_W[canonical]
+    gpu.force_generic(force_generic)
+    try:
+        for k in ks:
+            for w in ws:
+                if canonical and (k + w - 1) % 2 == 0:
+                    continue
+                b = _builder(sm, k, w, canonical, 0)
+                for ps, data, off, n in _sweep_inputs(rng, oracle, sm):
+                    want = oracle.run(data, n, k, w, canonical=canonical, flavour=oracle.NAIVE,
+                                      base_offset=off)
+                    got, _ = b._run_arrays(ps)
+                    assert np.array_equal(got, want), f"k={k} w={w} n={n} off={off} generic={force_generic}"
+                    if n >= k + w - 1:
+                        assert gpu.last_path() == (sm.PATH_GENERIC if force_generic else sm.PATH_FUSED)
+    finally:
+        gpu.force_generic(False)
+
+
+@pytest.mark.parametrize("canonical", [False, True])
+def test_sweep_superkmers(sm, oracle, gpu, canonical):
+    """src/test.rs:154-277: positions and super-k-mer start indices."""
+    rng = np.random.default_rng(99 + canonical)
+    for force_generic in (False, True):
+        gpu.force_generic(force_generic)
+        try:
+            for k, w in [(5, 7), (21, 11), (31, 19), (4, 5), (15, 17)]:
+                if canonical and (k + w - 1) % 2 == 0:
+                    continue
+                for ps, data, off, n in _sweep_inputs(rng, oracle, sm):
+                    wp, wsk = oracle.run(data, n, k, w, canonical=canonical, base_offset=off,
+                                         super_kmers=True)
+                    sk: list = []
+                    b = _builder(sm, k, w, canonical, 0).super_kmers(sk)
+                    pos = b.run_once(ps)
+                    assert pos == list(map(int, wp)) and sk == list(map(int, wsk)), (k, w, n, off)
+        finally:
+            gpu.force_generic(False)
+
+
+@pytest.mark.parametrize("canonical", [False, True])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_sweep_syncmers(sm, oracle, gpu, canonical, mode):
+    """src/test.rs:517-574, 599-640: syncmer window indices, open and closed."""
+    rng = np.random.default_rng(7 + canonical + 2 * mode)
+    for force_generic in (False, True):
+        gpu.force_generic(force_generic)
+        try:
+            for k, w in [(5, 7), (15, 17), (3, 5), (21, 11), (8, 19), (2, 33)]:
+                if canonical and (k + w - 1) % 2 == 0:
+                    continue
+                if mode == 2 and w % 2 == 0:
+                    continue
+                b = _builder(sm, k, w, canonical, mode)
+                for ps, data, off, n in _sweep_inputs(rng, oracle, sm):
+                    want = oracle.run(data, n, k, w, canonical=canonical, mode=mode,
+                                      flavour=oracle.NAIVE, base_offset=off)
+                    got, _ = b._run_arrays(ps)
+                    assert np.array_equal(got, want), (k, w, n, off, force_generic)
+        finally:
+            gpu.force_generic(False)
+
+
+def test_revcomp_metamorphic(sm, oracle, gpu):
+    """src/test.rs:112-152: pos_fwd[i] + pos_rc[-1-i] == len - k and equal values."""
+    rng = np.random.default_rng(5)
+    for k, w in [(5, 7), (21, 11), (31, 51), (15, 17)]:
+        for n in (0, 50, 200, 4097):
+            ps = sm.PackedSeqVec.random(n, seed=int(rng.integers(1 << 30)))
+            rc = ps.to_revcomp()
+            b = sm.canonical_minimizers(k, w)
+            fp: list = []
+            rp: list = []
+            fv = b.run(ps, fp).values_u64() if k <= 32 else None
+            rv = b.run(rc, rp).values_u64() if k <= 32 else None
+            assert len(fp) == len(rp)
+            for x, y in zip(fp, reversed(rp)):
+                assert x + y == n - k
+            if fv is not None:
+                assert np.array_equal(fv, rv[::-1])
+
+
+def test_append_semantics(sm, gpu):
+    """`run` appends; a leading duplicate of out_vec.last() is dropped (src/collect.rs:265-271)."""
+    ps = sm.PackedSeqVec.from_ascii(b"ACGTGCTCAGAGACTCAGAGGA")
+    out = [123, 0]
+    sm.canonical_minimizers(5, 7).run(ps, out)
+    assert out == [123, 0, 7, 9, 15]
+
+
+# ---------------------------------------------------------------- large sizes
+@pytest.mark.parametrize("k,w,canonical,mode", [(21, 11, False, 0), (21, 11, True, 0), (31, 51, True, 0),
+                                                (15, 17, True, 1), (5, 7, False, 0)])
+def test_large_device_vs_oracle(sm, oracle, gpu, k, w, canonical, mode):
+    """16 Mbp device-resident run, every position compared with the streaming oracle."""
+    import torch
+    n = 16_000_003
+    data = oracle.gen_packed(11, n)
+    want = oracle.run(data, n, k, w, canonical=canonical, mode=mode)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    b = _builder(sm, k, w, canonical, mode)
+    cnt = b.run_device(d, n, out)
+    assert gpu.last_path() == sm.PATH_FUSED
+    got = out[:cnt].cpu().numpy().view(np.uint32)
+    assert cnt == len(want)
+    assert np.array_equal(got, want)
+    # the generic family must agree on the device too
+    gpu.force_generic(True)
+    try:
+        out.zero_()
+        cnt2 = b.run_device(d, n, out)
+        assert cnt2 == cnt and np.array_equal(out[:cnt2].cpu().numpy().view(np.uint32), want)
+    finally:
+        gpu.force_generic(False)
+
+
+def test_window_range_sharding(sm, oracle, gpu):
+    """Concatenating window-range shards reproduces the whole-sequence output exactly
+    (this is what the multi-GPU path does; seam rule of src/collect.rs:265-271)."""
+    import torch
+    n, k, w = 3_000_017, 21, 11
+    data = oracle.gen_packed(21, n)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for canonical, mode in [(True, 0), (False, 0), (True, 1)]:
+        b = _builder(sm, k, w, canonical, mode)
+        whole = out[:b.run_device(d, n, out)].cpu().numpy().copy()
+        nw = n - (k + w - 1) + 1
+        cuts = [0, 1, 1000, nw // 3 + 5, nw // 2, nw - 1, nw]
+        parts = []
+        for a, e in zip(cuts[:-1], cuts[1:]):
+            c = b.run_device(d, n, out, win_begin=a, win_end=e)
+            parts.append(out[:c].cpu().numpy().copy())
+        assert np.array_equal(np.concatenate(parts), whole), (canonical, mode)
+
+
+def test_unaligned_device_pointer(sm, oracle, gpu):
+    """Device buffers at any byte alignment and base offset (PackedSeq slices, src/test.rs:42-45)."""
+    import torch
+    n, k, w = 100_003, 21, 11
+    data = oracle.gen_packed(3, n + 64)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for byte_off in (0, 1, 2, 3, 5):
+        for base_off in (0, 1, 3, 7):
+            nb = n - 4 * byte_off - base_off
+            want = oracle.run(data, nb, k, w, canonical=True, base_offset=4 * byte_off + base_off)
+            c = sm.canonical_minimizers(k, w).run_device(d[byte_off:], nb, out, base_offset=base_off)
+            assert np.array_equal(out[:c].cpu().numpy().view(np.uint32), want), (byte_off, base_off)
+
+
+def test_capacity_error(sm, oracle, gpu):
+    import torch
+    n = 100_000
+    d = torch.from_numpy(oracle.gen_packed(4, n)).cuda()
+    out = torch.zeros(10, dtype=torch.int32, device="cuda")
+    with pytest.raises(sm.MinimizerError) as e:
+        sm.minimizers(21, 11).run_device(d, n, out)
+    assert e.value.code == sm.ERR["CAPACITY"]
