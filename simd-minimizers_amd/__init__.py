@@ -64,6 +64,12 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:
+            # PyTorch-ROCm bundles its own libamdhip64.so.7; load it first so that the engine and
+            # torch share ONE HIP runtime (same SONAME) whatever the import order.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         u8p, u32p, u64p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_void_p
         L.mm_strerror.restype = C.c_char_p
