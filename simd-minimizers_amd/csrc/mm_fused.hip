@@ -6,6 +6,8 @@
 #include "mm_fused_impl.h"
 #include "mm_launch.h"
 
+#include <cstdlib>
+
 namespace mm {
 
 namespace {
@@ -16,11 +18,11 @@ struct Instance {
     uint32_t w;
     bool canon;
     bool hash_rc;
-    KernelFn fn;
+    KernelFn fn[3];  // per mode: minimizers, closed syncmers, open syncmers
 };
 
 #define MM_INST(W, C, R) \
-    { W, C, R, &fused_kernel<W, C, R> }
+    { W, C, R, { &fused_kernel<W, C, R, 0>, &fused_kernel<W, C, R, 1>, &fused_kernel<W, C, R, 2> } }
 
 // canonical windows (canonical hasher) and forward windows (forward hasher)
 const Instance kInstances[] = {
@@ -44,7 +46,7 @@ uint32_t default_nblk(uint32_t w) {
 }
 
 struct Geometry {
-    uint32_t nblk, S, NB, n_in_dwords, lds_in_off, lds_tab_off, lds_bytes;
+    uint32_t nblk, S, NB, lds_fl_off, lds_stage_off, lds_bytes;
     uint64_t nblocks;
 };
 
@@ -53,11 +55,12 @@ Geometry geometry(const RunArgs &a) {
     g.nblk = a.nblk ? a.nblk : default_nblk(a.w);
     g.S = a.w * g.nblk;
     g.NB = kBlockThreads * g.S;
-    const uint32_t nsub = (a.w + 15u) / 16u;
-    g.n_in_dwords = (g.NB + a.k + 16u * nsub + 15u) / 16u + 3u;
-    g.lds_in_off = (g.NB + 15u) & ~15u;
-    g.lds_tab_off = g.lds_in_off + ((4u * g.n_in_dwords + 15u) & ~15u);
-    g.lds_bytes = g.lds_tab_off + 20u * (uint32_t)sizeof(uint2);
+    const bool nib = a.w <= 16u;
+    const uint32_t offb = nib ? (a.w + 1u) / 2u : a.w;
+    const uint32_t flbytes = nib ? 2u : 4u * ((a.w + 31u) / 32u);
+    g.lds_fl_off = (kBlockThreads * g.nblk * offb + 15u) & ~15u;
+    g.lds_stage_off = g.lds_fl_off + ((kBlockThreads * g.nblk * flbytes + 15u) & ~15u);
+    g.lds_bytes = g.lds_stage_off + kWavesPerBlock * kStageCap * 2u;
     const uint64_t nwin = a.win_end - a.win_begin;
     g.nblocks = (nwin + g.NB - 1) / g.NB;
     return g;
@@ -77,7 +80,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     if (!inst) return -2;
     const Geometry g = geometry(a);
     if (g.nblocks == 0) return 0;
-    if (g.lds_bytes > 160u * 1024u) return -3;
+    if (g.lds_bytes > 159u * 1024u) return -3;
 
     FusedParams p;
     p.seq = a.seq;
@@ -86,14 +89,18 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.nblk = g.nblk;
     p.win_begin = (uint32_t)a.win_begin;
     p.win_end = (uint32_t)a.win_end;
-    p.mode = a.mode;
-    p.n_in_dwords = g.n_in_dwords;
-    p.lds_in_off = g.lds_in_off;
-    p.lds_tab_off = g.lds_tab_off;
+    p.lds_fl_off = g.lds_fl_off;
+    p.lds_stage_off = g.lds_stage_off;
     p.out = a.out;
+    {
+        const char *dbg = getenv("MM_DEBUG");
+        p.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
+    }
+    if (a.mode > 2) return -2;
+    KernelFn fn = inst->fn[a.mode];
 
     if (g.lds_bytes > 64u * 1024u) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(inst->fn),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)g.lds_bytes) != hipSuccess)
             return -1;
@@ -102,7 +109,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         return -1;
     if (hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
     if (a.timing_start) hipEventRecord(a.timing_start, stream);
-    hipLaunchKernelGGL(inst->fn, dim3((uint32_t)g.nblocks), dim3(kBlockThreads), g.lds_bytes, stream, p);
+    hipLaunchKernelGGL(fn, dim3((uint32_t)g.nblocks), dim3(kBlockThreads), g.lds_bytes, stream, p);
     if (a.timing_stop) hipEventRecord(a.timing_stop, stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -2,26 +2,33 @@
 //
 // Formulation (MI355X-first, not a translation of the reference's 8-lane loop):
 //
-//   phase 0  the workgroup (256 lanes = 4 wave64) stages the 2-bit bases of its tile of
-//            NB = 256*S windows (+ k+w halo) into LDS with coalesced dword loads.
-//   phase 1  every lane walks S = nblk*W consecutive windows serially, everything in
-//            registers: rolling ntHash through one LDS table look-up per base
-//            (t_in_out[(out<<2)|in], 16 x uint2), keys (hash_hi16 | pos16) for the leftmost
-//            minimum and the complemented key for the rightmost one, two-stacks sliding
-//            minimum over blocks of W with the ring held in W registers (W is a template
-//            parameter), incremental strand vote.  One byte per window -- the offset of the
-//            chosen k-mer inside its window -- goes to LDS.  Reference semantics:
-//            src/sliding_min.rs:86-212, src/canonical.rs:12-31, src/minimizers.rs:117-128.
-//   phase 2  lane-parallel over the tile's window bytes: SWAR predicate (adjacent dedup
-//            src/collect.rs:15-37, or the syncmer filter src/syncmers.rs:33-37), ordered
-//            compaction (wave scan), a decoupled look-back scan across workgroups for the
-//            global output offset, and the u32 stores.  Output order == window order.
+//   phase 1  every lane of a 256-lane workgroup walks S = nblk*W consecutive windows serially,
+//            everything in registers.  The lane's 2-bit bases come straight from HBM/L2 through
+//            bounds-checked raw buffer loads (three funnel-shifted 16-base views per W-block:
+//            base entering the hash, base leaving the hash, base leaving the strand window),
+//            prefetched one W-block ahead.  Rolling ntHash costs ONE LDS table look-up per base
+//            (s_tab[(out<<2)|in], 16 x uint2 = forward / reverse-complement contribution);
+//            keys are (hash_hi16 | pos16) for the leftmost minimum and the complemented key for
+//            the rightmost one; the two-stacks sliding minimum runs over blocks of W with the
+//            ring held in W registers (W is a template parameter); the strand vote is
+//            incremental.  The lane decides in place whether a window emits (adjacent dedup
+//            against its own previous window, or the syncmer predicate), shifts the flag into a
+//            per-block bit mask, counts it, and stores the offset of the chosen k-mer inside the
+//            window to LDS (4 bits per window when W <= 16, else a byte).  Reference semantics:
+//            src/sliding_min.rs:86-212, src/canonical.rs:12-31, src/minimizers.rs:117-128,
+//            src/collect.rs:15-37, src/syncmers.rs:33-37.
+//   phase 2  each wave compacts the windows of its own 64 lanes: DPP prefix sum over the flag
+//            words, a decoupled look-back across workgroups for the global output offset, window
+//            indices staged in LDS and then written as fully coalesced u32 stores.
+//            Output order == window order.
 //
 // No MFMA: this is integer / byte work bounded by VALU issue and HBM, not GEMM-shaped.
 #pragma once
 #include "mm_common.h"
 
 namespace mm {
+
+constexpr uint32_t kStageCap = 512;  // staged outputs per wave and phase-2 iteration
 
 struct FusedParams {
     SeqView seq;
@@ -30,301 +37,402 @@ struct FusedParams {
     uint32_t nblk;       // W-blocks per lane; S = W * nblk windows per lane
     uint32_t win_begin;  // window range [win_begin, win_end)
     uint32_t win_end;
-    uint32_t mode;
-    uint32_t n_in_dwords;  // staged input dwords per workgroup
-    uint32_t lds_in_off;   // byte offset of the staged input in dynamic LDS
-    uint32_t lds_tab_off;  // byte offset of the hash tables in dynamic LDS
+    uint32_t lds_fl_off;     // byte offset of the flag words in dynamic LDS
+    uint32_t lds_stage_off;  // byte offset of the per-wave staging buffers in dynamic LDS
+    uint32_t debug;          // timing experiments only (MM_DEBUG env): 1 no look-back, 2 no emit,
+                             // 4 no phase 1
     OutParams out;
 };
 
-__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
-    return (a & mask) | (b & ~mask);
+// inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts
+__device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t v) {
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return v;
 }
 
-// bit 7 of each byte set iff that byte of v is zero
-__device__ __forceinline__ uint32_t swar_zero_bytes(uint32_t v) {
-    return ~(((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) & 0x80808080u;
-}
-// compress bits 7,15,23,31 into bits 0..3
-__device__ __forceinline__ uint32_t swar_pack4(uint32_t f) {
-    return (((f >> 7) * 0x00204081u) >> 21) & 0xfu;
-}
-
-// Flags of 16 consecutive windows from their offset bytes.
-//   mode 0: window differs from its predecessor  <=>  off[i] + 1 != off[i-1]
-//   mode 1: closed syncmer                        <=>  off[i] == 0 || off[i] == W-1
-//   mode 2: open syncmer                          <=>  off[i] == W/2
+// Geometry shared by the kernel and its launcher.
 template <int W>
-__device__ __forceinline__ uint32_t window_flags16(const uint4 x, uint32_t prev_byte,
-                                                   uint32_t mode, bool force_first) {
-    const uint32_t X[4] = {x.x, x.y, x.z, x.w};
-    uint32_t f16 = 0;
-    if (mode == 0) {
-        uint32_t prevw = prev_byte << 24;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            uint32_t y = __builtin_amdgcn_alignbit(X[m], prevw, 24);  // (X << 8) | (prev >> 24)
-            uint32_t d = (X[m] + 0x01010101u) ^ y;
-            uint32_t nz = ~swar_zero_bytes(d) & 0x80808080u;
-            f16 |= swar_pack4(nz) << (4 * m);
-            prevw = X[m];
-        }
-        if (force_first) f16 |= 1u;
-    } else if (mode == 1) {
-        constexpr uint32_t kLast = 0x01010101u * (uint32_t)((W - 1) & 0xff);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            uint32_t z = swar_zero_bytes(X[m]) | swar_zero_bytes(X[m] ^ kLast);
-            f16 |= swar_pack4(z) << (4 * m);
-        }
-    } else {
-        constexpr uint32_t kMid = 0x01010101u * (uint32_t)((W / 2) & 0xff);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) f16 |= swar_pack4(swar_zero_bytes(X[m] ^ kMid)) << (4 * m);
-    }
-    return f16;
-}
+struct FusedGeom {
+    static constexpr bool NIB = (W <= 16);               // 4-bit offsets, 16-bit flag words
+    static constexpr int OFFB = NIB ? (W + 1) / 2 : W;   // offset bytes per W-block
+    static constexpr int NSEG = (W + 31) / 32;           // 32-bit flag segments per W-block
+    static constexpr int FLB = NIB ? 2 : 4 * NSEG;       // flag bytes per W-block
+    static constexpr int G = (W <= 32) ? (32 / W) : 1;   // W-blocks combined per phase-2 item
+    static constexpr int NSUB = (W + 15) / 16;           // 16-base view words per W-block
+};
 
-template <int W, bool CANON, bool HASH_RC>
+template <int W, bool CANON, bool HASH_RC, int MODE>
 __global__ __launch_bounds__(kBlockThreads) void fused_kernel(const FusedParams p) {
-    static_assert(W >= 1 && W <= 255, "window offsets are stored as bytes");
+    static_assert(W >= 1 && W <= 255, "window offsets are stored in at most a byte");
+    using GE = FusedGeom<W>;
+    constexpr bool NIB = GE::NIB;
+    constexpr int OFFB = GE::OFFB, NSEG = GE::NSEG, G = GE::G, NSUB = GE::NSUB;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // static LDS: distinct objects, so table look-ups can be scheduled across the dynamic stores
+    __shared__ uint2 s_tab[20];  // [0..15] (out<<2)|in, [16..19] in only (warm-up)
     __shared__ uint32_t s_bid;
-    __shared__ uint32_t s_prev_off;  // offset byte of the window preceding the tile (0x100: none)
     __shared__ uint32_t s_wave_tot[kWavesPerBlock];
     __shared__ unsigned long long s_excl;
 
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     if (tid == 0) s_bid = atomicAdd(p.out.ticket, 1u);
+    if (tid < 16) s_tab[tid] = p.ht.t_in_out[tid];
+    else if (tid < 20) s_tab[tid] = p.ht.t_in[tid - 16];
     __syncthreads();
-    const uint32_t bid = s_bid;
+    const uint32_t bid = __builtin_amdgcn_readfirstlane(s_bid);  // keep tile scalars in SGPRs
 
-    const uint32_t S = (uint32_t)W * p.nblk;
+    const uint32_t nblk = p.nblk;
+    const uint32_t S = (uint32_t)W * nblk;
     const uint32_t NB = kBlockThreads * S;
     const uint64_t bw0 = (uint64_t)p.win_begin + (uint64_t)bid * NB;  // first window of the tile
     const uint32_t nvalid =
         (uint32_t)(((uint64_t)p.win_end - bw0) < NB ? ((uint64_t)p.win_end - bw0) : NB);
+    const bool partial = nvalid < NB;
 
-    uint8_t *offs = smem;
-    uint32_t *inw = reinterpret_cast<uint32_t *>(smem + p.lds_in_off);
-    uint2 *tab = reinterpret_cast<uint2 *>(smem + p.lds_tab_off);  // [0..15] in/out, [16..19] in
-
-    // ---------------------------------------------------------------- phase 0
-    // Element 0 of lane 0 is the k-mer one position before the tile (its window is the
-    // dedup predecessor of the tile's first window).
-    const long long pblk = (long long)p.seq.base0 + (long long)bw0 - 1;
-    const long long q0 = pblk >> 4;
-    const uint32_t rb0 = (uint32_t)(pblk - (q0 << 4));
-    for (uint32_t i = tid; i < p.n_in_dwords; i += kBlockThreads)
-        inw[i] = load_dword_clamped(p.seq, q0 + i);
-    if (tid < 16) tab[tid] = p.ht.t_in_out[tid];
-    else if (tid < 20) tab[tid] = p.ht.t_in[tid - 16];
-    __syncthreads();
+    uint8_t *offs = smem;                          // [256 * nblk * OFFB]
+    uint8_t *flb = smem + p.lds_fl_off;            // [256 * nblk * FLB]
+    uint16_t *stage = reinterpret_cast<uint16_t *>(smem + p.lds_stage_off) + wave * kStageCap;
 
     // ---------------------------------------------------------------- phase 1
     const uint32_t lw = (uint32_t)tid * S;  // first window of this lane, tile-relative
-    if (lw < nvalid) {
-        const uint32_t rot = p.ht.rot;
+    uint32_t my_count = 0;
+    if (lw < nvalid && !(p.debug & 4u)) {
+        // Element 0 of a lane is the k-mer one position before its first window (that window is
+        // the dedup predecessor).  P0 = first base of the tile's element 0 in dword-array
+        // coordinates; it is -1 only for the very first window of an unshifted buffer.
+        const long long P0 = (long long)p.seq.base0 + (long long)bw0 - 1;
+        const long long Q0 = P0 >> 4;
+        const long long Q0c = Q0 < 0 ? 0 : Q0;
+        const int32_t prel0 = (int32_t)(P0 - (Q0c << 4));  // -1 .. 15
+        // Bounds-checked view of the packed sequence from dword Q0c on: dwords past the end read
+        // as 0, so the halo after the last base needs no clamping.
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint32_t *>(p.seq.d + Q0c), 0, (int)(((long long)p.seq.n_dwords - Q0c) * 4), 0x00020000);
+        const int32_t pb = prel0 + (int32_t)lw;  // first base of this lane's element 0
+        // 16-base view starting at tile-relative base position pos >= 0
+        auto view = [&](int32_t pos) -> uint32_t {
+            const auto d = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((uint32_t)pos >> 4) << 2, 0, 0);
+            return __builtin_amdgcn_alignbit(d[1], d[0], 2u * ((uint32_t)pos & 15u));
+        };
+        // same, but pos may be -1 (only at a lane's start): the missing base reads as code 0
+        auto view_first = [&](int32_t pos) -> uint32_t {
+            const bool neg = pos < 0;
+            const auto d = __builtin_amdgcn_raw_buffer_load_b64(rsrc, neg ? 0u : (((uint32_t)pos >> 4) << 2), 0, 0);
+            return __builtin_amdgcn_alignbit(neg ? d[0] : d[1], neg ? 0u : d[0], 2u * ((uint32_t)pos & 15u));
+        };
+
+        const uint32_t rot_l = (32u - p.ht.rot) & 31u;  // alignbit amount for rotl(x, rot)
+        const uint32_t rot_r = p.ht.rot & 31u;
         const uint32_t k = p.k;
-        const uint32_t rb = rb0 + lw;  // staged-base index of the first base of element 0
         uint32_t fw = 0, rc = 0;
-        // hash of element 0: k add-only steps
-        for (uint32_t j = 0; j < k; ++j) {
-            uint32_t pos = rb + j;
-            uint32_t c = (inw[pos >> 4] >> (2u * (pos & 15u))) & 3u;
-            uint2 t = tab[16 + c];
-            fw = rotl32(fw, rot) ^ t.x;
-            if (HASH_RC) rc = rotr32(rc, rot) ^ t.y;
+        const uint8_t *tabb = reinterpret_cast<const uint8_t *>(s_tab);
+
+        // hash of element 0: k add-only steps, 16 bases per view word
+        for (uint32_t g = 0; g * 16u < k; ++g) {
+            const uint32_t wa = g == 0 ? view_first(pb) : view(pb + 16 * (int32_t)g);
+            const uint32_t rem = k - 16u * g;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                if ((uint32_t)jj < rem) {
+                    const uint32_t a8 = (jj == 0 ? (wa << 3) : (jj == 1 ? (wa << 1) : (wa >> (2 * jj - 3)))) & 0x18u;
+                    const uint2 t = *reinterpret_cast<const uint2 *>(tabb + 128 + a8);
+                    fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t.x;
+                    if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t.y;
+                }
+            }
         }
 
         uint32_t ring_l[W], ring_r[W];
-        // stream cursors (staged-base index of the first base the stream yields in this block)
-        uint32_t pos_in = rb + k;   // base entering the hash at step e: rb + k + e
-        uint32_t pos_out = rb;      // base leaving the hash at step e:  rb + e
-        constexpr int NSUB = (W + 15) / 16;
+        int32_t pos_in = pb + (int32_t)k;  // base entering the hash at step e: pb + k + e
+        int32_t pos_out = pb;              // base leaving the hash at step e:  pb + e
+        // 0xffff0000 kept in a VGPR so that (h & mask) | e is one v_and_or_b32 with e in an SGPR
+        uint32_t kmask;
+        asm volatile("v_mov_b32 %0, 0xffff0000" : "=v"(kmask));
 
-        // ---- block 0: fill the ring with the keys of elements 0..W-1 (no complete window yet)
+        uint32_t va[NSUB], vr[NSUB], v2[NSUB];  // views of the block being processed
+#pragma unroll
+        for (int g = 0; g < NSUB; ++g) {
+            va[g] = view(pos_in + 16 * g);
+            vr[g] = g == 0 ? view_first(pos_out) : view(pos_out + 16 * g);
+            v2[g] = 0;
+        }
+
+        // ---- block 0: keys of elements 0..W-1 fill the ring (no complete window yet)
         {
             uint32_t me[NSUB], mo[NSUB];
 #pragma unroll
             for (int g = 0; g < NSUB; ++g) {
-                uint32_t pa = pos_in + 16 * g, pr = pos_out + 16 * g;
-                uint32_t wa = __builtin_amdgcn_alignbit(inw[(pa >> 4) + 1], inw[pa >> 4], 2u * (pa & 15u));
-                uint32_t wr = __builtin_amdgcn_alignbit(inw[(pr >> 4) + 1], inw[pr >> 4], 2u * (pr & 15u));
-                me[g] = bfi(0x33333333u, wa, wr << 2);
-                mo[g] = bfi(0x33333333u, wa >> 2, wr);
-            }
-#pragma unroll
-            for (int j = 0; j < W; ++j) {
-                const uint32_t h = HASH_RC ? fw + rc : fw;
-                const uint32_t kl = (h & 0xffff0000u) | (uint32_t)j;
-                ring_l[j] = kl;
-                if (CANON) ring_r[j] = kl ^ 0xffff0000u;
-                const int jj = j & 15, g = j >> 4, m = jj >> 1;
-                const uint32_t mw = (jj & 1) ? mo[g] : me[g];
-                const uint32_t a8 = (m == 0 ? (mw << 3) : (mw >> (4 * m - 3))) & 0x78u;
-                const uint2 t = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(tab) + a8);
-                fw = rotl32(fw, rot) ^ t.x;
-                if (HASH_RC) rc = rotr32(rc, rot) ^ t.y;
-            }
-#pragma unroll
-            for (int j = W - 2; j >= 0; --j) {
-                ring_l[j] = min(ring_l[j], ring_l[j + 1]);
-                if (CANON) ring_r[j] = max(ring_r[j], ring_r[j + 1]);
+                me[g] = (va[g] & 0x33333333u) | ((vr[g] << 2) & 0xccccccccu);
+                mo[g] = ((va[g] >> 2) & 0x33333333u) | (vr[g] & 0xccccccccu);
             }
             pos_in += W;
             pos_out += W;
-        }
-
-        // strand vote state: cnt = #(T|G) in the l bases of the window about to complete
-        int cnt = 0;
-        const uint32_t l = k + (uint32_t)W - 1;
-        const int thr = (int)(l / 2);
-        if (CANON) {
-            // window -1 covers staged bases [rb, rb + l)
-            uint32_t c = 0;
-            for (uint32_t q = rb >> 4; q <= (rb + l - 1) >> 4; ++q) {
-                uint32_t wd = inw[q] & 0xAAAAAAAAu;
-                uint32_t lo = q << 4;
-                if (lo < rb) wd &= ~0u << (2u * (rb - lo));
-                if (lo + 16 > rb + l) wd &= ~0u >> (2u * (lo + 16 - (rb + l)));
-                c += __popc(wd);
-            }
-            cnt = (int)c;
-        }
-        if (tid == 0) {
-            // predecessor window of the tile: the minimum of block 0
-            uint32_t sel = ring_l[0];
-            if (CANON) sel = (cnt > thr) ? ring_l[0] : ring_r[0];
-            s_prev_off = (bw0 == 0) ? 0x100u : (sel & 0xffffu);
-        }
-        uint32_t pos_r2 = rb;  // base leaving the strand window after window i: rb + i + 1 ... see below
-        if (CANON) {
-            // move cnt from window -1 to window 0: + base rb+l, - base rb
-            uint32_t pa = rb + l;
-            cnt += (int)((inw[pa >> 4] >> (2u * (pa & 15u) + 1u)) & 1u);
-            cnt -= (int)((inw[rb >> 4] >> (2u * (rb & 15u) + 1u)) & 1u);
-            pos_r2 = rb + 1;  // window 0 -> 1 drops base rb+1
-        }
-
-        // ---- blocks 1..nblk: one window per step
-        uint8_t *my_offs = offs + lw;
-        for (uint32_t b = 1; b <= p.nblk; ++b) {
-            uint32_t me[NSUB], mo[NSUB], wa_[NSUB], w2_[NSUB];
+            // prefetch block 1 (its strand stream starts at pb + 1)
 #pragma unroll
             for (int g = 0; g < NSUB; ++g) {
-                uint32_t pa = pos_in + 16 * g, pr = pos_out + 16 * g;
-                uint32_t wa = __builtin_amdgcn_alignbit(inw[(pa >> 4) + 1], inw[pa >> 4], 2u * (pa & 15u));
-                uint32_t wr = __builtin_amdgcn_alignbit(inw[(pr >> 4) + 1], inw[pr >> 4], 2u * (pr & 15u));
-                me[g] = bfi(0x33333333u, wa, wr << 2);
-                mo[g] = bfi(0x33333333u, wa >> 2, wr);
-                if (CANON) {
-                    uint32_t p2 = pos_r2 + 16 * g;
-                    wa_[g] = wa;
-                    w2_[g] = __builtin_amdgcn_alignbit(inw[(p2 >> 4) + 1], inw[p2 >> 4], 2u * (p2 & 15u));
-                }
+                va[g] = view(pos_in + 16 * g);
+                vr[g] = view(pos_out + 16 * g);
+                if (CANON) v2[g] = view(pb + 1 + 16 * g);
             }
-            const uint32_t e0 = b * (uint32_t)W;  // element index of step j = 0
-            uint32_t pl = 0, pr_ = 0;
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 const uint32_t h = HASH_RC ? fw + rc : fw;
-                const uint32_t kl = (h & 0xffff0000u) | (e0 + (uint32_t)j);
-                const uint32_t kr = kl ^ 0xffff0000u;
-                pl = (j == 0) ? kl : min(pl, kl);
-                uint32_t sel = (j + 1 < W) ? min(pl, ring_l[(j + 1 < W) ? j + 1 : 0]) : pl;
+                const uint32_t kl = (h & kmask) | (uint32_t)j;
                 ring_l[j] = kl;
-                if (CANON) {
-                    pr_ = (j == 0) ? kr : max(pr_, kr);
-                    uint32_t selr = (j + 1 < W) ? max(pr_, ring_r[(j + 1 < W) ? j + 1 : 0]) : pr_;
-                    ring_r[j] = kr;
-                    sel = (cnt > thr) ? sel : selr;
-                }
-                // window i = e - W starts at element i + 1; offset of the chosen k-mer inside it
-                const uint32_t off = (sel & 0xffffu) - (e0 + (uint32_t)j - (uint32_t)W + 1u);
-                my_offs[(b - 1) * (uint32_t)W + (uint32_t)j] = (uint8_t)off;
-
+                if (CANON) ring_r[j] = kl ^ kmask;
                 const int jj = j & 15, g = j >> 4, m = jj >> 1;
                 const uint32_t mw = (jj & 1) ? mo[g] : me[g];
                 const uint32_t a8 = (m == 0 ? (mw << 3) : (mw >> (4 * m - 3))) & 0x78u;
-                const uint2 t = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint8_t *>(tab) + a8);
-                fw = rotl32(fw, rot) ^ t.x;
-                if (HASH_RC) rc = rotr32(rc, rot) ^ t.y;
-                if (CANON) {
-                    cnt += (int)((wa_[g] >> (2 * jj + 1)) & 1u);
-                    cnt -= (int)((w2_[g] >> (2 * jj + 1)) & 1u);
-                }
+                const uint2 t = *reinterpret_cast<const uint2 *>(tabb + a8);
+                fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t.x;
+                if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t.y;
             }
 #pragma unroll
             for (int j = W - 2; j >= 0; --j) {
                 ring_l[j] = min(ring_l[j], ring_l[j + 1]);
                 if (CANON) ring_r[j] = max(ring_r[j], ring_r[j + 1]);
+            }
+        }
+
+        // strand vote: cnt - (#steps done) = #(T|G) among the l bases of the current window;
+        // each step adds tg(in) + 1 - tg(leaving base), the threshold moves by 1 per step.
+        int cnt = 0;
+        const uint32_t l = k + (uint32_t)W - 1;
+        const int thr = (int)(l / 2);
+        uint32_t prev;             // key of the predecessor window's k-mer (mode 0)
+        int32_t pos_r2 = pb + 1;   // window 0 -> 1 drops base pb + 1
+        if (CANON) {
+            // window -1 covers bases [pb, pb + l)
+            uint32_t c = 0;
+            for (uint32_t g = 0; g * 16u < l; ++g) {
+                uint32_t wd = (g == 0 ? view_first(pb) : view(pb + 16 * (int32_t)g)) & 0xAAAAAAAAu;
+                const uint32_t rem = l - 16u * g;
+                if (rem < 16u) wd &= (1u << (2u * rem)) - 1u;
+                c += __popc(wd);
+            }
+            cnt = (int)c;
+            prev = (cnt > thr) ? ring_l[0] : ring_r[0];
+            // move to window 0: + base pb + l, - base pb
+            cnt += (int)((view(pb + (int32_t)l) >> 1) & 1u);
+            cnt -= (int)((view_first(pb) >> 1) & 1u);
+        } else {
+            prev = ring_l[0];
+        }
+        if (bw0 + lw == 0) prev = 0xffffffffu;  // the very first window has no predecessor
+
+        // ---- blocks 1..nblk: one window per step
+        uint8_t *offs_blk = offs + (uint32_t)tid * nblk * OFFB;
+        uint8_t *fl_blk = flb + (uint32_t)tid * nblk * GE::FLB;
+        int rem_valid = (int)nvalid - (int)lw;  // windows of this lane still inside the range
+        for (uint32_t b = 1; b <= nblk; ++b) {
+            uint32_t me[NSUB], mo[NSUB], tgw[NSUB];
+#pragma unroll
+            for (int g = 0; g < NSUB; ++g) {
+                me[g] = (va[g] & 0x33333333u) | ((vr[g] << 2) & 0xccccccccu);
+                mo[g] = ((va[g] >> 2) & 0x33333333u) | (vr[g] & 0xccccccccu);
+                // 2-bit fields: tg(in) + 1 - tg(leaving) in {0,1,2}
+                if (CANON) tgw[g] = ((va[g] >> 1) & 0x55555555u) + (~(v2[g] >> 1) & 0x55555555u);
             }
             pos_in += W;
             pos_out += W;
             pos_r2 += W;
+            // prefetch the views of the next block (a harmless over-read after the last block)
+#pragma unroll
+            for (int g = 0; g < NSUB; ++g) {
+                va[g] = view(pos_in + 16 * g);
+                vr[g] = view(pos_out + 16 * g);
+                if (CANON) v2[g] = view(pos_r2 + 16 * g);
+            }
+
+            const uint32_t e0 = b * (uint32_t)W;  // element index of step j = 0
+            uint32_t pl = 0, pr_ = 0, fmask = 0, nib = 0;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const uint32_t e = e0 + (uint32_t)j;  // uniform
+                const uint32_t h = HASH_RC ? fw + rc : fw;
+                const uint32_t kl = (h & kmask) | e;
+                pl = (j == 0) ? kl : min(pl, kl);
+                uint32_t sel = (j + 1 < W) ? min(pl, ring_l[(j + 1 < W) ? j + 1 : 0]) : pl;
+                ring_l[j] = kl;
+                if (CANON) {
+                    const uint32_t kr = kl ^ kmask;
+                    pr_ = (j == 0) ? kr : max(pr_, kr);
+                    const uint32_t selr = (j + 1 < W) ? max(pr_, ring_r[(j + 1 < W) ? j + 1 : 0]) : pr_;
+                    ring_r[j] = kr;
+                    sel = (cnt > thr + (int)(e - (uint32_t)W)) ? sel : selr;
+                }
+                // window i = e - W starts at element i + 1
+                bool flag;
+                if (MODE == 0) {
+                    flag = (uint16_t)sel != (uint16_t)prev;
+                    prev = sel;
+                    // offset of the chosen k-mer inside the window
+                    const uint32_t off = sel - (e - (uint32_t)W + 1u);
+                    if (NIB) {
+                        if ((j & 1) == 0) nib = off & 15u;
+                        if ((j & 1) == 1 || j == W - 1)
+                            offs_blk[j >> 1] = (uint8_t)((j & 1) ? (nib | (off << 4)) : nib);
+                    } else {
+                        offs_blk[j] = (uint8_t)off;
+                    }
+                } else if (MODE == 1) {
+                    flag = ((uint16_t)sel == (uint16_t)(e - (uint32_t)W + 1u)) | ((uint16_t)sel == (uint16_t)e);
+                } else {
+                    flag = (uint16_t)sel == (uint16_t)(e - (uint32_t)W + 1u + (uint32_t)(W / 2));
+                }
+                fmask = (fmask << 1) | (uint32_t)flag;
+                if ((j & 31) == 31 || j == W - 1) {
+                    const int seg = j >> 5;
+                    const int seglen = (seg == NSEG - 1) ? (W - 32 * seg) : 32;
+                    // LSB = first window of the segment
+                    uint32_t f = __builtin_bitreverse32(fmask) >> (32 - seglen);
+                    if (partial) {
+                        const int v = rem_valid - 32 * seg;
+                        f = v <= 0 ? 0u : (v >= seglen ? f : (f & ((1u << v) - 1u)));
+                    }
+                    my_count += __popc(f);
+                    if (NIB) *reinterpret_cast<uint16_t *>(fl_blk) = (uint16_t)f;
+                    else reinterpret_cast<uint32_t *>(fl_blk)[seg] = f;
+                    fmask = 0;
+                }
+
+                const int jj = j & 15, g = j >> 4, m = jj >> 1;
+                const uint32_t mw = (jj & 1) ? mo[g] : me[g];
+                const uint32_t a8 = (m == 0 ? (mw << 3) : (mw >> (4 * m - 3))) & 0x78u;
+                const uint2 t = *reinterpret_cast<const uint2 *>(tabb + a8);
+                fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t.x;
+                if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t.y;
+                if (CANON) cnt += (int)((tgw[g] >> (2 * jj)) & 3u);
+            }
+#pragma unroll
+            for (int j = W - 2; j >= 0; --j) {
+                ring_l[j] = min(ring_l[j], ring_l[j + 1]);
+                if (CANON) ring_r[j] = max(ring_r[j], ring_r[j + 1]);
+            }
+            offs_blk += OFFB;
+            fl_blk += GE::FLB;
+            rem_valid -= W;
         }
     }
-    __syncthreads();
 
     // ---------------------------------------------------------------- phase 2
-    // Each wave owns a contiguous quarter of the tile's 16-window groups.
-    const uint32_t ngroups = (nvalid + 15u) / 16u;
-    const uint32_t gpw = (ngroups + kWavesPerBlock - 1) / kWavesPerBlock;  // groups per wave
-    const uint32_t g_begin = wave * gpw;
-    const uint32_t g_end = (g_begin + gpw < ngroups) ? g_begin + gpw : ngroups;
-    const uint32_t prev_tile = s_prev_off;
-    const uint32_t mode = p.mode;
-
-    auto group_flags = [&](uint32_t g) -> uint32_t {
-        const uint4 x = *reinterpret_cast<const uint4 *>(offs + 16u * g);
-        const uint32_t prevb = (g == 0) ? (prev_tile & 0xffu) : (uint32_t)offs[16u * g - 1u];
-        uint32_t f = window_flags16<W>(x, prevb, mode, g == 0 && prev_tile == 0x100u);
-        const uint32_t rem = nvalid - 16u * g;
-        if (rem < 16u) f &= (1u << rem) - 1u;
-        return f;
-    };
-
-    // 2a: count
-    uint32_t my_cnt = 0;
-    for (uint32_t g = g_begin + lane; g < g_end; g += kWave) my_cnt += __popc(group_flags(g));
-    uint32_t wave_incl = wave_inclusive_sum(my_cnt);
-    if (lane == kWave - 1) s_wave_tot[wave] = wave_incl;
+    // Wave w owns the windows of its own 64 lanes (a contiguous quarter of the tile), so the
+    // only cross-wave exchange is the four wave totals.
+    const uint32_t wave_total = __builtin_amdgcn_readlane(wave_scan_dpp(my_count), kWave - 1);
+    if (lane == 0) s_wave_tot[wave] = wave_total;
     __syncthreads();
     uint32_t wave_base = 0, block_total = 0;
 #pragma unroll
     for (int v = 0; v < kWavesPerBlock; ++v) {
-        uint32_t t = s_wave_tot[v];
+        const uint32_t t = s_wave_tot[v];
         if (v < wave) wave_base += t;
         block_total += t;
     }
     if (wave == 0) {
-        unsigned long long carry = (bid == 0) ? *p.out.total : 0ull;
-        unsigned long long e = lookback_exclusive(p.out.status, bid, block_total, carry);
-        if (lane == 0) s_excl = e;
+        const unsigned long long carry = (bid == 0) ? *p.out.total : 0ull;
+        const unsigned long long ex = (p.debug & 1u) ? (unsigned long long)bid * (NB / 6u)
+                                                     : lookback_exclusive(p.out.status, bid, block_total, carry);
+        if (lane == 0) s_excl = ex;
     }
     __syncthreads();
 
-    // 2b: emit, wave by wave in group order
-    unsigned long long run = s_excl + wave_base;
-    for (uint32_t gb = g_begin; gb < g_end; gb += kWave) {
-        const uint32_t g = gb + lane;
-        uint32_t f = (g < g_end) ? group_flags(g) : 0u;
-        const uint32_t c = __popc(f);
-        const uint32_t incl = wave_inclusive_sum(c);
-        unsigned long long dst = run + (incl - c);
-        while (f) {
-            const uint32_t bit = __builtin_ctz(f);
-            f &= f - 1u;
-            const uint32_t wi = 16u * g + bit;
-            const uint32_t widx = (uint32_t)(bw0 + wi);
-            if (dst < p.out.cap) {
-                p.out.pos[dst] = (mode == 0) ? widx + (uint32_t)offs[wi] : widx;
-                if (p.out.sk) p.out.sk[dst] = widx;
+    // Items: G consecutive W-blocks (W <= 32) or one 32-window segment (W > 32), in window order.
+    const unsigned long long run0 = s_excl + wave_base;
+    uint32_t run = 0;  // outputs of this wave emitted so far
+    const uint32_t wave_blk0 = (uint32_t)wave * kWave * nblk;    // first W-block of this wave
+    const uint32_t items = (NSEG == 1) ? (kWave * nblk + G - 1) / G : kWave * nblk * NSEG;
+    const uint32_t wave_win0 = wave_blk0 * (uint32_t)W;          // tile-relative
+    const uint32_t bw0_lo = (uint32_t)bw0;
+    uint32_t *outp = p.out.pos;
+    uint32_t *outs = p.out.sk;
+    for (uint32_t it0 = 0; it0 < items && !(p.debug & 2u); it0 += kWave) {
+        const uint32_t it = it0 + lane;
+        uint32_t wrel;  // wave-relative first window of the item
+        uint32_t f = 0;
+        if (NSEG == 1) {
+            wrel = it * (uint32_t)(G * W);
+            if (it < items && wave_win0 + wrel < nvalid) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const uint32_t blk = it * G + g;
+                    if (blk < kWave * nblk) {
+                        const uint8_t *fp = flb + (size_t)(wave_blk0 + blk) * GE::FLB;
+                        const uint32_t w = NIB ? (uint32_t)*reinterpret_cast<const uint16_t *>(fp)
+                                               : *reinterpret_cast<const uint32_t *>(fp);
+                        // blocks of lanes past the valid range were never written
+                        f |= (wave_win0 + blk * (uint32_t)W < nvalid ? w : 0u) << (g * W);
+                    }
+                }
             }
-            ++dst;
+        } else {
+            const uint32_t blk = it / NSEG, seg = it - blk * NSEG;
+            wrel = blk * (uint32_t)W + 32u * seg;
+            if (it < items && wave_win0 + blk * (uint32_t)W < nvalid)
+                f = reinterpret_cast<const uint32_t *>(flb)[(size_t)(wave_blk0 + blk) * NSEG + seg];
         }
-        run += __shfl(incl, kWave - 1, kWave);
+        if (__builtin_amdgcn_readfirstlane(wave_win0 + wrel) >= nvalid) break;  // items are in window order
+        const uint32_t c = __popc(f);
+        const uint32_t incl = wave_scan_dpp(c);
+        const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
+        const unsigned long long base = run0 + run;
+        if (total <= kStageCap) {
+            // stage wave-relative window indices in order, then coalesced stores
+            uint32_t slot = incl - c;
+            while (f) {
+                const uint32_t bit = __builtin_ctz(f);
+                f &= f - 1u;
+                stage[slot++] = (uint16_t)(wrel + bit);
+            }
+            for (uint32_t i = lane; i < total; i += kWave) {
+                const uint32_t wr = stage[i];
+                const uint32_t wi = wave_win0 + wr;  // tile-relative window
+                const uint32_t widx = bw0_lo + wi;
+                uint32_t val = widx;
+                if (MODE == 0) {
+                    const uint32_t blk = wi / (uint32_t)W, j = wi - blk * (uint32_t)W;
+                    if (NIB) {
+                        const uint32_t byte = offs[blk * OFFB + (j >> 1)];
+                        val += (j & 1) ? (byte >> 4) : (byte & 15u);
+                    } else {
+                        val += offs[blk * OFFB + j];
+                    }
+                }
+                if (base + i < p.out.cap) {
+                    outp[base + i] = val;
+                    if (MODE == 0 && outs) outs[base + i] = widx;
+                }
+            }
+        } else {
+            // dense region (more than kStageCap outputs in one iteration): direct ordered stores
+            unsigned long long dst = base + (incl - c);
+            while (f) {
+                const uint32_t bit = __builtin_ctz(f);
+                f &= f - 1u;
+                const uint32_t wi = wave_win0 + wrel + bit;
+                const uint32_t widx = bw0_lo + wi;
+                uint32_t val = widx;
+                if (MODE == 0) {
+                    const uint32_t blk = wi / (uint32_t)W, j = wi - blk * (uint32_t)W;
+                    if (NIB) {
+                        const uint32_t byte = offs[blk * OFFB + (j >> 1)];
+                        val += (j & 1) ? (byte >> 4) : (byte & 15u);
+                    } else {
+                        val += offs[blk * OFFB + j];
+                    }
+                }
+                if (dst < p.out.cap) {
+                    outp[dst] = val;
+                    if (MODE == 0 && outs) outs[dst] = widx;
+                }
+                ++dst;
+            }
+        }
+        run += total;
     }
     if (tid == 0 && bid == gridDim.x - 1) *p.out.total = s_excl + block_total;
 }

@@ -31,7 +31,7 @@ def run(n, k, w, canonical, mode, nblks, reps=5, seed=2):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 268435456
-    run(n, 21, 11, False, 0, [0, 4, 8, 12, 16, 20, 28])
-    run(n, 21, 11, True, 0, [0, 4, 8, 12, 16, 20, 28])
+    run(n, 21, 11, False, 0, [0, 4, 8, 12, 16, 20, 24, 32])
+    run(n, 21, 11, True, 0, [0, 4, 8, 12, 16, 20, 24, 32])
     run(n, 31, 51, True, 0, [0, 2, 3, 4, 6])
     run(n, 15, 17, True, 1, [0, 4, 8, 12])
