@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -81,8 +82,9 @@ struct mm_workspace {
     unsigned long long *status = nullptr;
     uint64_t status_words = 0;
     uint32_t *ticket = nullptr;
-    unsigned long long *total = nullptr;
-    unsigned long long *h_total = nullptr;  // pinned
+    unsigned long long *total = nullptr;    // [0] running total, [1] low word = error flag
+    unsigned long long *h_total = nullptr;  // pinned copy of both words
+    bool force_ticket = false;
     // generic-path scratch
     void *scratch = nullptr;
     uint64_t scratch_bytes = 0;
@@ -344,7 +346,7 @@ int mm_run_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d
     const uint64_t l = (uint64_t)plan->k + plan->w - 1;
     const uint64_t n_w = n_bases >= l ? n_bases - l + 1 : 0;
     if (win_end > n_w) win_end = n_w;
-    MM_HIP(hipMemsetAsync(ws->total, 0, sizeof(unsigned long long), ws->stream));
+    MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
     if (win_begin < win_end) {
         if (!d_packed) return MM_ERR_NULL;
         mm::RunArgs a;
@@ -362,7 +364,9 @@ int mm_run_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d
         a.out.cap = capacity;
         a.out.total = ws->total;
         a.out.ticket = ws->ticket;
+        a.out.error = reinterpret_cast<uint32_t *>(ws->total + 1);
         a.nblk = ws->nblk;
+        a.use_ticket = (ws->force_ticket || getenv("MM_FORCE_TICKET")) ? 1 : 0;
         a.scratch = nullptr;
         a.generic_round_windows = 0;
         a.timing_start = a.timing_stop = nullptr;
@@ -411,14 +415,24 @@ int mm_run_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packe
                   uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
                   uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos, uint32_t *d_out_sk,
                   uint64_t capacity, uint64_t *out_count) {
-    int r = mm_run_device_async(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin,
-                                win_end, d_out_pos, d_out_sk, capacity, nullptr);
-    if (r) return r;
-    MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                          ws->stream));
-    MM_HIP(hipStreamSynchronize(ws->stream));
-    if (out_count) *out_count = *ws->h_total;
-    if (d_out_pos && *ws->h_total > capacity) return MM_ERR_CAPACITY;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int r = mm_run_device_async(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin,
+                                    win_end, d_out_pos, d_out_sk, capacity, nullptr);
+        if (r) return r;
+        MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, ws->stream));
+        MM_HIP(hipStreamSynchronize(ws->stream));
+        if (ws->h_total[1] == 0) break;
+        // A look-back spin ran out: workgroups were not dispatched in index order. Redo the run
+        // with tile ids taken from an atomic ticket, which defines the order itself.
+        if (ws->force_ticket) {
+            g_last_error = "look-back scan timed out in ticket mode";
+            return MM_ERR_HIP;
+        }
+        ws->force_ticket = true;
+    }
+    if (out_count) *out_count = ws->h_total[0];
+    if (d_out_pos && ws->h_total[0] > capacity) return MM_ERR_CAPACITY;
     return MM_OK;
 }
 

@@ -42,6 +42,7 @@ struct OutParams {
     unsigned long long *total;   // device counter: running total of outputs
     unsigned long long *status;  // decoupled look-back words, one per block, zeroed per launch
     uint32_t *ticket;            // dynamic block id counter, zeroed per launch
+    uint32_t *error;             // set to 1 when a look-back spin ran out (see lookback_exclusive)
 };
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, uint32_t r) {
@@ -81,6 +82,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
 constexpr unsigned long long kFlagAgg = 1ull << 62;
 constexpr unsigned long long kFlagIncl = 2ull << 62;
 constexpr unsigned long long kValMask = (1ull << 62) - 1;
+constexpr uint32_t kMaxLookbackSpins = 1u << 22;
 
 __device__ __forceinline__ unsigned long long ld_status(unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -95,7 +97,8 @@ __device__ __forceinline__ void st_status(unsigned long long *p, unsigned long l
 __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long long *status,
                                                                  uint32_t bid,
                                                                  unsigned long long block_total,
-                                                                 unsigned long long carry_in) {
+                                                                 unsigned long long carry_in,
+                                                                 uint32_t *error) {
     const int lane = threadIdx.x & (kWave - 1);
     if (bid == 0) {
         if (lane == 0) st_status(&status[0], kFlagIncl | ((carry_in + block_total) & kValMask));
@@ -109,8 +112,15 @@ __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long l
         unsigned long long s;
         if (idx >= 0) {
             s = ld_status(&status[idx]);
-            while ((s >> 62) == 0) {
-                __builtin_amdgcn_s_sleep(1);
+            // bounded: a predecessor that never shows up (dispatch-order violation) must not
+            // hang the GPU; the launch is then reported as failed and redone in ticket mode
+            for (uint32_t spins = 0; (s >> 62) == 0; ++spins) {
+                if (spins > kMaxLookbackSpins) {
+                    *error = 1u;
+                    s = kFlagIncl;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
                 s = ld_status(&status[idx]);
             }
         } else {

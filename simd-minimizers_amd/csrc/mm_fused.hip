@@ -39,10 +39,18 @@ const Instance *find_instance(uint32_t w, int canonical_windows, int hasher_cano
     return nullptr;
 }
 
-uint32_t default_nblk(uint32_t w) {
-    // about 136 windows per lane: tile bytes + staged input stay near 42 KB (3 workgroups / CU)
-    uint32_t n = (136u + w / 2u) / w;
-    return n ? n : 1u;
+uint32_t gcd_u32(uint32_t a, uint32_t b) { return b ? gcd_u32(b, a % b) : a; }
+
+// W-blocks per lane. With 4-bit offsets (w <= 16) the lane length S = w * nblk must be a
+// multiple of 16 (phase 2 recovers the offset from the low nibble of the window index).
+uint32_t legal_nblk(uint32_t w, uint32_t want) {
+    if (want == 0) want = (176u + w / 2u) / w;  // about 176 windows per lane
+    if (want == 0) want = 1;
+    if (w <= 16u) {
+        const uint32_t step = 16u / gcd_u32(w, 16u);
+        want = (want + step - 1u) / step * step;
+    }
+    return want;
 }
 
 struct Geometry {
@@ -52,7 +60,7 @@ struct Geometry {
 
 Geometry geometry(const RunArgs &a) {
     Geometry g;
-    g.nblk = a.nblk ? a.nblk : default_nblk(a.w);
+    g.nblk = legal_nblk(a.w, a.nblk);
     g.S = a.w * g.nblk;
     g.NB = kBlockThreads * g.S;
     const bool nib = a.w <= 16u;
@@ -92,6 +100,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.lds_fl_off = g.lds_fl_off;
     p.lds_stage_off = g.lds_stage_off;
     p.out = a.out;
+    p.use_ticket = a.use_ticket ? 1u : 0u;
     {
         const char *dbg = getenv("MM_DEBUG");
         p.debug = dbg ? (uint32_t)atoi(dbg) : 0u;

@@ -39,6 +39,7 @@ struct FusedParams {
     uint32_t win_end;
     uint32_t lds_fl_off;     // byte offset of the flag words in dynamic LDS
     uint32_t lds_stage_off;  // byte offset of the per-wave staging buffers in dynamic LDS
+    uint32_t use_ticket;     // 1: tile id from an atomic ticket (safe mode), 0: blockIdx.x
     uint32_t debug;          // timing experiments only (MM_DEBUG env): 1 no look-back, 2 no emit,
                              // 4 no phase 1
     OutParams out;
@@ -53,6 +54,17 @@ __device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t v) {
     v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
     v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
     return v;
+}
+
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 // Geometry shared by the kernel and its launcher.
@@ -80,7 +92,10 @@ __global__ __launch_bounds__(kBlockThreads) void fused_kernel(const FusedParams 
     __shared__ unsigned long long s_excl;
 
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    if (tid == 0) s_bid = atomicAdd(p.out.ticket, 1u);
+    // Tile id.  Default: blockIdx.x (workgroups are dispatched in index order on gfx950, which
+    // the look-back needs for forward progress; its spins are bounded and report a violation,
+    // upon which the host re-runs in ticket mode where an atomic counter defines the order).
+    if (tid == 0) s_bid = p.use_ticket ? atomicAdd(p.out.ticket, 1u) : blockIdx.x;
     if (tid < 16) s_tab[tid] = p.ht.t_in_out[tid];
     else if (tid < 20) s_tab[tid] = p.ht.t_in[tid - 16];
     __syncthreads();
@@ -256,36 +271,62 @@ __global__ __launch_bounds__(kBlockThreads) void fused_kernel(const FusedParams 
                 const uint32_t e = e0 + (uint32_t)j;  // uniform
                 const uint32_t h = HASH_RC ? fw + rc : fw;
                 const uint32_t kl = (h & kmask) | e;
-                pl = (j == 0) ? kl : min(pl, kl);
-                uint32_t sel = (j + 1 < W) ? min(pl, ring_l[(j + 1 < W) ? j + 1 : 0]) : pl;
+                // prefix minimum over the block so far and the window minimum; odd steps fold the
+                // previous key in with one v_min3 (3 ops per 2 steps and side instead of 4)
+                uint32_t sel;
+                if (j == 0) {
+                    pl = kl;
+                    sel = (W > 1) ? min(kl, ring_l[(W > 1) ? 1 : 0]) : kl;
+                } else if (j & 1) {
+                    // pl still excludes key j: sel = min3(pl, kl, ring[j+1]); pl is updated on even steps
+                    sel = (j + 1 < W) ? min3u(pl, kl, ring_l[(j + 1 < W) ? j + 1 : 0]) : min(pl, kl);
+                } else {
+                    pl = min3u(pl, ring_l[j - 1], kl);  // ring_l[j-1] holds key j-1
+                    sel = (j + 1 < W) ? min(pl, ring_l[(j + 1 < W) ? j + 1 : 0]) : pl;
+                }
                 ring_l[j] = kl;
                 if (CANON) {
                     const uint32_t kr = kl ^ kmask;
-                    pr_ = (j == 0) ? kr : max(pr_, kr);
-                    const uint32_t selr = (j + 1 < W) ? max(pr_, ring_r[(j + 1 < W) ? j + 1 : 0]) : pr_;
+                    uint32_t selr;
+                    if (j == 0) {
+                        pr_ = kr;
+                        selr = (W > 1) ? max(kr, ring_r[(W > 1) ? 1 : 0]) : kr;
+                    } else if (j & 1) {
+                        selr = (j + 1 < W) ? max3u(pr_, kr, ring_r[(j + 1 < W) ? j + 1 : 0]) : max(pr_, kr);
+                    } else {
+                        pr_ = max3u(pr_, ring_r[j - 1], kr);
+                        selr = (j + 1 < W) ? max(pr_, ring_r[(j + 1 < W) ? j + 1 : 0]) : pr_;
+                    }
                     ring_r[j] = kr;
                     sel = (cnt > thr + (int)(e - (uint32_t)W)) ? sel : selr;
                 }
-                // window i = e - W starts at element i + 1
-                bool flag;
+                // window i = e - W starts at element i + 1.  The emit flag is shifted into fmask
+                // with v_cmp + v_addc (fmask = 2*fmask + flag).
                 if (MODE == 0) {
-                    flag = (uint16_t)sel != (uint16_t)prev;
+                    asm("v_cmp_ne_u16 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                        : "+v"(fmask) : "v"(sel), "v"(prev) : "vcc");
                     prev = sel;
-                    // offset of the chosen k-mer inside the window
-                    const uint32_t off = sel - (e - (uint32_t)W + 1u);
                     if (NIB) {
-                        if ((j & 1) == 0) nib = off & 15u;
+                        // low nibble of the chosen element index; phase 2 subtracts the window
+                        // index (S is a multiple of 16 in this mode)
+                        if ((j & 1) == 0) nib = sel & 15u;
                         if ((j & 1) == 1 || j == W - 1)
-                            offs_blk[j >> 1] = (uint8_t)((j & 1) ? (nib | (off << 4)) : nib);
+                            offs_blk[j >> 1] = (uint8_t)((j & 1) ? (nib | (sel << 4)) : nib);
                     } else {
-                        offs_blk[j] = (uint8_t)off;
+                        // offset of the chosen k-mer inside the window
+                        offs_blk[j] = (uint8_t)(sel - (e - (uint32_t)W + 1u));
                     }
                 } else if (MODE == 1) {
-                    flag = ((uint16_t)sel == (uint16_t)(e - (uint32_t)W + 1u)) | ((uint16_t)sel == (uint16_t)e);
+                    const uint32_t first = e - (uint32_t)W + 1u;
+                    unsigned long long t;
+                    asm("v_cmp_eq_u16 vcc, %3, %2\n\tv_cmp_eq_u16 %1, %2, %4\n\ts_or_b64 vcc, vcc, %1\n\t"
+                        "v_addc_co_u32 %0, vcc, %0, %0, vcc"
+                        : "+v"(fmask), "=&s"(t) : "v"(sel), "s"(first), "s"(e) : "vcc");
                 } else {
-                    flag = (uint16_t)sel == (uint16_t)(e - (uint32_t)W + 1u + (uint32_t)(W / 2));
+                    const uint32_t mid = e - (uint32_t)W + 1u + (uint32_t)(W / 2);
+                    asm("v_cmp_eq_u16 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                        : "+v"(fmask) : "v"(sel), "s"(mid) : "vcc");
                 }
-                fmask = (fmask << 1) | (uint32_t)flag;
                 if ((j & 31) == 31 || j == W - 1) {
                     const int seg = j >> 5;
                     const int seglen = (seg == NSEG - 1) ? (W - 32 * seg) : 32;
@@ -336,7 +377,7 @@ __global__ __launch_bounds__(kBlockThreads) void fused_kernel(const FusedParams 
     if (wave == 0) {
         const unsigned long long carry = (bid == 0) ? *p.out.total : 0ull;
         const unsigned long long ex = (p.debug & 1u) ? (unsigned long long)bid * (NB / 6u)
-                                                     : lookback_exclusive(p.out.status, bid, block_total, carry);
+                                                     : lookback_exclusive(p.out.status, bid, block_total, carry, p.out.error);
         if (lane == 0) s_excl = ex;
     }
     __syncthreads();
@@ -397,7 +438,7 @@ __global__ __launch_bounds__(kBlockThreads) void fused_kernel(const FusedParams 
                     const uint32_t blk = wi / (uint32_t)W, j = wi - blk * (uint32_t)W;
                     if (NIB) {
                         const uint32_t byte = offs[blk * OFFB + (j >> 1)];
-                        val += (j & 1) ? (byte >> 4) : (byte & 15u);
+                        val += (((j & 1) ? (byte >> 4) : byte) - (wi + 1u)) & 15u;
                     } else {
                         val += offs[blk * OFFB + j];
                     }
@@ -420,7 +461,7 @@ __global__ __launch_bounds__(kBlockThreads) void fused_kernel(const FusedParams 
                     const uint32_t blk = wi / (uint32_t)W, j = wi - blk * (uint32_t)W;
                     if (NIB) {
                         const uint32_t byte = offs[blk * OFFB + (j >> 1)];
-                        val += (j & 1) ? (byte >> 4) : (byte & 15u);
+                        val += (((j & 1) ? (byte >> 4) : byte) - (wi + 1u)) & 15u;
                     } else {
                         val += offs[blk * OFFB + j];
                     }

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlockThreads) void generic_compact_kernel(
     }
     if (wave == 0) {
         unsigned long long carry = (bid == 0) ? *out.total : 0ull;
-        unsigned long long e = lookback_exclusive(out.status, bid, block_total, carry);
+        unsigned long long e = lookback_exclusive(out.status, bid, block_total, carry, out.error);
         if (lane == 0) s_excl = e;
     }
     __syncthreads();

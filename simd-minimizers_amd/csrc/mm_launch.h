@@ -17,6 +17,7 @@ struct RunArgs {
     OutParams out;
     // fused path
     uint32_t nblk;  // w-blocks per lane (0 = default)
+    int use_ticket; // tile ids from an atomic ticket instead of blockIdx.x (safe mode)
     // generic path
     void *scratch;
     uint64_t generic_round_windows;
