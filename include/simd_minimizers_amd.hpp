@@ -1,0 +1,174 @@
+// simd_minimizers_amd.hpp — header-only C++ mirror of the reference's builder API
+// (rust-seq/simd-minimizers src/lib.rs:225-654) over the C ABI of simd_minimizers_amd.h.
+//
+//   using namespace simd_minimizers;
+//   std::vector<uint32_t> pos, sk;
+//   auto out = canonical_minimizers(21, 11).super_kmers(&sk).run(PackedSeq{bytes, 0, n}, pos);
+//   std::vector<uint64_t> vals = out.values_u64();
+//
+// Names, argument meaning and error behaviour follow the reference: `run` APPENDS to the
+// output vector (src/lib.rs:80-81) and drops a leading result equal to its previous last
+// element (src/collect.rs:265-271); the reference's assert!/panic! conditions surface as
+// simd_minimizers::Error carrying the MM_ERR_* code.  All compute happens in the HIP library.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "simd_minimizers_amd.h"
+
+namespace simd_minimizers {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c) : std::runtime_error(std::string(mm_strerror(c)) + " " + mm_last_error()), code(c) {}
+};
+inline void check(int c) {
+    if (c != MM_OK) throw Error(c);
+}
+
+// packed-seq PackedSeq: borrowed view of 2-bit bases (A0 C1 T2 G3, 4 per byte)
+struct PackedSeq {
+    const uint8_t *data;
+    uint64_t offset;  // first base inside `data`
+    uint64_t len;
+    PackedSeq slice(uint64_t b, uint64_t e) const { return PackedSeq{data, offset + b, e - b}; }
+};
+// packed-seq AsciiSeq: ACTG / actg characters
+struct AsciiSeq {
+    const uint8_t *data;
+    uint64_t len;
+};
+
+// seq-hash NtHasher<CANONICAL>::new(k)
+template <bool CANONICAL = true>
+struct NtHasher {
+    mm_hasher_t tables;
+    uint32_t k;
+    explicit NtHasher(uint32_t k_) : k(k_) { check(mm_default_hasher(&tables, CANONICAL)); }
+    bool is_canonical() const { return CANONICAL; }
+};
+
+class Workspace {
+  public:
+    explicit Workspace(int device = 0, void *stream = nullptr) { check(mm_workspace_create(&ws_, device, stream)); }
+    ~Workspace() { mm_workspace_destroy(ws_); }
+    Workspace(const Workspace &) = delete;
+    Workspace &operator=(const Workspace &) = delete;
+    mm_workspace_t *get() const { return ws_; }
+    static Workspace &thread_default() {  // the reference's thread_local CACHE (src/lib.rs:217-219)
+        thread_local Workspace w;
+        return w;
+    }
+
+  private:
+    mm_workspace_t *ws_ = nullptr;
+};
+
+template <bool CANONICAL>
+class Output {  // src/lib.rs:232-237
+  public:
+    Output(uint32_t len, PackedSeq seq, const std::vector<uint32_t> *pos, Workspace *ws)
+        : len_(len), seq_(seq), pos_(pos), ws_(ws) {}
+    std::vector<uint64_t> values_u64() const {  // src/lib.rs:584-612
+        std::vector<uint64_t> v(pos_->size());
+        check(mm_values_u64_host(ws_->get(), seq_.data, seq_.offset, seq_.len, len_, CANONICAL, pos_->data(),
+                                 pos_->size(), v.data()));
+        return v;
+    }
+    const std::vector<uint32_t> &positions() const { return *pos_; }
+
+  private:
+    uint32_t len_;
+    PackedSeq seq_;
+    const std::vector<uint32_t> *pos_;
+    Workspace *ws_;
+};
+
+template <bool CANONICAL, int SYNCMER>
+class Builder {  // src/lib.rs:225-230
+  public:
+    Builder(uint32_t k, uint32_t w) : k_(k), w_(w) {}
+    template <bool C>
+    Builder hasher(const NtHasher<C> &h) const {  // src/lib.rs:327
+        Builder b = *this;
+        b.hasher_ = h.tables;
+        b.has_hasher_ = true;
+        return b;
+    }
+    Builder super_kmers(std::vector<uint32_t> *sk) const {  // src/lib.rs:341 (minimizers only)
+        static_assert(SYNCMER == 0, "super_kmers() is only defined for minimizers");
+        Builder b = *this;
+        b.sk_ = sk;
+        return b;
+    }
+    Builder workspace(Workspace *ws) const {
+        Builder b = *this;
+        b.ws_ = ws;
+        return b;
+    }
+    Output<CANONICAL> run(PackedSeq seq, std::vector<uint32_t> &min_pos) const {  // src/lib.rs:378
+        Workspace &ws = ws_ ? *ws_ : Workspace::thread_default();
+        mm_plan_t *plan = nullptr;
+        check(mm_plan_create(&plan, k_, w_, CANONICAL, (mm_mode_t)SYNCMER, has_hasher_ ? &hasher_ : nullptr));
+        const uint64_t l = (uint64_t)k_ + w_ - 1;
+        const uint64_t cap = seq.len >= l ? seq.len - l + 1 : 0;
+        std::vector<uint32_t> pos(cap ? cap : 1), sk(sk_ ? (cap ? cap : 1) : 0);
+        uint64_t n = 0;
+        int r = mm_run_host(plan, ws.get(), seq.data, seq.offset, seq.len, pos.data(), sk_ ? sk.data() : nullptr,
+                            cap, &n);
+        mm_plan_destroy(plan);
+        check(r);
+        size_t first = 0;
+        if (SYNCMER == 0)
+            while (first < n && !min_pos.empty() && pos[first] == min_pos.back()) ++first;
+        min_pos.insert(min_pos.end(), pos.begin() + first, pos.begin() + n);
+        if (sk_) sk_->insert(sk_->end(), sk.begin() + first, sk.begin() + n);
+        return Output<CANONICAL>(SYNCMER ? k_ + w_ - 1 : k_, seq, &min_pos, &ws);
+    }
+    std::vector<uint32_t> run_once(PackedSeq seq) const {  // src/lib.rs:364
+        std::vector<uint32_t> v;
+        run(seq, v);
+        return v;
+    }
+    std::vector<uint32_t> run_once(AsciiSeq seq) const {
+        Workspace &ws = ws_ ? *ws_ : Workspace::thread_default();
+        mm_plan_t *plan = nullptr;
+        check(mm_plan_create(&plan, k_, w_, CANONICAL, (mm_mode_t)SYNCMER, has_hasher_ ? &hasher_ : nullptr));
+        const uint64_t l = (uint64_t)k_ + w_ - 1;
+        const uint64_t cap = seq.len >= l ? seq.len - l + 1 : 0;
+        std::vector<uint32_t> pos(cap ? cap : 1);
+        uint64_t n = 0;
+        int r = mm_run_host_ascii(plan, ws.get(), seq.data, seq.len, pos.data(), nullptr, cap, &n);
+        mm_plan_destroy(plan);
+        check(r);
+        pos.resize(n);
+        return pos;
+    }
+
+  private:
+    uint32_t k_, w_;
+    mm_hasher_t hasher_{};
+    bool has_hasher_ = false;
+    std::vector<uint32_t> *sk_ = nullptr;
+    Workspace *ws_ = nullptr;
+};
+
+// constructors, src/lib.rs:240-321
+inline Builder<false, 0> minimizers(uint32_t k, uint32_t w) { return {k, w}; }
+inline Builder<true, 0> canonical_minimizers(uint32_t k, uint32_t w) { return {k, w}; }
+inline Builder<false, 1> closed_syncmers(uint32_t k, uint32_t w) { return {k, w}; }
+inline Builder<true, 1> canonical_closed_syncmers(uint32_t k, uint32_t w) { return {k, w}; }
+inline Builder<false, 2> open_syncmers(uint32_t k, uint32_t w) { return {k, w}; }
+inline Builder<true, 2> canonical_open_syncmers(uint32_t k, uint32_t w) { return {k, w}; }
+inline Builder<true, 1> canonical_syncmers(uint32_t k, uint32_t w) { return {k, w}; }  // README.md:65 name
+
+// free functions, src/lib.rs:639-654
+inline std::vector<uint32_t> minimizer_positions(PackedSeq s, uint32_t k, uint32_t w) { return minimizers(k, w).run_once(s); }
+inline std::vector<uint32_t> minimizer_positions(AsciiSeq s, uint32_t k, uint32_t w) { return minimizers(k, w).run_once(s); }
+inline std::vector<uint32_t> canonical_minimizer_positions(PackedSeq s, uint32_t k, uint32_t w) {
+    return canonical_minimizers(k, w).run_once(s);
+}
+
+}  // namespace simd_minimizers

@@ -15,6 +15,11 @@ namespace mm {
 constexpr int kBlockThreads = 256;
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = kBlockThreads / kWave;
+#ifndef MM_FUSED_THREADS
+#define MM_FUSED_THREADS 256
+#endif
+constexpr int kFusedThreads = MM_FUSED_THREADS;  // workgroup size of the fused kernel
+constexpr int kFusedWaves = kFusedThreads / kWave;
 
 // Rolling ntHash tables prepared on the host for one (hasher, k):
 //   fw' = rotl(fw, rot) ^ t_in_out[out][in].x ;  rc' = rotr(rc, rot) ^ t_in_out[out][in].y

@@ -62,13 +62,13 @@ Geometry geometry(const RunArgs &a) {
     Geometry g;
     g.nblk = legal_nblk(a.w, a.nblk);
     g.S = a.w * g.nblk;
-    g.NB = kBlockThreads * g.S;
+    g.NB = kFusedThreads * g.S;
     const bool nib = a.w <= 16u;
     const uint32_t offb = nib ? (a.w + 1u) / 2u : a.w;
     const uint32_t flbytes = nib ? 2u : 4u * ((a.w + 31u) / 32u);
-    g.lds_fl_off = (kBlockThreads * g.nblk * offb + 15u) & ~15u;
-    g.lds_stage_off = g.lds_fl_off + ((kBlockThreads * g.nblk * flbytes + 15u) & ~15u);
-    g.lds_bytes = g.lds_stage_off + kWavesPerBlock * kStageCap * 2u;
+    g.lds_fl_off = (kFusedThreads * g.nblk * offb + 15u) & ~15u;
+    g.lds_stage_off = g.lds_fl_off + ((kFusedThreads * g.nblk * flbytes + 15u) & ~15u);
+    g.lds_bytes = g.lds_stage_off + kFusedWaves * kStageCap * 2u;
     const uint64_t nwin = a.win_end - a.win_begin;
     g.nblocks = (nwin + g.NB - 1) / g.NB;
     return g;
@@ -118,7 +118,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         return -1;
     if (hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
     if (a.timing_start) hipEventRecord(a.timing_start, stream);
-    hipLaunchKernelGGL(fn, dim3((uint32_t)g.nblocks), dim3(kBlockThreads), g.lds_bytes, stream, p);
+    hipLaunchKernelGGL(fn, dim3((uint32_t)g.nblocks), dim3(kFusedThreads), g.lds_bytes, stream, p);
     if (a.timing_stop) hipEventRecord(a.timing_stop, stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

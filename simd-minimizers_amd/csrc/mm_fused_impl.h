@@ -79,7 +79,7 @@ struct FusedGeom {
 };
 
 template <int W, bool CANON, bool HASH_RC, int MODE>
-__global__ __launch_bounds__(kBlockThreads) void fused_kernel(const FusedParams p) {
+__global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams p) {
     static_assert(W >= 1 && W <= 255, "window offsets are stored in at most a byte");
     using GE = FusedGeom<W>;
     constexpr bool NIB = GE::NIB;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBlockThreads) void fused_kernel(const FusedParams 
     // static LDS: distinct objects, so table look-ups can be scheduled across the dynamic stores
     __shared__ uint2 s_tab[20];  // [0..15] (out<<2)|in, [16..19] in only (warm-up)
     __shared__ uint32_t s_bid;
-    __shared__ uint32_t s_wave_tot[kWavesPerBlock];
+    __shared__ uint32_t s_wave_tot[kFusedWaves];
     __shared__ unsigned long long s_excl;
 
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kBlockThreads) void fused_kernel(const FusedParams 
 
     const uint32_t nblk = p.nblk;
     const uint32_t S = (uint32_t)W * nblk;
-    const uint32_t NB = kBlockThreads * S;
+    const uint32_t NB = kFusedThreads * S;
     const uint64_t bw0 = (uint64_t)p.win_begin + (uint64_t)bid * NB;  // first window of the tile
     const uint32_t nvalid =
         (uint32_t)(((uint64_t)p.win_end - bw0) < NB ? ((uint64_t)p.win_end - bw0) : NB);
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(kBlockThreads) void fused_kernel(const FusedParams 
     __syncthreads();
     uint32_t wave_base = 0, block_total = 0;
 #pragma unroll
-    for (int v = 0; v < kWavesPerBlock; ++v) {
+    for (int v = 0; v < kFusedWaves; ++v) {
         const uint32_t t = s_wave_tot[v];
         if (v < wave) wave_base += t;
         block_total += t;

@@ -1,0 +1,75 @@
+"""Multi-GPU sharding of the minimizer path (one process per GPU, torch.distributed).
+
+The path partitions into independent units, so there is no data-path collective:
+  * independent sequences (contigs) are assigned to ranks greedily, longest first
+    (the reference's only parallel benchmark does `seqs.par_iter()` over contigs,
+    bench/src/bin/paper.rs:442-459);
+  * ONE long sequence is cut into window ranges [win_begin, win_end); every rank reads its
+    range plus a (k + w - 2)-base halo and produces ABSOLUTE positions, and because the kernel
+    also evaluates the window just before its range the dedup at the seam is exact
+    (src/collect.rs:265-271): concatenating the rank outputs in rank order IS the result.
+The only exchange is optional and tiny: an all-gather of the per-rank counts (offsets of each
+shard in a notional concatenated buffer) and, if a caller wants everything on one rank, a
+gather of the position buffers (RCCL over xGMI when the backend is nccl).
+"""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import numpy as np
+
+
+def shard_windows(n_windows: int, world: int) -> list[tuple[int, int]]:
+    """Equal window ranges, one per rank (the last ranks may be empty for tiny inputs)."""
+    per = -(-n_windows // world) if n_windows else 0
+    return [(min(r * per, n_windows), min((r + 1) * per, n_windows)) for r in range(world)]
+
+
+def assign_contigs(lengths: Sequence[int], world: int) -> list[list[int]]:
+    """Greedy longest-first placement of contigs on ranks; returns contig indices per rank."""
+    loads = [0] * world
+    out: list[list[int]] = [[] for _ in range(world)]
+    for i in sorted(range(len(lengths)), key=lambda i: -lengths[i]):
+        r = min(range(world), key=lambda r: loads[r])
+        out[r].append(i)
+        loads[r] += lengths[i]
+    for lst in out:
+        lst.sort()
+    return out
+
+
+def run_sharded(compute: Callable[[int, int], np.ndarray], n_windows: int, group=None,
+                gather_to: int | None = None):
+    """Run one window-range shard per rank.
+
+    ``compute(win_begin, win_end)`` produces this rank's positions (on the GPU box it wraps
+    ``Builder.run_device(..., win_begin=, win_end=)``).  Returns ``(local, counts, gathered)``:
+    this rank's positions, every rank's count (all-gather of one int64), and the concatenated
+    result on rank ``gather_to`` (None elsewhere / when not requested).
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    begin, end = shard_windows(n_windows, world)[rank]
+    local = np.ascontiguousarray(compute(begin, end), dtype=np.uint32)
+    if world == 1:
+        return local, [len(local)], (local if gather_to == 0 else None)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    cnt = torch.tensor([len(local)], dtype=torch.int64, device=dev)
+    counts_t = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts_t, cnt, group=group)
+    counts = [int(c.item()) for c in counts_t]
+    gathered = None
+    if gather_to is not None:
+        # variable-size gather as a padded all-gather (payload is small: 4 B per ~(w+1)/2 bases)
+        m = max(counts) if counts else 0
+        buf = torch.zeros(max(m, 1), dtype=torch.int32, device=dev)
+        buf[: len(local)] = torch.from_numpy(local.view(np.int32)).to(dev)
+        parts = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf, group=group)
+        if rank == gather_to:
+            gathered = np.concatenate([p[:c].cpu().numpy().view(np.uint32) for p, c in zip(parts, counts)])
+    return local, counts, gathered

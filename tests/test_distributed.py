@@ -1,0 +1,74 @@
+"""world_size-2 gloo test of the sharded (multi-GPU) path on CPU: window-range shards computed
+independently, counts all-gathered, positions gathered — the concatenation must equal the
+single-process result.  The oracle stands in for the per-rank GPU run here (tests only)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, k, w, canonical, mode, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mm_oracle as o
+    from simd_minimizers_amd import sharding
+
+    data = o.gen_packed(17, n)
+    l = k + w - 1
+    nw = n - l + 1
+    win = o.window_positions(data, n, k, w, o.default_hasher(canonical), canonical)
+
+    def compute(b, e):
+        # what the kernel does for a window range: windows [b, e) with the seam rule against b-1
+        out = []
+        for i in range(b, e):
+            p = int(win[i])
+            if mode == 0:
+                if i == 0 or int(win[i - 1]) != p:
+                    out.append(p)
+            elif mode == 1:
+                if p == i or p == i + w - 1:
+                    out.append(i)
+        return np.array(out, dtype=np.uint32)
+
+    local, counts, gathered = sharding.run_sharded(compute, nw, gather_to=0)
+    if rank == 0:
+        want = o.run(data, n, k, w, canonical=canonical, mode=mode)
+        q.put((counts, bool(np.array_equal(gathered, want)), len(want)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,w,canonical,mode", [(21, 11, True, 0), (5, 7, False, 0), (15, 17, True, 1)])
+def test_two_rank_window_sharding(k, w, canonical, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + 7 * mode + k
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 20011, k, w, canonical, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    counts, equal, total = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert equal and sum(counts) == total and len(counts) == 2
+
+
+def test_shard_helpers():
+    sys.path.insert(0, ROOT)
+    from simd_minimizers_amd import sharding
+    assert sharding.shard_windows(10, 4) == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert sharding.shard_windows(0, 2) == [(0, 0), (0, 0)]
+    assert sharding.shard_windows(3, 8)[-1] == (3, 3)
+    a = sharding.assign_contigs([248, 242, 201, 193, 182, 172, 160, 146, 150, 134, 135, 133], 4)
+    assert sorted(i for lst in a for i in lst) == list(range(12))
+    loads = [sum([248, 242, 201, 193, 182, 172, 160, 146, 150, 134, 135, 133][i] for i in lst) for lst in a]
+    assert max(loads) - min(loads) < 60

@@ -252,3 +252,114 @@ def test_capacity_error(sm, oracle, gpu):
     with pytest.raises(sm.MinimizerError) as e:
         sm.minimizers(21, 11).run_device(d, n, out)
     assert e.value.code == sm.ERR["CAPACITY"]
+
+
+def test_low_complexity_dense_output(sm, oracle, gpu):
+    """Homopolymers / short repeats: every hash ties, the output is dense (one position per
+    window for forward minimizers) — exercises the direct-store path of the compaction."""
+    import torch
+    n = 300_000
+    for unit in (b"A", b"AC", b"ACGTT", b"G"):
+        seq = (unit * (n // len(unit) + 1))[:n]
+        data = oracle.pack_ascii(seq)
+        d = torch.from_numpy(data).cuda()
+        out = torch.zeros(n, dtype=torch.int32, device="cuda")
+        for k, w, canonical, mode in [(21, 11, False, 0), (21, 11, True, 0), (15, 17, True, 1), (5, 7, False, 2)]:
+            want = oracle.run(data, n, k, w, canonical=canonical, mode=mode)
+            c = _builder(sm, k, w, canonical, mode).run_device(d, n, out)
+            assert c == len(want) and np.array_equal(out[:c].cpu().numpy().view(np.uint32), want), (unit, k, w)
+
+
+def test_custom_hasher_tables(sm, oracle, gpu):
+    """.hasher(&h) (src/lib.rs:327): tables cross the ABI as data (seeded hashers)."""
+    rng = np.random.default_rng(77)
+    n = 50_000
+    data = oracle.gen_packed(8, n)
+    ps = sm.PackedSeq(data, 0, n)
+    for canonical in (False, True):
+        fw = [int(x) for x in rng.integers(0, 1 << 32, size=4)]
+        rc = [fw[c ^ 2] for c in range(4)]
+        for rot in (7, 1, 13):
+            h = sm.Hasher.from_tables(fw, rc, rot, canonical)
+            oh = oracle.Hasher()
+            for i in range(4):
+                oh.fw[i], oh.rc[i] = fw[i], rc[i]
+            oh.rot, oh.canonical = rot, int(canonical)
+            for k, w in [(21, 11), (5, 7), (31, 19)]:
+                if canonical and (k + w - 1) % 2 == 0:
+                    continue
+                want = oracle.run(data, n, k, w, hasher=oh, canonical=canonical)
+                got, _ = sm.Builder(k, w, canonical, 0, hasher=h)._run_arrays(ps)
+                assert np.array_equal(got, want), (canonical, rot, k, w)
+    # forward windows with a canonical hasher (allowed by the reference, generic kernel family)
+    h = sm.NtHasher(21, canonical=True)
+    want = oracle.run(data, n, 21, 11, hasher=oracle.default_hasher(True), canonical=False)
+    got, _ = sm.minimizers(21, 11).hasher(h)._run_arrays(ps)
+    assert np.array_equal(got, want)
+
+
+def test_ticket_mode_matches(sm, oracle, gpu, monkeypatch):
+    """Safe mode (tile ids from an atomic ticket) produces the same output."""
+    import torch
+    n, k, w = 5_000_011, 21, 11
+    data = oracle.gen_packed(31, n)
+    want = oracle.run(data, n, k, w, canonical=True)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    monkeypatch.setenv("MM_FORCE_TICKET", "1")
+    c = sm.canonical_minimizers(k, w).run_device(d, n, out)
+    assert c == len(want) and np.array_equal(out[:c].cpu().numpy().view(np.uint32), want)
+
+
+def test_blocks_per_lane_knob(sm, oracle, gpu):
+    """Any legal tile geometry gives the same result."""
+    import torch
+    n, k, w = 2_000_003, 21, 11
+    data = oracle.gen_packed(41, n)
+    want = oracle.run(data, n, k, w, canonical=True)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    try:
+        for nblk in (1, 16, 32, 48):
+            gpu.set_blocks_per_lane(nblk)
+            c = sm.canonical_minimizers(k, w).run_device(d, n, out)
+            assert c == len(want) and np.array_equal(out[:c].cpu().numpy().view(np.uint32), want), nblk
+        for nblk, (k2, w2) in ((1, (31, 51)), (3, (31, 51)), (5, (15, 19))):
+            gpu.set_blocks_per_lane(nblk)
+            want2 = oracle.run(data, n, k2, w2, canonical=True)
+            c = sm.canonical_minimizers(k2, w2).run_device(d, n, out)
+            assert c == len(want2) and np.array_equal(out[:c].cpu().numpy().view(np.uint32), want2), (nblk, k2, w2)
+    finally:
+        gpu.set_blocks_per_lane(0)
+
+
+def test_cxx_builder_example(gpu):
+    """The header-only C++ mirror of the builder reproduces the reference doctests."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "cxx", "builder_example")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe)], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+
+
+def test_device_values_and_generator(sm, oracle, gpu):
+    """Output::values_u64 on device-resident positions; device generator == host generator."""
+    import ctypes as C
+    import torch
+    n = 1_000_000
+    d = sm.generate_device(n, 1)
+    host = oracle.gen_packed(1, n)
+    assert np.array_equal(d[: (n + 3) // 4].cpu().numpy(), host[: (n + 3) // 4])
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for k, w, canonical, mode in [(21, 11, True, 0), (15, 17, True, 1), (31, 5, False, 0)]:
+        b = _builder(sm, k, w, canonical, mode)
+        c = b.run_device(d, n, out)
+        vals = torch.zeros(c, dtype=torch.int64, device="cuda")
+        ln = k if mode == 0 else k + w - 1
+        sm._check(sm.lib().mm_values_u64_device_async(gpu.h, C.c_void_p(d.data_ptr()), d.numel(), 0, n, ln,
+                                                      int(canonical), C.c_void_p(out.data_ptr()), c,
+                                                      C.c_void_p(vals.data_ptr())))
+        gpu.sync()
+        want = oracle.values_u64(host, ln, out[:c].cpu().numpy().view(np.uint32), canonical)
+        assert np.array_equal(vals.cpu().numpy().view(np.uint64), want), (k, w, mode)

@@ -1,0 +1,151 @@
+"""CPU-only tests of the oracle (oracle/mm_oracle.c): pinned against every known-answer vector the
+reference's own tests hold for the path (tests/golden/reference_vectors.json), against the
+model anchors, and self-consistency naive == streaming (the reference's own test strategy,
+src/test.rs:53-110)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REF = json.load(open(os.path.join(GOLD, "reference_vectors.json")))
+
+
+def test_reference_minimizer_vectors(oracle):
+    for case in REF["minimizers"]:
+        seq = case["seq"].encode()
+        packed = oracle.pack_ascii(seq)
+        n = len(seq)
+        if case.get("revcomp_input"):
+            packed = oracle.revcomp_packed(packed, n)
+        for flavour in (oracle.NAIVE, oracle.STREAMING):
+            pos = oracle.run(packed, n, case["k"], case["w"], canonical=case["canonical"],
+                             mode=case["mode"], flavour=flavour)
+            assert list(map(int, pos)) == case["positions"], (case["source"], flavour)
+        if "values_u64" in case:
+            vals = oracle.values_u64(packed, case["k"], np.array(case["positions"], dtype=np.uint32),
+                                     case["canonical"])
+            assert list(map(int, vals)) == case["values_u64"], case["source"]
+
+
+def test_reference_collector_vectors(oracle):
+    import ctypes as C
+    L = oracle.lib()
+    u32 = C.POINTER(C.c_uint32)
+    for case in REF["collect_and_dedup"]:
+        a = np.array(case["in"], dtype=np.uint32)
+        out = np.zeros(len(a) + 1, dtype=np.uint32)
+        m = L.mmo_collect_and_dedup(a.ctypes.data_as(u32), len(a), out.ctypes.data_as(u32))
+        assert list(out[:m]) == case["out"], case["source"]
+    for case in REF["collect_and_dedup_with_index"]:
+        a = np.array(case["in"], dtype=np.uint32)
+        out = np.zeros(len(a) + 1, dtype=np.uint32)
+        idx = np.zeros(len(a) + 1, dtype=np.uint32)
+        m = L.mmo_collect_and_dedup_with_index(a.ctypes.data_as(u32), len(a), out.ctypes.data_as(u32),
+                                               idx.ctypes.data_as(u32))
+        assert list(out[:m]) == case["out"] and list(idx[:m]) == case["idx"], case["source"]
+    for case in REF["collect_syncmers"]:
+        a = np.array(case["in"], dtype=np.uint32)
+        out = np.zeros(len(a) + 1, dtype=np.uint32)
+        m = L.mmo_collect_syncmers(a.ctypes.data_as(u32), len(a), case["w"], int(case["open"]),
+                                   out.ctypes.data_as(u32))
+        assert list(out[:m]) == case["out"], case["source"]
+
+
+def test_reference_closed_syncmer_values(oracle):
+    c = REF["closed_syncmer_values"]
+    n = c["n"]
+    packed = oracle.pack_ascii(c["base"].encode() * n)
+    for k in range(*c["k_range"]):
+        for w in range(*c["w_range"]):
+            pos = oracle.run(packed, n, k, w, mode=oracle.CLOSED_SYNCMERS)
+            l = k + w - 1
+            vals = oracle.values_u64(packed, l, pos, False)
+            assert len(vals) == n - l + 1
+            assert all(int(v) == (1 << (2 * l)) - 1 for v in vals)
+
+
+def test_model_anchors(oracle):
+    anchors = json.load(open(os.path.join(GOLD, "model_anchors.json")))
+    g = anchors["generator"]
+    packed = oracle.gen_packed(g["seed"], g["n"])
+    first = "".join("ACTG"[(packed[i >> 2] >> (2 * (i & 3))) & 3] for i in range(32))
+    assert first == g["first32"]
+    for c in anchors["cases"]:
+        r = oracle.run(packed, g["n"], c["k"], c["w"], canonical=c["canonical"], mode=c["mode"])
+        assert len(r) == c["count"] and [int(x) for x in r[:8]] == c["first8"], c["name"]
+        assert oracle.checksum(r) == (c["checksum_weighted"], c["checksum_plain"]), c["name"]
+    for key, canon in (("fwd_hashes_k5", False), ("canonical_hashes_k5", True)):
+        seq = anchors[key]["seq"].encode()
+        h = oracle.hash_kmers(oracle.pack_ascii(seq), len(seq), 5, oracle.default_hasher(canon))
+        assert ["%08x" % x for x in h] == anchors[key]["hashes"]
+
+
+@pytest.mark.parametrize("canonical", [False, True])
+def test_naive_equals_streaming(oracle, canonical):
+    """src/test.rs:53-110: definition == scalar two-stacks path, all (k, w, len, offset)."""
+    rng = np.random.default_rng(42 + canonical)
+    data = oracle.gen_packed(7, 8192 + 8)
+    ks = [1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65] + [int(x) for x in rng.integers(6, 100, size=4)]
+    ws = [1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65] + [int(x) for x in rng.integers(6, 100, size=4)]
+    lens = list(range(0, 100, 9)) + [int(x) for x in rng.integers(100, 8192, size=3)]
+    for k in ks:
+        for w in ws:
+            if canonical and (k + w - 1) % 2 == 0:
+                continue
+            for ln in lens:
+                off = int(rng.integers(0, min(3, ln) + 1))
+                n = ln - off
+                a = oracle.run(data, n, k, w, canonical=canonical, flavour=oracle.NAIVE, base_offset=off)
+                b = oracle.run(data, n, k, w, canonical=canonical, flavour=oracle.STREAMING,
+                               base_offset=off)
+                assert np.array_equal(a, b), (k, w, n, off)
+
+
+def test_rolling_hash_equals_closed_form(oracle):
+    data = oracle.gen_packed(9, 5000)
+    for canon in (False, True):
+        h = oracle.default_hasher(canon)
+        for k in (1, 2, 5, 21, 31, 32, 33, 64, 99):
+            a = oracle.hash_kmers(data, 5000, k, h, rolling=False)
+            b = oracle.hash_kmers(data, 5000, k, h, rolling=True)
+            assert np.array_equal(a, b), (canon, k)
+
+
+def test_sixteen_bit_position_wrap(oracle):
+    """src/sliding_min.rs:117-125: the 16-bit position rebase (never hit by the reference's own
+    tests, which stop at 8192 bases) must not change results."""
+    n = 200_000
+    data = oracle.gen_packed(5, n)
+    for k, w, canon in [(5, 7, False), (21, 11, True), (3, 200, False)]:
+        if canon and (k + w - 1) % 2 == 0:
+            continue
+        a = oracle.run(data, n, k, w, canonical=canon, flavour=oracle.NAIVE)
+        b = oracle.run(data, n, k, w, canonical=canon, flavour=oracle.STREAMING)
+        assert np.array_equal(a, b), (k, w)
+
+
+def test_revcomp_symmetry(oracle):
+    """src/test.rs:112-152 on the oracle itself."""
+    rng = np.random.default_rng(3)
+    for k, w in [(5, 7), (21, 11), (31, 51)]:
+        n = 3001
+        data = oracle.gen_packed(int(rng.integers(1 << 20)), n)
+        rc = oracle.revcomp_packed(data, n)
+        f = oracle.run(data, n, k, w, canonical=True)
+        r = oracle.run(rc, n, k, w, canonical=True)
+        assert len(f) == len(r)
+        assert all(int(x) + int(y) == n - k for x, y in zip(f, r[::-1]))
+        assert np.array_equal(oracle.values_u64(data, k, f, True), oracle.values_u64(rc, k, r, True)[::-1])
+
+
+def test_error_codes(oracle):
+    data = oracle.gen_packed(1, 100)
+    for args, kw in [((data, 100, 5, 6), dict(canonical=True)),       # even l
+                     ((data, 100, 5, 6), dict(mode=oracle.OPEN_SYNCMERS)),  # open, even w
+                     ((data, 100, 5, 0), {}), ((data, 100, 0, 5), {}), ((data, 100, 5, 1 << 15), {})]:
+        with pytest.raises(ValueError):
+            oracle.run(*args, **kw)
+    with pytest.raises(ValueError):
+        oracle.run(data, 100, 5, 7, hasher=oracle.default_hasher(False), canonical=True)
