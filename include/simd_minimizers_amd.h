@@ -93,7 +93,8 @@ uint32_t mm_plan_value_len(const mm_plan_t *plan);
 /* -------------------------------------------------------------- workspace */
 
 /* Device scratch bound to one HIP device and one stream.  `hip_stream` may be NULL
- * (a private stream is created) or a hipStream_t owned by the caller. */
+ * (a private stream is created; it is a blocking stream, i.e. ordered against the legacy
+ * default stream) or a hipStream_t owned by the caller. */
 int mm_workspace_create(mm_workspace_t **out, int device, void *hip_stream);
 void mm_workspace_destroy(mm_workspace_t *ws);
 int mm_workspace_sync(mm_workspace_t *ws);

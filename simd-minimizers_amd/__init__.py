@@ -249,8 +249,17 @@ _default_ws: dict[int, Workspace] = {}
 
 
 def default_workspace(device: int = 0) -> Workspace:
+    """Per-device workspace bound to torch's current stream when torch is importable, so that
+    tensor fills / copies issued through torch are ordered with the engine's kernels."""
     if device not in _default_ws:
-        _default_ws[device] = Workspace(device)
+        stream = None
+        try:
+            import torch
+            if torch.cuda.is_available():
+                stream = torch.cuda.current_stream(device).cuda_stream
+        except ImportError:
+            pass
+        _default_ws[device] = Workspace(device, stream)
     return _default_ws[device]
 
 

@@ -254,7 +254,9 @@ int mm_workspace_create(mm_workspace_t **out, int device, void *hip_stream) {
     if (hip_stream) {
         ws->stream = reinterpret_cast<hipStream_t>(hip_stream);
     } else {
-        hipError_t e = hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking);
+        // a BLOCKING stream: it orders itself against the legacy null stream, so callers that
+        // fill / copy buffers on the default stream (torch does) need no extra events
+        hipError_t e = hipStreamCreateWithFlags(&ws->stream, hipStreamDefault);
         if (e != hipSuccess) {
             delete ws;
             return hip_fail(e, "hipStreamCreate");
