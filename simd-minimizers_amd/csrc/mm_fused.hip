@@ -39,36 +39,34 @@ const Instance *find_instance(uint32_t w, int canonical_windows, int hasher_cano
     return nullptr;
 }
 
-uint32_t gcd_u32(uint32_t a, uint32_t b) { return b ? gcd_u32(b, a % b) : a; }
-
-// W-blocks per lane. With 4-bit offsets (w <= 16) the lane length S = w * nblk must be a
-// multiple of 16 (phase 2 recovers the offset from the low nibble of the window index).
+// W-blocks per lane (S = w * nblk windows per lane).
 uint32_t legal_nblk(uint32_t w, uint32_t want) {
-    if (want == 0) want = (176u + w / 2u) / w;  // about 176 windows per lane
-    if (want == 0) want = 1;
-    if (w <= 16u) {
-        const uint32_t step = 16u / gcd_u32(w, 16u);
-        want = (want + step - 1u) / step * step;
-    }
+    if (want == 0) want = (w <= 16u) ? (132u + w / 2u) / w : (200u + w / 2u) / w;
+    if (want < 2u) want = 2u;                  // umulhi(blk, ceil(2^32 / nblk)) needs nblk >= 2
+    if (want > 255u) want = 255u;              // block index travels in 8 bits of a stage entry
+    while (w * want > 60000u && want > 2u) --want;  // 16-bit element positions inside a lane
     return want;
 }
 
 struct Geometry {
-    uint32_t nblk, S, NB, lds_fl_off, lds_stage_off, lds_bytes;
+    uint32_t nblk, S, NB, lds_stage_off, lds_bytes;
     uint64_t nblocks;
 };
+
+uint32_t planes_per_block(uint32_t w) {
+    const bool nib = w <= 16u;
+    const uint32_t nw = nib ? (w + 7u) / 8u : (w + 3u) / 4u;
+    const bool packed = nib && (w % 8u != 0u) && ((w % 8u) * 4u + w <= 32u);
+    return nw + (packed ? 0u : (w + 31u) / 32u);
+}
 
 Geometry geometry(const RunArgs &a) {
     Geometry g;
     g.nblk = legal_nblk(a.w, a.nblk);
     g.S = a.w * g.nblk;
     g.NB = kFusedThreads * g.S;
-    const bool nib = a.w <= 16u;
-    const uint32_t offb = nib ? (a.w + 1u) / 2u : a.w;
-    const uint32_t flbytes = nib ? 2u : 4u * ((a.w + 31u) / 32u);
-    g.lds_fl_off = (kFusedThreads * g.nblk * offb + 15u) & ~15u;
-    g.lds_stage_off = g.lds_fl_off + ((kFusedThreads * g.nblk * flbytes + 15u) & ~15u);
-    g.lds_bytes = g.lds_stage_off + kFusedWaves * kStageCap * 2u;
+    g.lds_stage_off = (g.nblk * planes_per_block(a.w) * kPlane * 4u + 15u) & ~15u;
+    g.lds_bytes = g.lds_stage_off + kFusedWaves * kStageCap * 4u;
     const uint64_t nwin = a.win_end - a.win_begin;
     g.nblocks = (nwin + g.NB - 1) / g.NB;
     return g;
@@ -97,7 +95,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.nblk = g.nblk;
     p.win_begin = (uint32_t)a.win_begin;
     p.win_end = (uint32_t)a.win_end;
-    p.lds_fl_off = g.lds_fl_off;
+    p.nblk_inv = (uint32_t)((0x100000000ull + g.nblk - 1) / g.nblk);
     p.lds_stage_off = g.lds_stage_off;
     p.out = a.out;
     p.use_ticket = a.use_ticket ? 1u : 0u;

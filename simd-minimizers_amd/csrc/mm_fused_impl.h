@@ -28,7 +28,7 @@
 
 namespace mm {
 
-constexpr uint32_t kStageCap = 512;  // staged outputs per wave and phase-2 iteration
+constexpr uint32_t kStageCap = 384;  // staged outputs (u32) per wave and phase-2 iteration
 
 struct FusedParams {
     SeqView seq;
@@ -37,7 +37,7 @@ struct FusedParams {
     uint32_t nblk;       // W-blocks per lane; S = W * nblk windows per lane
     uint32_t win_begin;  // window range [win_begin, win_end)
     uint32_t win_end;
-    uint32_t lds_fl_off;     // byte offset of the flag words in dynamic LDS
+    uint32_t nblk_inv;       // ceil(2^32 / nblk): blk / nblk == umulhi(blk, nblk_inv) for blk < 2^16
     uint32_t lds_stage_off;  // byte offset of the per-wave staging buffers in dynamic LDS
     uint32_t use_ticket;     // 1: tile id from an atomic ticket (safe mode), 0: blockIdx.x
     uint32_t debug;          // timing experiments only (MM_DEBUG env): 1 no look-back, 2 no emit,
@@ -68,22 +68,32 @@ __device__ __forceinline__ uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) {
 }
 
 // Geometry shared by the kernel and its launcher.
+// Per lane and W-block the kernel keeps NPL dwords in LDS, stored as planes of kPlane dwords
+// (one dword per lane + 1 pad, so both the lane-serial writes of phase 1 and the block-order reads
+// of phase 2 are bank-conflict free):
+//   planes [0, NW)          chosen-k-mer offsets: 4 bits per window when W <= 16 (low nibble of
+//                            the lane-relative element index), else one byte per window
+//   flag words              emit flags, LSB = first window; packed into the spare high bits of
+//                            the last offset plane when they fit (FLAG_PACKED), else NSEG planes
 template <int W>
 struct FusedGeom {
-    static constexpr bool NIB = (W <= 16);               // 4-bit offsets, 16-bit flag words
-    static constexpr int OFFB = NIB ? (W + 1) / 2 : W;   // offset bytes per W-block
-    static constexpr int NSEG = (W + 31) / 32;           // 32-bit flag segments per W-block
-    static constexpr int FLB = NIB ? 2 : 4 * NSEG;       // flag bytes per W-block
+    static constexpr bool NIB = (W <= 16);
+    static constexpr int NW = NIB ? (W + 7) / 8 : (W + 3) / 4;
+    static constexpr int NSEG = (W + 31) / 32;
+    static constexpr bool FLAG_PACKED = NIB && (W % 8 != 0) && ((W % 8) * 4 + W <= 32);
+    static constexpr int FLAG_SHIFT = FLAG_PACKED ? (W % 8) * 4 : 0;
+    static constexpr int NPL = NW + (FLAG_PACKED ? 0 : NSEG);
     static constexpr int G = (W <= 32) ? (32 / W) : 1;   // W-blocks combined per phase-2 item
     static constexpr int NSUB = (W + 15) / 16;           // 16-base view words per W-block
 };
+constexpr uint32_t kPlane = kFusedThreads + 1;  // dwords per plane
 
 template <int W, bool CANON, bool HASH_RC, int MODE>
 __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams p) {
     static_assert(W >= 1 && W <= 255, "window offsets are stored in at most a byte");
     using GE = FusedGeom<W>;
-    constexpr bool NIB = GE::NIB;
-    constexpr int OFFB = GE::OFFB, NSEG = GE::NSEG, G = GE::G, NSUB = GE::NSUB;
+    constexpr bool NIB = GE::NIB, FLAG_PACKED = GE::FLAG_PACKED;
+    constexpr int NW = GE::NW, NPL = GE::NPL, NSEG = GE::NSEG, G = GE::G, NSUB = GE::NSUB;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // static LDS: distinct objects, so table look-ups can be scheduled across the dynamic stores
     __shared__ uint2 s_tab[20];  // [0..15] (out<<2)|in, [16..19] in only (warm-up)
@@ -109,9 +119,8 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         (uint32_t)(((uint64_t)p.win_end - bw0) < NB ? ((uint64_t)p.win_end - bw0) : NB);
     const bool partial = nvalid < NB;
 
-    uint8_t *offs = smem;                          // [256 * nblk * OFFB]
-    uint8_t *flb = smem + p.lds_fl_off;            // [256 * nblk * FLB]
-    uint16_t *stage = reinterpret_cast<uint16_t *>(smem + p.lds_stage_off) + wave * kStageCap;
+    uint32_t *planes = reinterpret_cast<uint32_t *>(smem);  // [nblk][NPL][kPlane]
+    uint32_t *stage = reinterpret_cast<uint32_t *>(smem + p.lds_stage_off) + wave * kStageCap;
 
     // ---------------------------------------------------------------- phase 1
     const uint32_t lw = (uint32_t)tid * S;  // first window of this lane, tile-relative
@@ -241,8 +250,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         if (bw0 + lw == 0) prev = 0xffffffffu;  // the very first window has no predecessor
 
         // ---- blocks 1..nblk: one window per step
-        uint8_t *offs_blk = offs + (uint32_t)tid * nblk * OFFB;
-        uint8_t *fl_blk = flb + (uint32_t)tid * nblk * GE::FLB;
+        uint32_t *pl_blk = planes + tid;  // this lane's column; advances NPL planes per block
         int rem_valid = (int)nvalid - (int)lw;  // windows of this lane still inside the range
         for (uint32_t b = 1; b <= nblk; ++b) {
             uint32_t me[NSUB], mo[NSUB], tgw[NSUB];
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
             }
 
             const uint32_t e0 = b * (uint32_t)W;  // element index of step j = 0
-            uint32_t pl = 0, pr_ = 0, fmask = 0, nib = 0;
+            uint32_t pl = 0, pr_ = 0, fmask = 0, acc = 0;
 #pragma unroll
             for (int j = 0; j < W; ++j) {
                 const uint32_t e = e0 + (uint32_t)j;  // uniform
@@ -306,15 +314,23 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
                     asm("v_cmp_ne_u16 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                         : "+v"(fmask) : "v"(sel), "v"(prev) : "vcc");
                     prev = sel;
+                    // Offsets are shifted into acc from the top (v_alignbit): 4 bits (low nibble of
+                    // the chosen element index; phase 2 subtracts the window's own index) or 8 bits
+                    // (offset inside the window) per step; a full dword goes to its plane.
                     if (NIB) {
-                        // low nibble of the chosen element index; phase 2 subtracts the window
-                        // index (S is a multiple of 16 in this mode)
-                        if ((j & 1) == 0) nib = sel & 15u;
-                        if ((j & 1) == 1 || j == W - 1)
-                            offs_blk[j >> 1] = (uint8_t)((j & 1) ? (nib | (sel << 4)) : nib);
+                        acc = __builtin_amdgcn_alignbit(sel, acc, 4);
+                        if ((j & 7) == 7 || j == W - 1) {
+                            const int cntn = (j & 7) + 1;
+                            uint32_t wv = cntn == 8 ? acc : (acc >> (32 - 4 * cntn));
+                            if (!(FLAG_PACKED && j == W - 1)) pl_blk[(j >> 3) * kPlane] = wv;
+                            else acc = wv;  // stored together with the flags below
+                        }
                     } else {
-                        // offset of the chosen k-mer inside the window
-                        offs_blk[j] = (uint8_t)(sel - (e - (uint32_t)W + 1u));
+                        acc = __builtin_amdgcn_alignbit(sel - (e - (uint32_t)W + 1u), acc, 8);
+                        if ((j & 3) == 3 || j == W - 1) {
+                            const int cntb = (j & 3) + 1;
+                            pl_blk[(j >> 2) * kPlane] = cntb == 4 ? acc : (acc >> (32 - 8 * cntb));
+                        }
                     }
                 } else if (MODE == 1) {
                     const uint32_t first = e - (uint32_t)W + 1u;
@@ -337,8 +353,8 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
                         f = v <= 0 ? 0u : (v >= seglen ? f : (f & ((1u << v) - 1u)));
                     }
                     my_count += __popc(f);
-                    if (NIB) *reinterpret_cast<uint16_t *>(fl_blk) = (uint16_t)f;
-                    else reinterpret_cast<uint32_t *>(fl_blk)[seg] = f;
+                    if (FLAG_PACKED) pl_blk[(NW - 1) * kPlane] = (MODE == 0 ? acc : 0u) | (f << GE::FLAG_SHIFT);
+                    else pl_blk[(NW + seg) * kPlane] = f;
                     fmask = 0;
                 }
 
@@ -355,8 +371,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
                 ring_l[j] = min(ring_l[j], ring_l[j + 1]);
                 if (CANON) ring_r[j] = max(ring_r[j], ring_r[j + 1]);
             }
-            offs_blk += OFFB;
-            fl_blk += GE::FLB;
+            pl_blk += NPL * kPlane;
             rem_valid -= W;
         }
     }
@@ -382,67 +397,72 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     }
     __syncthreads();
 
-    // Items: G consecutive W-blocks (W <= 32) or one 32-window segment (W > 32), in window order.
+    // Items: G consecutive W-blocks (W <= 32) or one 32-window segment (W > 32), in window order
+    // (lane-major: W-block blk of the wave belongs to lane blk / nblk, block blk % nblk).
     const unsigned long long run0 = s_excl + wave_base;
     uint32_t run = 0;  // outputs of this wave emitted so far
-    const uint32_t wave_blk0 = (uint32_t)wave * kWave * nblk;    // first W-block of this wave
-    const uint32_t items = (NSEG == 1) ? (kWave * nblk + G - 1) / G : kWave * nblk * NSEG;
-    const uint32_t wave_win0 = wave_blk0 * (uint32_t)W;          // tile-relative
+    const uint32_t wave_blocks = kWave * nblk;
+    const uint32_t items = (NSEG == 1) ? (wave_blocks + G - 1) / G : wave_blocks * NSEG;
     const uint32_t bw0_lo = (uint32_t)bw0;
+    const uint32_t tid0 = (uint32_t)wave * kWave;
     uint32_t *outp = p.out.pos;
     uint32_t *outs = p.out.sk;
     for (uint32_t it0 = 0; it0 < items && !(p.debug & 2u); it0 += kWave) {
         const uint32_t it = it0 + lane;
-        uint32_t wrel;  // wave-relative first window of the item
-        uint32_t f = 0;
-        if (NSEG == 1) {
-            wrel = it * (uint32_t)(G * W);
-            if (it < items && wave_win0 + wrel < nvalid) {
+        uint32_t fg[G], ent[G];  // flags and entry prefix (bb << 8 | tid << 16) per combined block
+        uint32_t c = 0;
+        uint32_t first_win = 0xffffffffu;  // tile-relative first window of the item
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const uint32_t blk = it * G + g;
-                    if (blk < kWave * nblk) {
-                        const uint8_t *fp = flb + (size_t)(wave_blk0 + blk) * GE::FLB;
-                        const uint32_t w = NIB ? (uint32_t)*reinterpret_cast<const uint16_t *>(fp)
-                                               : *reinterpret_cast<const uint32_t *>(fp);
-                        // blocks of lanes past the valid range were never written
-                        f |= (wave_win0 + blk * (uint32_t)W < nvalid ? w : 0u) << (g * W);
-                    }
-                }
+        for (int g = 0; g < G; ++g) {
+            const uint32_t blk = (NSEG == 1) ? it * G + g : it / NSEG;
+            const uint32_t seg = (NSEG == 1) ? 0u : it - blk * NSEG;
+            const uint32_t lw_ = __umulhi(blk, p.nblk_inv);  // wave-relative lane
+            const uint32_t bb = blk - lw_ * nblk;
+            const uint32_t tl = tid0 + lw_;
+            const uint32_t win = tl * S + bb * (uint32_t)W + 32u * seg;
+            if (g == 0) first_win = win;
+            uint32_t f = 0;
+            // blocks of lanes past the valid range were never written
+            if (it < items && blk < wave_blocks && win < nvalid) {
+                const uint32_t w = planes[(bb * NPL + (FLAG_PACKED ? NW - 1 : NW + seg)) * kPlane + tl];
+                f = FLAG_PACKED ? (w >> GE::FLAG_SHIFT) : w;
             }
-        } else {
-            const uint32_t blk = it / NSEG, seg = it - blk * NSEG;
-            wrel = blk * (uint32_t)W + 32u * seg;
-            if (it < items && wave_win0 + blk * (uint32_t)W < nvalid)
-                f = reinterpret_cast<const uint32_t *>(flb)[(size_t)(wave_blk0 + blk) * NSEG + seg];
+            fg[g] = f;
+            ent[g] = (bb << 8) | (tl << 16) | (32u * seg);
+            c += __popc(f);
         }
-        if (__builtin_amdgcn_readfirstlane(wave_win0 + wrel) >= nvalid) break;  // items are in window order
-        const uint32_t c = __popc(f);
+        if (__builtin_amdgcn_readfirstlane(first_win) >= nvalid) break;  // items are in window order
         const uint32_t incl = wave_scan_dpp(c);
         const uint32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
         const unsigned long long base = run0 + run;
+        // value of one emitted window from its entry (j | bb << 8 | tid << 16)
+        auto emit_value = [&](uint32_t e, uint32_t &widx) -> uint32_t {
+            const uint32_t j = e & 0xffu, bb = (e >> 8) & 0xffu, tl = e >> 16;
+            const uint32_t lwin = bb * (uint32_t)W + j;  // lane-relative window
+            widx = bw0_lo + tl * S + lwin;
+            if (MODE != 0) return widx;
+            if (NIB) {
+                const uint32_t wv = planes[(bb * NPL + (j >> 3)) * kPlane + tl];
+                return widx + (((wv >> (4u * (j & 7u))) - (lwin + 1u)) & 15u);
+            }
+            const uint32_t wv = planes[(bb * NPL + (j >> 2)) * kPlane + tl];
+            return widx + ((wv >> (8u * (j & 3u))) & 0xffu);
+        };
         if (total <= kStageCap) {
-            // stage wave-relative window indices in order, then coalesced stores
+            // stage the entries in window order, then coalesced stores
             uint32_t slot = incl - c;
-            while (f) {
-                const uint32_t bit = __builtin_ctz(f);
-                f &= f - 1u;
-                stage[slot++] = (uint16_t)(wrel + bit);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                uint32_t f = fg[g];
+                while (f) {
+                    const uint32_t bit = __builtin_ctz(f);
+                    f &= f - 1u;
+                    stage[slot++] = ent[g] + bit;
+                }
             }
             for (uint32_t i = lane; i < total; i += kWave) {
-                const uint32_t wr = stage[i];
-                const uint32_t wi = wave_win0 + wr;  // tile-relative window
-                const uint32_t widx = bw0_lo + wi;
-                uint32_t val = widx;
-                if (MODE == 0) {
-                    const uint32_t blk = wi / (uint32_t)W, j = wi - blk * (uint32_t)W;
-                    if (NIB) {
-                        const uint32_t byte = offs[blk * OFFB + (j >> 1)];
-                        val += (((j & 1) ? (byte >> 4) : byte) - (wi + 1u)) & 15u;
-                    } else {
-                        val += offs[blk * OFFB + j];
-                    }
-                }
+                uint32_t widx;
+                const uint32_t val = emit_value(stage[i], widx);
                 if (base + i < p.out.cap) {
                     outp[base + i] = val;
                     if (MODE == 0 && outs) outs[base + i] = widx;
@@ -451,26 +471,20 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         } else {
             // dense region (more than kStageCap outputs in one iteration): direct ordered stores
             unsigned long long dst = base + (incl - c);
-            while (f) {
-                const uint32_t bit = __builtin_ctz(f);
-                f &= f - 1u;
-                const uint32_t wi = wave_win0 + wrel + bit;
-                const uint32_t widx = bw0_lo + wi;
-                uint32_t val = widx;
-                if (MODE == 0) {
-                    const uint32_t blk = wi / (uint32_t)W, j = wi - blk * (uint32_t)W;
-                    if (NIB) {
-                        const uint32_t byte = offs[blk * OFFB + (j >> 1)];
-                        val += (((j & 1) ? (byte >> 4) : byte) - (wi + 1u)) & 15u;
-                    } else {
-                        val += offs[blk * OFFB + j];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                uint32_t f = fg[g];
+                while (f) {
+                    const uint32_t bit = __builtin_ctz(f);
+                    f &= f - 1u;
+                    uint32_t widx;
+                    const uint32_t val = emit_value(ent[g] + bit, widx);
+                    if (dst < p.out.cap) {
+                        outp[dst] = val;
+                        if (MODE == 0 && outs) outs[dst] = widx;
                     }
+                    ++dst;
                 }
-                if (dst < p.out.cap) {
-                    outp[dst] = val;
-                    if (MODE == 0 && outs) outs[dst] = widx;
-                }
-                ++dst;
             }
         }
         run += total;
