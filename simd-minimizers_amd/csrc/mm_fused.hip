@@ -18,11 +18,16 @@ struct Instance {
     uint32_t w;
     bool canon;
     bool hash_rc;
-    KernelFn fn[3];  // per mode: minimizers, closed syncmers, open syncmers
+    KernelFn fn[4];  // minimizers, closed syncmers, open syncmers, minimizers + super-k-mer indices
 };
 
-#define MM_INST(W, C, R) \
-    { W, C, R, { &fused_kernel<W, C, R, 0>, &fused_kernel<W, C, R, 1>, &fused_kernel<W, C, R, 2> } }
+#define MM_INST(W, C, R)                                                                    \
+    {                                                                                       \
+        W, C, R, {                                                                          \
+            &fused_kernel<W, C, R, 0, false>, &fused_kernel<W, C, R, 1, false>,             \
+                &fused_kernel<W, C, R, 2, false>, &fused_kernel<W, C, R, 0, true>           \
+        }                                                                                   \
+    }
 
 // canonical windows (canonical hasher) and forward windows (forward hasher)
 const Instance kInstances[] = {
@@ -42,31 +47,29 @@ const Instance *find_instance(uint32_t w, int canonical_windows, int hasher_cano
 // W-blocks per lane (S = w * nblk windows per lane).
 uint32_t legal_nblk(uint32_t w, uint32_t want) {
     if (want == 0) want = (w <= 16u) ? (132u + w / 2u) / w : (200u + w / 2u) / w;
-    if (want < 2u) want = 2u;                  // umulhi(blk, ceil(2^32 / nblk)) needs nblk >= 2
-    if (want > 255u) want = 255u;              // block index travels in 8 bits of a stage entry
-    while (w * want > 60000u && want > 2u) --want;  // 16-bit element positions inside a lane
+    if (want < 1u) want = 1u;
+    while (w * want > 60000u && want > 1u) --want;  // 16-bit element positions inside a lane
     return want;
 }
 
 struct Geometry {
-    uint32_t nblk, S, NB, lds_stage_off, lds_bytes;
+    uint32_t nblk, S, NB, list_cap, lds_bytes;
     uint64_t nblocks;
 };
-
-uint32_t planes_per_block(uint32_t w) {
-    const bool nib = w <= 16u;
-    const uint32_t nw = nib ? (w + 7u) / 8u : (w + 3u) / 4u;
-    const bool packed = nib && (w % 8u != 0u) && ((w % 8u) * 4u + w <= 32u);
-    return nw + (packed ? 0u : (w + 31u) / 32u);
-}
 
 Geometry geometry(const RunArgs &a) {
     Geometry g;
     g.nblk = legal_nblk(a.w, a.nblk);
     g.S = a.w * g.nblk;
     g.NB = kFusedThreads * g.S;
-    g.lds_stage_off = (g.nblk * planes_per_block(a.w) * kPlane * 4u + 15u) & ~15u;
-    g.lds_bytes = g.lds_stage_off + kFusedWaves * kStageCap * 4u;
+    // Lane list capacity: 1.3 x the expected number of emitted windows + 8 (> 5 sigma on random
+    // sequence; denser tiles take the in-kernel redo path) + one W-block of head-room, because
+    // the kernel checks the remaining room once per W-block.
+    const double density = (a.mode == 2) ? 1.0 / a.w : (a.mode == 1 ? 2.0 / a.w : 2.0 / (a.w + 1.0));
+    uint32_t cap = (uint32_t)(1.3 * density * g.S) + 8u + a.w;
+    if (cap > g.S + a.w) cap = g.S + a.w;
+    g.list_cap = cap;
+    g.lds_bytes = cap * kListStride * ((a.out.sk && a.mode == 0) ? 2u : 1u);
     const uint64_t nwin = a.win_end - a.win_begin;
     g.nblocks = (nwin + g.NB - 1) / g.NB;
     return g;
@@ -95,8 +98,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.nblk = g.nblk;
     p.win_begin = (uint32_t)a.win_begin;
     p.win_end = (uint32_t)a.win_end;
-    p.nblk_inv = (uint32_t)((0x100000000ull + g.nblk - 1) / g.nblk);
-    p.lds_stage_off = g.lds_stage_off;
+    p.list_cap = g.list_cap;
     p.out = a.out;
     p.use_ticket = a.use_ticket ? 1u : 0u;
     {
@@ -104,7 +106,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         p.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
     }
     if (a.mode > 2) return -2;
-    KernelFn fn = inst->fn[a.mode];
+    KernelFn fn = inst->fn[(a.mode == 0 && a.out.sk) ? 3 : a.mode];
 
     if (g.lds_bytes > 64u * 1024u) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
