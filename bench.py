@@ -156,7 +156,7 @@ def main():
             "config": {"workload": f"canonical minimizers k={K} w={W}, one {n} bp PackedSeq per GPU "
                                    f"(generator G seed {SEED}+rank), device-resident input and output",
                        "k": K, "w": W, "bases_per_gpu": n, "outputs_per_gpu": n_out,
-                       "kernel": "mm::fused_kernel<11, true, true>", "parallelism": f"shard{world}"},
+                       "kernel": "mm::fused_kernel<11, true, true, 0, false>", "parallelism": f"shard{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel_ms": round(kern_s * 1e3, 4), "algorithmic_bytes": alg_bytes},

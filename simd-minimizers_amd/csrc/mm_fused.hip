@@ -4,6 +4,7 @@
 // k and the hasher tables are runtime parameters.  Window sizes without an instance fall
 // back to the generic family (mm_generic.hip) — still HIP, never the CPU.
 #include "mm_fused_impl.h"
+#include "mm_fused_inst.h"
 #include "mm_launch.h"
 
 #include <cstdlib>
@@ -12,41 +13,37 @@ namespace mm {
 
 namespace {
 
-using KernelFn = void (*)(const FusedParams);
-
-struct Instance {
-    uint32_t w;
-    bool canon;
-    bool hash_rc;
-    KernelFn fn[4];  // minimizers, closed syncmers, open syncmers, minimizers + super-k-mer indices
-};
-
-#define MM_INST(W, C, R)                                                                    \
-    {                                                                                       \
-        W, C, R, {                                                                          \
-            &fused_kernel<W, C, R, 0, false>, &fused_kernel<W, C, R, 1, false>,             \
-                &fused_kernel<W, C, R, 2, false>, &fused_kernel<W, C, R, 0, true>           \
-        }                                                                                   \
-    }
-
-// canonical windows (canonical hasher) and forward windows (forward hasher)
-const Instance kInstances[] = {
-    MM_INST(11, true, true),  MM_INST(51, true, true),  MM_INST(17, true, true),
-    MM_INST(7, true, true),   MM_INST(5, true, true),   MM_INST(19, true, true),
-    MM_INST(11, false, false), MM_INST(7, false, false), MM_INST(5, false, false),
-    MM_INST(19, false, false), MM_INST(17, false, false),
-};
+using KernelFn = FusedKernelFn;
+using Instance = FusedInstance;
 
 const Instance *find_instance(uint32_t w, int canonical_windows, int hasher_canonical) {
-    for (const Instance &i : kInstances)
-        if (i.w == w && i.canon == (canonical_windows != 0) && i.hash_rc == (hasher_canonical != 0))
-            return &i;
+    using Getter = const Instance *(*)(int *);
+    static const Getter kGroups[] = {fused_instances_a, fused_instances_b, fused_instances_c,
+                                     fused_instances_d, fused_instances_e};
+    for (Getter get : kGroups) {
+        int n = 0;
+        const Instance *inst = get(&n);
+        for (int i = 0; i < n; ++i)
+            if (inst[i].w == w && inst[i].canon == (canonical_windows != 0) &&
+                inst[i].hash_rc == (hasher_canonical != 0))
+                return &inst[i];
+    }
     return nullptr;
 }
 
-// W-blocks per lane (S = w * nblk windows per lane).
-uint32_t legal_nblk(uint32_t w, uint32_t want) {
-    if (want == 0) want = (w <= 16u) ? (132u + w / 2u) / w : (200u + w / 2u) / w;
+double emit_density(uint32_t w, uint32_t mode) {
+    return mode == 2 ? 1.0 / w : (mode == 1 ? 2.0 / w : 2.0 / (w + 1.0));
+}
+
+// W-blocks per lane (S = w * nblk windows per lane).  Default: the longest lane whose list
+// (1.3 x expected + 8 + w entries of kListStride bytes) keeps a workgroup near 40 KB of LDS
+// (4 workgroups per CU), but at least 12 W-blocks so that the k+w warm-up of a lane is amortised.
+uint32_t legal_nblk(uint32_t w, uint32_t mode, uint32_t want) {
+    if (want == 0) {
+        const double s_lds = (69.0 - (double)w) / (1.3 * emit_density(w, mode));
+        const double s = s_lds > 12.0 * w ? s_lds : 12.0 * w;
+        want = (uint32_t)(s / w + 0.5);
+    }
     if (want < 1u) want = 1u;
     while (w * want > 60000u && want > 1u) --want;  // 16-bit element positions inside a lane
     return want;
@@ -59,14 +56,13 @@ struct Geometry {
 
 Geometry geometry(const RunArgs &a) {
     Geometry g;
-    g.nblk = legal_nblk(a.w, a.nblk);
+    g.nblk = legal_nblk(a.w, a.mode, a.nblk);
     g.S = a.w * g.nblk;
     g.NB = kFusedThreads * g.S;
     // Lane list capacity: 1.3 x the expected number of emitted windows + 8 (> 5 sigma on random
     // sequence; denser tiles take the in-kernel redo path) + one W-block of head-room, because
     // the kernel checks the remaining room once per W-block.
-    const double density = (a.mode == 2) ? 1.0 / a.w : (a.mode == 1 ? 2.0 / a.w : 2.0 / (a.w + 1.0));
-    uint32_t cap = (uint32_t)(1.3 * density * g.S) + 8u + a.w;
+    uint32_t cap = (uint32_t)(1.3 * emit_density(a.w, a.mode) * g.S) + 8u + a.w;
     if (cap > g.S + a.w) cap = g.S + a.w;
     g.list_cap = cap;
     g.lds_bytes = cap * kListStride * ((a.out.sk && a.mode == 0) ? 2u : 1u);

@@ -1,0 +1,30 @@
+// mm_fused_inst.h — table entry describing one specialisation of the fused kernel.
+#pragma once
+#include "mm_fused_impl.h"
+
+namespace mm {
+
+using FusedKernelFn = void (*)(const FusedParams);
+
+struct FusedInstance {
+    uint32_t w;
+    bool canon;    // canonical windows (strand vote)
+    bool hash_rc;  // canonical hasher (forward + reverse-complement hash)
+    FusedKernelFn fn[4];  // minimizers, closed syncmers, open syncmers, minimizers + super-k-mers
+};
+
+#define MM_FUSED_INST(W, C, R)                                                              \
+    {                                                                                       \
+        W, C, R, {                                                                          \
+            &fused_kernel<W, C, R, 0, false>, &fused_kernel<W, C, R, 1, false>,             \
+                &fused_kernel<W, C, R, 2, false>, &fused_kernel<W, C, R, 0, true>           \
+        }                                                                                   \
+    }
+
+const FusedInstance *fused_instances_a(int *count);
+const FusedInstance *fused_instances_b(int *count);
+const FusedInstance *fused_instances_c(int *count);
+const FusedInstance *fused_instances_d(int *count);
+const FusedInstance *fused_instances_e(int *count);
+
+}  // namespace mm

@@ -1,0 +1,17 @@
+// Explicit instantiations of the fused kernel (split over several files so that the
+// build parallelises); the launcher in mm_fused.hip looks them up through fused_instances_d().
+#include "mm_fused_impl.h"
+#include "mm_fused_inst.h"
+
+namespace mm {
+
+const FusedInstance *fused_instances_d(int *count) {
+    static const FusedInstance kInst[] = {
+        MM_FUSED_INST(17, true, true),
+        MM_FUSED_INST(19, true, true),
+    };
+    *count = (int)(sizeof(kInst) / sizeof(kInst[0]));
+    return kInst;
+}
+
+}  // namespace mm
