@@ -78,10 +78,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    distributed = "RANK" in os.environ and "MASTER_PORT" in os.environ  # launched by torchrun
+    torch.cuda.set_device(local_rank)
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
     import simd_minimizers_amd as sm
@@ -110,23 +111,28 @@ def main():
 
     ws.enable_timing(True)
     ws.kernel_time(True)
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if distributed:
         dist.barrier()
+    torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     kern_ms, launches = ws.kernel_time(True)
     ws.enable_timing(False)
 
-    if world > 1:
+    if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank must have produced a plausible result (density ~ 2/(w+1))
+        ok = torch.tensor([1 if abs(n_out / n - 2.0 / (W + 1)) < 0.01 else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        assert int(ok.item()) == 1, "a rank produced an implausible number of minimizers"
 
     if rank == 0:
         total_bases = float(n) * world * args.steps
@@ -164,7 +170,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -363,3 +363,68 @@ def test_device_values_and_generator(sm, oracle, gpu):
         gpu.sync()
         want = oracle.values_u64(host, ln, out[:c].cpu().numpy().view(np.uint32), canonical)
         assert np.array_equal(vals.cpu().numpy().view(np.uint64), want), (k, w, mode)
+
+
+def _device_checksum(t, c):
+    """(count, sum, order-sensitive weighted sum mod 2^64) of the first c int32 entries."""
+    import torch
+    v = t[:c].to(torch.int64) & 0xFFFFFFFF
+    plain = int(v.sum().item())
+    weighted = 0
+    step = 1 << 27
+    for a in range(0, c, step):
+        e = min(c, a + step)
+        idx = torch.arange(a + 1, e + 1, dtype=torch.int64, device=t.device)
+        weighted = (weighted + int((v[a:e] * idx).sum().item())) & ((1 << 64) - 1)
+    return c, plain, weighted
+
+
+def test_full_size_properties(sm, oracle, gpu):
+    """BASELINE's full size (3.1 Gbp, canonical k=21 w=11) through size-independent properties:
+    fused kernel == generic kernel family (independent implementation) == concatenation of
+    window-range shards, by count and an order-sensitive checksum; densities as expected; and
+    the first / last megabase against the oracle."""
+    import torch
+    n, k, w = 3_100_000_000, 21, 11
+    d = sm.generate_device(n, 3)
+    cap = int(n * 2.3 / (w + 1))
+    out = torch.empty(cap, dtype=torch.int32, device="cuda")
+    b = sm.canonical_minimizers(k, w)
+    c = b.run_device(d, n, out)
+    assert gpu.last_path() == sm.PATH_FUSED
+    assert abs(c / n - 2.0 / (w + 1)) < 1e-3
+    whole = _device_checksum(out, c)
+    # head and tail against the oracle
+    m = 1_000_000
+    head = oracle.run(oracle.gen_packed(3, m + 64), m + 64, k, w, canonical=True)
+    head = head[head < m - 64]
+    got_head = out[: len(head)].cpu().numpy().view(np.uint32)
+    assert np.array_equal(got_head, head)
+    tail_start = n - m
+    tail = oracle.run(oracle.gen_packed(3, m, first_base=tail_start), m, k, w, canonical=True)
+    got_tail = out[c - len(tail) + 50: c].cpu().numpy().view(np.uint32).astype(np.int64) - tail_start
+    assert np.array_equal(got_tail, tail[50:].astype(np.int64))
+    # monotone-ish: canonical positions never jump back by w or more
+    diffs = (out[1:c].to(torch.int64) & 0xFFFFFFFF) - (out[: c - 1].to(torch.int64) & 0xFFFFFFFF)
+    assert int(diffs.min().item()) > -w
+    del diffs
+    # window-range shards
+    nw = n - (k + w - 1) + 1
+    cuts = [0, nw // 3 + 11, 2 * nw // 3 - 5, nw]
+    tot_c, tot_plain, tot_weighted = 0, 0, 0
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        cc = b.run_device(d, n, out, win_begin=a, win_end=e)
+        _, plain, weighted = _device_checksum(out, cc)
+        # re-base the weighted sum: indices of this shard start at tot_c
+        tot_weighted = (tot_weighted + weighted + tot_c * plain) & ((1 << 64) - 1)
+        tot_plain += plain
+        tot_c += cc
+    assert (tot_c, tot_plain, tot_weighted) == whole
+    # generic family
+    gpu.force_generic(True)
+    try:
+        cg = b.run_device(d, n, out)
+        assert gpu.last_path() == sm.PATH_GENERIC
+        assert _device_checksum(out, cg) == whole
+    finally:
+        gpu.force_generic(False)
