@@ -420,3 +420,131 @@ void mmo_checksum(const uint32_t *v, uint64_t n, uint64_t *weighted, uint64_t *p
     *weighted = a;
     *plain = b;
 }
+
+/* ------------------------------------------------ faster port for timing
+ * Same algorithm as positions_streaming + collect_and_dedup (src/minimizers.rs:74-129,
+ * src/sliding_min.rs:145-212, src/collect.rs:15-37), fused into one pass without the
+ * per-window intermediate array, and optionally spread over threads by window range (like the
+ * reference's rayon-over-contigs benchmark, bench/src/bin/paper.rs:442-459).  Used only as the
+ * cpu_baseline of bench.py and checked against mmo_run by the tests. */
+#include <pthread.h>
+
+typedef struct {
+    const uint8_t *packed;
+    uint64_t off, n;
+    uint32_t k, w;
+    const mmo_hasher *h;
+    int canonical;
+    uint64_t win_begin, win_end;
+    uint32_t *out;
+    uint64_t cap, count;
+} fast_job;
+
+static void fast_range(fast_job *jb) {
+    const uint8_t *packed = jb->packed;
+    const uint64_t off = jb->off;
+    const uint32_t k = jb->k, w = jb->w;
+    const uint64_t l = (uint64_t)k + w - 1;
+    const int canonical = jb->canonical;
+    /* element 0 = k-mer (win_begin - 1) when it exists, so that the seam dedup is exact */
+    const uint64_t first_km = jb->win_begin > 0 ? jb->win_begin - 1 : 0;
+    const int have_prev = jb->win_begin > 0;
+    roll_state st;
+    roll_init(&st, jb->h, k);
+    lrmin_state lr;
+    jb->count = 0;
+    if (lrmin_init(&lr, w)) return;
+    uint64_t a = first_km; /* next base to consume */
+    for (uint32_t j = 0; j + 1 < k; ++j, ++a) roll_push(&st, mmo_base(packed, off + a));
+    int64_t cnt = 0;
+    if (canonical) {
+        /* T/G count of the first l-1 bases of the first window */
+        cnt = -(int64_t)l;
+        for (uint64_t j = first_km; j + 1 < first_km + l; ++j) cnt += mmo_base(packed, off + j) & 2u;
+    }
+    uint32_t left, right, prev = 0;
+    int first = 1;
+    uint64_t m = 0;
+    /* k-mers first_km .. win_end + w - 2; window i completes with k-mer i + w - 1 */
+    const uint64_t last_km = jb->win_end + w - 1; /* exclusive */
+    for (uint64_t km = first_km; km < last_km; ++km, ++a) {
+        uint32_t c = mmo_base(packed, off + a);
+        if (km == first_km) roll_push(&st, c);
+        else roll_step(&st, c, mmo_base(packed, off + a - k));
+        lrmin_push(&lr, roll_value(&st), &left, &right);
+        if (km + 1 < first_km + w) continue; /* window not complete yet */
+        uint64_t i = km + 1 - w;             /* window index */
+        uint32_t pos = left;
+        if (canonical) {
+            cnt += c & 2u;
+            pos = cnt > 0 ? left : right;
+            cnt -= mmo_base(packed, off + i) & 2u;
+        }
+        pos += (uint32_t)first_km;
+        if (i >= jb->win_begin) {
+            if ((first && !have_prev) || pos != prev) {
+                if (m < jb->cap) jb->out[m] = pos;
+                ++m;
+            }
+        }
+        prev = pos;
+        first = 0;
+    }
+    lrmin_free(&lr);
+    jb->count = m;
+}
+
+static void *fast_thread(void *p) {
+    fast_range((fast_job *)p);
+    return NULL;
+}
+
+/* Minimizer positions (mode 0) with `threads` worker threads; returns the count or MMO_ERR_*. */
+int64_t mmo_run_fast(const uint8_t *packed, uint64_t off, uint64_t n, uint32_t k, uint32_t w,
+                     const mmo_hasher *h, int canonical, int threads, uint32_t *out_pos, uint64_t cap) {
+    int e = check_params(n, k, w, h, canonical);
+    if (e) return e;
+    uint64_t l = (uint64_t)k + w - 1;
+    if (n < l) return 0;
+    uint64_t nw = n - l + 1;
+    if (threads < 1) threads = 1;
+    if ((uint64_t)threads > nw) threads = (int)nw;
+    fast_job *jobs = (fast_job *)calloc((size_t)threads, sizeof(fast_job));
+    pthread_t *tids = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    uint64_t per = (nw + threads - 1) / threads;
+    uint64_t slot = (uint64_t)((double)per * 2.2 / (w + 1.0)) + 1024;
+    if (slot > per) slot = per;
+    int ok = 1;
+    for (int t = 0; t < threads; ++t) {
+        fast_job *jb = &jobs[t];
+        jb->packed = packed; jb->off = off; jb->n = n; jb->k = k; jb->w = w; jb->h = h;
+        jb->canonical = canonical;
+        jb->win_begin = (uint64_t)t * per < nw ? (uint64_t)t * per : nw;
+        jb->win_end = (uint64_t)(t + 1) * per < nw ? (uint64_t)(t + 1) * per : nw;
+        jb->cap = (t == 0 && threads == 1) ? cap : slot;
+        jb->out = (t == 0 && threads == 1) ? out_pos : (uint32_t *)malloc(sizeof(uint32_t) * (size_t)slot);
+        if (!jb->out) ok = 0;
+    }
+    int64_t total = MMO_ERR_CAPACITY;
+    if (ok) {
+        if (threads == 1) fast_range(&jobs[0]);
+        else {
+            for (int t = 0; t < threads; ++t) pthread_create(&tids[t], NULL, fast_thread, &jobs[t]);
+            for (int t = 0; t < threads; ++t) pthread_join(tids[t], NULL);
+        }
+        uint64_t m = 0;
+        int fits = 1;
+        for (int t = 0; t < threads; ++t) {
+            if (jobs[t].count > jobs[t].cap) fits = 0;
+            if (threads > 1 && fits && m + jobs[t].count <= cap)
+                memcpy(out_pos + m, jobs[t].out, sizeof(uint32_t) * (size_t)jobs[t].count);
+            m += jobs[t].count;
+        }
+        total = (fits && m <= cap) ? (int64_t)m : MMO_ERR_CAPACITY;
+    }
+    if (threads > 1)
+        for (int t = 0; t < threads; ++t) free(jobs[t].out);
+    free(jobs);
+    free(tids);
+    return total;
+}

@@ -99,6 +99,12 @@ int64_t mmo_run(const uint8_t *packed, uint64_t base_offset, uint64_t n, uint32_
                 const mmo_hasher *h, int canonical_windows, int mode, int flavour,
                 uint32_t *out_pos, uint32_t *out_sk, uint64_t cap);
 
+/* One-pass, optionally multi-threaded port of the minimizer path (mode 0), used as the timed
+ * cpu_baseline of bench.py; same output as mmo_run(..., MMO_MINIMIZERS, ...). */
+int64_t mmo_run_fast(const uint8_t *packed, uint64_t base_offset, uint64_t n, uint32_t k, uint32_t w,
+                     const mmo_hasher *h, int canonical_windows, int threads, uint32_t *out_pos,
+                     uint64_t cap);
+
 /* Output::values_u64 (src/lib.rs:579-612) + read_kmer / read_revcomp_kmer (packed-seq) */
 uint64_t mmo_read_kmer_u64(const uint8_t *packed, uint64_t base_offset, uint32_t len, uint64_t pos);
 uint64_t mmo_read_revcomp_kmer_u64(const uint8_t *packed, uint64_t base_offset, uint32_t len,

@@ -60,6 +60,9 @@ def _bind(lib):
     lib.mmo_run.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, hp, C.c_int,
                             C.c_int, C.c_int, u32p, u32p, C.c_uint64]
     lib.mmo_run.restype = C.c_int64
+    lib.mmo_run_fast.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, hp, C.c_int, C.c_int,
+                                 u32p, C.c_uint64]
+    lib.mmo_run_fast.restype = C.c_int64
     lib.mmo_values_u64.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_int, u32p, C.c_uint64, u64p]
     lib.mmo_values_u64.restype = None
     lib.mmo_checksum.argtypes = [u32p, C.c_uint64, u64p, u64p]
@@ -149,6 +152,19 @@ def run(packed, n, k, w, hasher=None, canonical=False, mode=MINIMIZERS, flavour=
         raise ValueError(f"oracle error {r}")
     if super_kmers:
         return pos[:r].copy(), sk[:r].copy()
+    return pos[:r].copy()
+
+
+def run_fast(packed, n, k, w, canonical=False, threads=1, hasher=None, base_offset=0, lib_=None):
+    """One-pass (optionally threaded) port used for CPU timing; equals run(..., mode=MINIMIZERS)."""
+    if hasher is None:
+        hasher = default_hasher(canonical)
+    cap = max(1, n)
+    pos = np.zeros(cap, dtype=np.uint32)
+    r = (lib_ or lib()).mmo_run_fast(_p(packed, C.c_uint8), base_offset, n, k, w, C.byref(hasher),
+                                     int(canonical), threads, _p(pos, C.c_uint32), cap)
+    if r < 0:
+        raise ValueError(f"oracle error {r}")
     return pos[:r].copy()
 
 

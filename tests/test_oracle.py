@@ -149,3 +149,15 @@ def test_error_codes(oracle):
             oracle.run(*args, **kw)
     with pytest.raises(ValueError):
         oracle.run(data, 100, 5, 7, hasher=oracle.default_hasher(False), canonical=True)
+
+
+def test_fast_port_equals_run(oracle):
+    """The timed CPU-baseline port (one pass, threaded) produces exactly the oracle's output."""
+    n = 600_011
+    data = oracle.gen_packed(12, n)
+    for k, w, canon in [(21, 11, True), (21, 11, False), (5, 7, False), (31, 51, True), (3, 1, True)]:
+        want = oracle.run(data, n, k, w, canonical=canon)
+        for threads in (1, 2, 5):
+            got = oracle.run_fast(data, n, k, w, canonical=canon, threads=threads)
+            assert np.array_equal(got, want), (k, w, canon, threads)
+    assert len(oracle.run_fast(data, 20, 21, 11, canonical=True, threads=4)) == 0
