@@ -213,9 +213,13 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     if (ctx.bw0 + ctx.lw == 0) prev = 0xffffffffu;  // the very first window has no predecessor
 
     // ---- blocks 1..nblk: one window per step
-    uint8_t *lp = ctx.list;  // next free list slot (list mode)
-    uint8_t *const lp_end = ctx.list + ctx.list_bytes;
+    // next free list slot as a 32-bit LDS address (the low half of the flat address of LDS memory)
+    const uint32_t list0 = (uint32_t)reinterpret_cast<uintptr_t>(ctx.list);
+    uint32_t lp32 = list0;
+    const uint32_t lp_end = list0 + ctx.list_bytes;
     uint32_t dropped = 0;              // entries that did not fit the list
+    uint32_t valreg = 0;
+    (void)valreg;
     unsigned long long dst = ctx.dst;  // next output slot (DIRECT mode)
     // value of an emitted window: mode 0: (bw0 + lw - 1) + element index; syncmers: bw0 + lw + i
     const uint32_t wbase = (uint32_t)ctx.bw0 + ctx.lw;
@@ -242,18 +246,32 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         if (!DIRECT) {
             // keep a whole block of appends inside the list: a lane that is about to run out of
             // slots is parked on its last W slots (its tile is then redone in DIRECT mode)
-            if (lp + (uint32_t)W * kListStride > lp_end) {
-                uint8_t *park = lp_end - (uint32_t)W * kListStride;
-                dropped += (uint32_t)(lp - park) / kListStride;
-                lp = park;
+            if (!(p.debug & 16u) && lp32 + (uint32_t)W * kListStride > lp_end) {
+                const uint32_t park = lp_end - (uint32_t)W * kListStride;
+                dropped += (lp32 - park) / kListStride;
+                lp32 = park;
             }
         }
 
         const uint32_t e0 = b * (uint32_t)W;  // element index of step j = 0
         uint32_t pl = 0, pr_ = 0;
+        // Table look-ups do not depend on the hash state: issue them PF steps ahead so that the
+        // LDS latency is off the serial fw/rc chain (the emit below ends a scheduling region at
+        // every step, so the compiler cannot hoist them by itself).
+        constexpr int PF = W < 12 ? W : 12;
+        uint2 tq[W];
+        auto lookup = [&](int j) -> uint2 {
+            const int jj = j & 15, g = j >> 4, m = jj >> 1;
+            const uint32_t mw = (jj & 1) ? mo[g] : me[g];
+            const uint32_t a8 = (m == 0 ? (mw << 3) : (mw >> (4 * m - 3))) & 0x78u;
+            return *reinterpret_cast<const uint2 *>(tabb + a8);
+        };
+#pragma unroll
+        for (int j = 0; j < PF; ++j) tq[j] = lookup(j);
 #pragma unroll
         for (int j = 0; j < W; ++j) {
             const uint32_t e = e0 + (uint32_t)j;  // uniform
+            if (j + PF < W) tq[j + PF] = lookup(j + PF);
             const uint32_t h = HASH_RC ? fw + rc : fw;
             const uint32_t kl = (h & kmask) | e;
             // prefix minimum over the block so far and the window minimum; odd steps fold the
@@ -286,37 +304,80 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             }
             // window i = e - W starts at element i + 1
             const uint32_t i = e - (uint32_t)W;  // uniform
-            bool flag;
-            if (MODE == 0) {
-                flag = (uint16_t)sel != (uint16_t)prev;
-                prev = sel;
-            } else if (MODE == 1) {
-                flag = ((uint16_t)sel == (uint16_t)(i + 1u)) | ((uint16_t)sel == (uint16_t)e);
-            } else {
-                flag = (uint16_t)sel == (uint16_t)(i + 1u + (uint32_t)(W / 2));
-            }
-            if (PARTIAL) flag = flag && ((int)i < ctx.rem_valid);
-            if (flag) {
-                if (DIRECT) {
-                    if (dst < p.out.cap) {
-                        p.out.pos[dst] = (MODE == 0) ? vbase + (sel & 0xffffu) : vbase + i;
-                        if (SK) p.out.sk[dst] = wbase + i;
-                    }
-                    ++dst;
+            if (!DIRECT && !PARTIAL && !SK) {
+                // Common path: compare, and under the resulting exec mask append the 16-bit value
+                // to the lane's list and advance its slot pointer (2 VALU + 2 SALU + 1 LDS).
+                unsigned long long sv;
+                if (MODE == 0) {
+                    asm volatile(
+                        "v_cmp_ne_u32_sdwa vcc, %[sel], %[prev] src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+                        "s_and_saveexec_b64 %[sv], vcc\n\t"
+                        "ds_write_b16 %[lp], %[sel]\n\t"
+                        "v_add_u32 %[lp], %[st], %[lp]\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [lp] "+v"(lp32), [sv] "=&s"(sv)
+                        : [sel] "v"(sel), [prev] "v"(prev), [st] "s"(kListStride)
+                        : "vcc", "scc", "memory");  // s_and_saveexec writes SCC
+                    prev = sel;
+                } else if (MODE == 1) {
+                    unsigned long long t2;
+                    const uint32_t first = i + 1u;
+                    asm volatile(
+                        "v_cmp_eq_u16 vcc, %[a], %[sel]\n\t"
+                        "v_cmp_eq_u16 %[t2], %[sel], %[b]\n\t"
+                        "s_or_b64 vcc, vcc, %[t2]\n\t"
+                        "v_mov_b32 %[val], %[iv]\n\t"
+                        "s_and_saveexec_b64 %[sv], vcc\n\t"
+                        "ds_write_b16 %[lp], %[val]\n\t"
+                        "v_add_u32 %[lp], %[st], %[lp]\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [lp] "+v"(lp32), [sv] "=&s"(sv), [t2] "=&s"(t2), [val] "=&v"(valreg)
+                        : [sel] "v"(sel), [a] "s"(first), [b] "s"(e), [iv] "s"(i), [st] "s"(kListStride)
+                        : "vcc", "scc", "memory");  // s_and_saveexec writes SCC
                 } else {
-                    *reinterpret_cast<uint16_t *>(lp) = (uint16_t)(MODE == 0 ? sel : i);
-                    if (SK) *reinterpret_cast<uint16_t *>(lp + ctx.list_bytes) = (uint16_t)i;
-                    lp += kListStride;
+                    const uint32_t mid = i + 1u + (uint32_t)(W / 2);
+                    asm volatile(
+                        "v_cmp_eq_u16 vcc, %[a], %[sel]\n\t"
+                        "v_mov_b32 %[val], %[iv]\n\t"
+                        "s_and_saveexec_b64 %[sv], vcc\n\t"
+                        "ds_write_b16 %[lp], %[val]\n\t"
+                        "v_add_u32 %[lp], %[st], %[lp]\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [lp] "+v"(lp32), [sv] "=&s"(sv), [val] "=&v"(valreg)
+                        : [sel] "v"(sel), [a] "s"(mid), [iv] "s"(i), [st] "s"(kListStride)
+                        : "vcc", "scc", "memory");  // s_and_saveexec writes SCC
+                }
+            } else {
+                bool flag;
+                if (MODE == 0) {
+                    flag = (uint16_t)sel != (uint16_t)prev;
+                    prev = sel;
+                } else if (MODE == 1) {
+                    flag = ((uint16_t)sel == (uint16_t)(i + 1u)) | ((uint16_t)sel == (uint16_t)e);
+                } else {
+                    flag = (uint16_t)sel == (uint16_t)(i + 1u + (uint32_t)(W / 2));
+                }
+                if (PARTIAL) flag = flag && ((int)i < ctx.rem_valid);
+                if (flag) {
+                    if (DIRECT) {
+                        if (dst < p.out.cap) {
+                            p.out.pos[dst] = (MODE == 0) ? vbase + (sel & 0xffffu) : vbase + i;
+                            if (SK) p.out.sk[dst] = wbase + i;
+                        }
+                        ++dst;
+                    } else {
+                        uint8_t *lp = ctx.list + (lp32 - list0);
+                        *reinterpret_cast<uint16_t *>(lp) = (uint16_t)(MODE == 0 ? sel : i);
+                        if (SK) *reinterpret_cast<uint16_t *>(lp + ctx.list_bytes) = (uint16_t)i;
+                        lp32 += kListStride;
+                    }
                 }
             }
 
-            const int jj = j & 15, g = j >> 4, m = jj >> 1;
-            const uint32_t mw = (jj & 1) ? mo[g] : me[g];
-            const uint32_t a8 = (m == 0 ? (mw << 3) : (mw >> (4 * m - 3))) & 0x78u;
-            const uint2 t = *reinterpret_cast<const uint2 *>(tabb + a8);
+            const uint2 t = tq[j];
             fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t.x;
             if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t.y;
-            if (CANON) cnt += (int)((tgw[g] >> (2 * jj)) & 3u);
+            if (CANON) cnt += (int)((tgw[j >> 4] >> (2 * (j & 15))) & 3u);
         }
 #pragma unroll
         for (int j = W - 2; j >= 0; --j) {
@@ -326,7 +387,9 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     }
     overflowed = dropped != 0;  // a parked list is no longer in order
     if (DIRECT) return (uint32_t)(dst - ctx.dst);
-    return (uint32_t)(lp - ctx.list) / kListStride + dropped;
+    if (p.debug & 32u) return dropped;
+    if (p.debug & 64u) return lp32 - list0;
+    return (lp32 - list0) / kListStride + dropped;
 }
 
 template <int W, bool CANON, bool HASH_RC, int MODE, bool SK>
@@ -377,6 +440,14 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         if (over) s_overflow = 1;  // benign race: every writer stores 1
     }
 
+    if (p.debug & 8u) {  // debugging aid: dump per-lane counts and list heads of tile 0
+        __syncthreads();
+        if (bid == 0) {
+            p.out.pos[tid] = my_count;
+            for (int c = 0; c < 8; ++c) p.out.pos[256 + tid * 8 + c] = *reinterpret_cast<const uint16_t *>(ctx.list + c * kListStride);
+        }
+        return;
+    }
     // ---------------------------------------------------------------- phase 2
     const uint32_t incl = wave_scan_dpp(my_count);
     const uint32_t wave_total = __builtin_amdgcn_readlane(incl, kWave - 1);
