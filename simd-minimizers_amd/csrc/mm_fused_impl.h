@@ -70,6 +70,20 @@ __device__ __forceinline__ uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) {
     return r;
 }
 
+// gfx950 issues v_bitop3_b32 / v_xor / v_add / shifts at full rate (2 clk per wave64) but
+// v_and_or, v_cndmask, v_cmp, v_bfe, v_alignbit, v_min/v_max at half rate (tools/ubench), so the
+// walk prefers the former.
+__device__ __forceinline__ uint32_t and_or3(uint32_t a, uint32_t b, uint32_t c) {  // (a & b) | c
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xea" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t select3(uint32_t m, uint32_t a, uint32_t b) {  // m ? a : b (bitwise)
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+
 // What one lane needs to walk its windows.
 struct LaneCtx {
     const uint2 *tab;        // LDS hash tables
@@ -186,9 +200,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         }
     }
 
-    // strand vote: cnt - (#steps done) = #(T|G) among the l bases of the current window;
-    // each step adds tg(in) + 1 - tg(leaving base), the threshold moves by 1 per step.
-    int cnt = 0;
+    // strand vote: dn = #(T|G among the l bases of the current window) - l/2 - 1, so the window
+    // is canonical iff dn >= 0; each step adds tg(in) - tg(leaving base) from packed 2-bit signed
+    // fields.
+    int dn = 0;
     const uint32_t l = k + (uint32_t)W - 1;
     const int thr = (int)(l / 2);
     uint32_t prev;            // key of the predecessor window's k-mer (mode 0)
@@ -202,11 +217,12 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             if (rem < 16u) wd &= (1u << (2u * rem)) - 1u;
             c += __popc(wd);
         }
-        cnt = (int)c;
+        int cnt = (int)c;
         prev = (cnt > thr) ? ring_l[0] : ring_r[0];
         // move to window 0: + base pb + l, - base pb
         cnt += (int)((view(pb + (int32_t)l) >> 1) & 1u);
         cnt -= (int)((view_first(pb) >> 1) & 1u);
+        dn = cnt - thr - 1;
     } else {
         prev = ring_l[0];
     }
@@ -220,6 +236,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     uint32_t dropped = 0;              // entries that did not fit the list
     uint32_t valreg = 0;
     (void)valreg;
+    uint32_t stride_v;  // list stride in a VGPR: v_add with two VGPR sources issues at full rate
+    asm volatile("v_mov_b32 %0, %1" : "=v"(stride_v) : "s"(kListStride));
     unsigned long long dst = ctx.dst;  // next output slot (DIRECT mode)
     // value of an emitted window: mode 0: (bw0 + lw - 1) + element index; syncmers: bw0 + lw + i
     const uint32_t wbase = (uint32_t)ctx.bw0 + ctx.lw;
@@ -230,8 +248,11 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         for (int g = 0; g < NSUB; ++g) {
             me[g] = (va[g] & 0x33333333u) | ((vr[g] << 2) & 0xccccccccu);
             mo[g] = ((va[g] >> 2) & 0x33333333u) | (vr[g] & 0xccccccccu);
-            // 2-bit fields: tg(in) + 1 - tg(leaving) in {0,1,2}
-            if (CANON) tgw[g] = ((va[g] >> 1) & 0x55555555u) + (~(v2[g] >> 1) & 0x55555555u);
+            // 2-bit two's-complement fields: tg(in) - tg(leaving) in {-1,0,1}
+            if (CANON) {
+                const uint32_t ti = (va[g] >> 1) & 0x55555555u, to = (v2[g] >> 1) & 0x55555555u;
+                tgw[g] = (ti ^ to) | ((to & ~ti) << 1);
+            }
         }
         pos_in += W;
         pos_out += W;
@@ -246,7 +267,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         if (!DIRECT) {
             // keep a whole block of appends inside the list: a lane that is about to run out of
             // slots is parked on its last W slots (its tile is then redone in DIRECT mode)
-            if (!(p.debug & 16u) && lp32 + (uint32_t)W * kListStride > lp_end) {
+            if (lp32 + (uint32_t)W * kListStride > lp_end) {
                 const uint32_t park = lp_end - (uint32_t)W * kListStride;
                 dropped += (lp32 - park) / kListStride;
                 lp32 = park;
@@ -273,7 +294,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             const uint32_t e = e0 + (uint32_t)j;  // uniform
             if (j + PF < W) tq[j + PF] = lookup(j + PF);
             const uint32_t h = HASH_RC ? fw + rc : fw;
-            const uint32_t kl = (h & kmask) | e;
+            const uint32_t kl = and_or3(h, kmask, e);
             // prefix minimum over the block so far and the window minimum; odd steps fold the
             // previous key in with one v_min3 (3 ops per 2 steps and side instead of 4)
             uint32_t sel;
@@ -300,7 +321,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                     selr = (j + 1 < W) ? max(pr_, ring_r[(j + 1 < W) ? j + 1 : 0]) : pr_;
                 }
                 ring_r[j] = kr;
-                sel = (cnt > thr + (int)(e - (uint32_t)W)) ? sel : selr;
+                sel = select3((uint32_t)(dn >> 31), selr, sel);  // dn < 0: rightmost
             }
             // window i = e - W starts at element i + 1
             const uint32_t i = e - (uint32_t)W;  // uniform
@@ -316,7 +337,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                         "v_add_u32 %[lp], %[st], %[lp]\n\t"
                         "s_mov_b64 exec, %[sv]"
                         : [lp] "+v"(lp32), [sv] "=&s"(sv)
-                        : [sel] "v"(sel), [prev] "v"(prev), [st] "s"(kListStride)
+                        : [sel] "v"(sel), [prev] "v"(prev), [st] "v"(stride_v)
                         : "vcc", "scc", "memory");  // s_and_saveexec writes SCC
                     prev = sel;
                 } else if (MODE == 1) {
@@ -332,7 +353,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                         "v_add_u32 %[lp], %[st], %[lp]\n\t"
                         "s_mov_b64 exec, %[sv]"
                         : [lp] "+v"(lp32), [sv] "=&s"(sv), [t2] "=&s"(t2), [val] "=&v"(valreg)
-                        : [sel] "v"(sel), [a] "s"(first), [b] "s"(e), [iv] "s"(i), [st] "s"(kListStride)
+                        : [sel] "v"(sel), [a] "s"(first), [b] "s"(e), [iv] "s"(i), [st] "v"(stride_v)
                         : "vcc", "scc", "memory");  // s_and_saveexec writes SCC
                 } else {
                     const uint32_t mid = i + 1u + (uint32_t)(W / 2);
@@ -344,7 +365,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                         "v_add_u32 %[lp], %[st], %[lp]\n\t"
                         "s_mov_b64 exec, %[sv]"
                         : [lp] "+v"(lp32), [sv] "=&s"(sv), [val] "=&v"(valreg)
-                        : [sel] "v"(sel), [a] "s"(mid), [iv] "s"(i), [st] "s"(kListStride)
+                        : [sel] "v"(sel), [a] "s"(mid), [iv] "s"(i), [st] "v"(stride_v)
                         : "vcc", "scc", "memory");  // s_and_saveexec writes SCC
                 }
             } else {
@@ -377,7 +398,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             const uint2 t = tq[j];
             fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t.x;
             if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t.y;
-            if (CANON) cnt += (int)((tgw[j >> 4] >> (2 * (j & 15))) & 3u);
+            if (CANON) dn += __builtin_amdgcn_sbfe((int)tgw[j >> 4], 2 * (j & 15), 2);
         }
 #pragma unroll
         for (int j = W - 2; j >= 0; --j) {
@@ -387,8 +408,6 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     }
     overflowed = dropped != 0;  // a parked list is no longer in order
     if (DIRECT) return (uint32_t)(dst - ctx.dst);
-    if (p.debug & 32u) return dropped;
-    if (p.debug & 64u) return lp32 - list0;
     return (lp32 - list0) / kListStride + dropped;
 }
 
@@ -440,14 +459,6 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         if (over) s_overflow = 1;  // benign race: every writer stores 1
     }
 
-    if (p.debug & 8u) {  // debugging aid: dump per-lane counts and list heads of tile 0
-        __syncthreads();
-        if (bid == 0) {
-            p.out.pos[tid] = my_count;
-            for (int c = 0; c < 8; ++c) p.out.pos[256 + tid * 8 + c] = *reinterpret_cast<const uint16_t *>(ctx.list + c * kListStride);
-        }
-        return;
-    }
     // ---------------------------------------------------------------- phase 2
     const uint32_t incl = wave_scan_dpp(my_count);
     const uint32_t wave_total = __builtin_amdgcn_readlane(incl, kWave - 1);

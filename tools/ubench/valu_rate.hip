@@ -1,0 +1,76 @@
+// Micro-benchmark: issue rate of the VALU ops the minimizer kernel is made of (gfx950).
+// Each kernel runs a long unrolled chain mix of ONE instruction on 8 independent registers.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP 256
+template <int OP>
+__global__ __launch_bounds__(256) void k(unsigned *out, unsigned seed, int iters) {
+    unsigned a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    unsigned b = seed * 2654435761u + threadIdx.x, c = b ^ 0x55aa55aa;
+    unsigned long long m64 = 0x5555aaaa5555aaaaull * seed;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < REP / 8; ++r) {
+#define STEP(x)                                                                                   \
+    if (OP == 0) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(x) : "v"(b));                         \
+    if (OP == 1) asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(x));                          \
+    if (OP == 2) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));            \
+    if (OP == 3) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));          \
+    if (OP == 4) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x26" : "+v"(x) : "v"(b), "v"(c)); \
+    if (OP == 5) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "v"(b));                         \
+    if (OP == 6) asm volatile("v_min_u32 %0, %1, %0" : "+v"(x) : "v"(b));                         \
+    if (OP == 7) asm volatile("v_bfe_u32 %0, %0, 3, 2" : "+v"(x));                                \
+    if (OP == 8) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(b));                \
+    if (OP == 9) asm volatile("v_cmp_lt_i32 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc");             \
+    if (OP == 10) asm volatile("v_alignbit_b32 %0, %0, %0, %1" : "+v"(x) : "s"(seed));            \
+    if (OP == 11) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "s"(seed));      \
+    if (OP == 12) asm volatile("v_lshrrev_b32 %0, 5, %0" : "+v"(x));                              \
+    if (OP == 13) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x) : "v"(b));                     \
+    if (OP == 14) asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(x));                             \
+    if (OP == 15) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "s"(m64));      \
+    if (OP == 16) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x) : "v"(b));                \
+    if (OP == 17) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));        \
+    if (OP == 18) asm volatile("v_sub_u32 %0, %1, %0" : "+v"(x) : "s"(seed));                     \
+    if (OP == 19) asm volatile("v_max_u32 %0, %1, %0" : "+v"(x) : "v"(b));                        \
+    if (OP == 20) asm volatile("v_and_b32 %0, 0x78, %0" : "+v"(x));                               \
+    if (OP == 21) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(x) : "v"(b));                 \
+    if (OP == 22) asm volatile("v_min_i32 %0, %1, %0" : "+v"(x) : "v"(b));                        \
+    if (OP == 23) asm volatile("v_min_f32 %0, %1, %0" : "+v"(x) : "v"(b));                        \
+    if (OP == 24) asm volatile("v_pk_min_u16 %0, %1, %0" : "+v"(x) : "v"(b));                     \
+    if (OP == 25) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));           \
+    if (OP == 26) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));            \
+    if (OP == 27) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+            STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+
+template <int OP>
+void run(const char *name, unsigned *d) {
+    const int blocks = 256 * 8, iters = 200;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1u, 2);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 7u, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double winst = (double)blocks * 4 * iters * REP;       // wave-instructions
+    double per_simd_per_clk = winst / (ms * 1e-3) / (1024.0 * 2.4e9);
+    printf("%-28s %8.3f ms  %.3f wave-instr/clk/SIMD (@2.4GHz)  -> %.2f clk per wave-instr\n", name, ms, per_simd_per_clk, 1.0 / per_simd_per_clk);
+}
+
+int main() {
+    unsigned *d; hipMalloc(&d, 256 * 8 * 256 * 4);
+    run<0>("v_xor_b32", d); run<5>("v_add_u32", d); run<6>("v_min_u32", d); run<12>("v_lshrrev_b32 imm", d);
+    run<7>("v_bfe_u32 imm", d); run<1>("v_alignbit_b32 imm", d); run<10>("v_alignbit_b32 sgpr", d);
+    run<2>("v_min3_u32", d); run<3>("v_and_or_b32 vvv", d); run<11>("v_and_or_b32 vvs", d);
+    run<4>("v_bitop3_b32", d); run<8>("v_cndmask_b32 vcc", d); run<9>("v_cmp_lt_i32", d); run<13>("v_mul_lo_u32", d);
+    run<14>("v_ashrrev_i32", d); run<15>("v_cndmask_b32 sgpr-mask", d); run<16>("v_lshl_add_u32", d); run<17>("v_mad_u32_u24", d);
+    run<18>("v_sub_u32", d); run<19>("v_max_u32", d); run<20>("v_and_b32 lit", d); run<21>("v_lshl_or_b32", d); run<22>("v_min_i32", d);
+    run<23>("v_min_f32", d); run<24>("v_pk_min_u16", d); run<25>("v_add3_u32", d); run<26>("v_xad_u32", d); run<27>("v_perm_b32", d);
+    return 0;
+}
