@@ -18,8 +18,7 @@ using Instance = FusedInstance;
 
 const Instance *find_instance(uint32_t w, int canonical_windows, int hasher_canonical) {
     using Getter = const Instance *(*)(int *);
-    static const Getter kGroups[] = {fused_instances_a, fused_instances_b, fused_instances_c,
-                                     fused_instances_d, fused_instances_e};
+    static const Getter kGroups[] = {fused_instances_a, fused_instances_b, fused_instances_c, fused_instances_d, fused_instances_e, fused_instances_f, fused_instances_g, fused_instances_h, fused_instances_i};
     for (Getter get : kGroups) {
         int n = 0;
         const Instance *inst = get(&n);

@@ -26,5 +26,9 @@ const FusedInstance *fused_instances_b(int *count);
 const FusedInstance *fused_instances_c(int *count);
 const FusedInstance *fused_instances_d(int *count);
 const FusedInstance *fused_instances_e(int *count);
+const FusedInstance *fused_instances_f(int *count);
+const FusedInstance *fused_instances_g(int *count);
+const FusedInstance *fused_instances_h(int *count);
+const FusedInstance *fused_instances_i(int *count);
 
 }  // namespace mm

@@ -1,5 +1,6 @@
 // Explicit instantiations of the fused kernel (split over several files so that the
 // build parallelises); the launcher in mm_fused.hip looks them up through fused_instances_d().
+// Generated list: window sizes 1..16, odd 17..33, 41, 51, canonical and forward.
 #include "mm_fused_impl.h"
 #include "mm_fused_inst.h"
 
@@ -7,8 +8,12 @@ namespace mm {
 
 const FusedInstance *fused_instances_d(int *count) {
     static const FusedInstance kInst[] = {
-        MM_FUSED_INST(17, true, true),
-        MM_FUSED_INST(19, true, true),
+        MM_FUSED_INST(41, false, false),
+        MM_FUSED_INST(25, true, true),
+        MM_FUSED_INST(17, false, false),
+        MM_FUSED_INST(12, true, true),
+        MM_FUSED_INST(8, false, false),
+        MM_FUSED_INST(3, true, true),
     };
     *count = (int)(sizeof(kInst) / sizeof(kInst[0]));
     return kInst;

@@ -1,0 +1,22 @@
+// Explicit instantiations of the fused kernel (split over several files so that the
+// build parallelises); the launcher in mm_fused.hip looks them up through fused_instances_f().
+// Generated list: window sizes 1..16, odd 17..33, 41, 51, canonical and forward.
+#include "mm_fused_impl.h"
+#include "mm_fused_inst.h"
+
+namespace mm {
+
+const FusedInstance *fused_instances_f(int *count) {
+    static const FusedInstance kInst[] = {
+        MM_FUSED_INST(33, false, false),
+        MM_FUSED_INST(23, true, true),
+        MM_FUSED_INST(16, false, false),
+        MM_FUSED_INST(11, true, true),
+        MM_FUSED_INST(7, false, false),
+        MM_FUSED_INST(2, true, true),
+    };
+    *count = (int)(sizeof(kInst) / sizeof(kInst[0]));
+    return kInst;
+}
+
+}  // namespace mm

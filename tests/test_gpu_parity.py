@@ -73,7 +73,9 @@ def test_model_anchors_1mbp(sm, oracle, gpu):
 
 
 # ------------------------------------------------------------------- sweeps
-FUSED_W = {True: [5, 7, 11, 17, 19, 51], False: [5, 7, 11, 17, 19]}
+# window sizes with a fused-kernel instance (mm_fused_inst_*.hip): 1..16, odd 17..33, 41, 51
+FUSED_W = {True: [1, 2, 3, 4, 5, 7, 8, 11, 12, 16, 17, 19, 31, 33, 41, 51],
+           False: [1, 2, 3, 4, 5, 7, 8, 11, 13, 16, 17, 19, 31, 33, 41, 51]}
 
 
 def _sweep_inputs(rng, oracle, sm):
