@@ -60,7 +60,7 @@ enum {
     MM_ERR_CAPACITY = -8,             /* caller's output buffer too small; *out_count holds the need */
     MM_ERR_BAD_MODE = -9,             /* src/lib.rs:437; super-k-mers with syncmers, src/lib.rs:339 */
     MM_ERR_NULL = -10,
-    MM_ERR_VALUE_LEN = -11,           /* values_u64 needs len <= 32 (packed-seq read_kmer) */
+    MM_ERR_VALUE_LEN = -11,           /* values_u64 needs len <= 32, values_u128 len <= 64 */
     MM_ERR_NO_DEVICE = -20,           /* no HIP device: the engine has no CPU fallback */
     MM_ERR_HIP = -21,                 /* a HIP call failed; see mm_last_error() */
     MM_ERR_ALLOC = -22
@@ -162,6 +162,30 @@ int mm_values_u64_device_async(mm_workspace_t *ws, const void *d_packed, uint64_
 int mm_values_u64_host(mm_workspace_t *ws, const uint8_t *packed, uint64_t base_offset,
                        uint64_t n_bases, uint32_t len, int canonical, const uint32_t *pos,
                        uint64_t n_pos, uint64_t *values);
+
+/* Output::values_u128 (src/lib.rs:587-629): len <= 64; value i is stored little-endian as
+ * values[2i] (low 64 bits) and values[2i+1] (high 64 bits). */
+int mm_values_u128_device_async(mm_workspace_t *ws, const void *d_packed, uint64_t packed_bytes,
+                                uint64_t base_offset, uint64_t n_bases, uint32_t len,
+                                int canonical, const uint32_t *d_pos, uint64_t n_pos,
+                                uint64_t *d_values);
+int mm_values_u128_host(mm_workspace_t *ws, const uint8_t *packed, uint64_t base_offset,
+                        uint64_t n_bases, uint32_t len, int canonical, const uint32_t *pos,
+                        uint64_t n_pos, uint64_t *values);
+
+/* ------------------------------------------------------------------ batch */
+
+/* Many independent sequences (contigs) with one plan: what the reference does by calling
+ * Builder::run once per sequence (bench/src/bin/paper.rs:410-431).  Sequence s lives at
+ * d_packed[s] (device pointers, host array).  Positions are sequence-local and are written back
+ * to back into d_out_pos; out_offsets[s] .. out_offsets[s+1] (host array of n_seqs+1 entries)
+ * delimit sequence s.  One kernel launch per sequence on the workspace stream, no host
+ * synchronisation in between. */
+int mm_run_batch_device(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_seqs,
+                        const void *const *d_packed, const uint64_t *packed_bytes,
+                        const uint64_t *base_offsets, const uint64_t *n_bases,
+                        uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
+                        uint64_t *out_offsets);
 
 /* ------------------------------------------------------------------ input */
 

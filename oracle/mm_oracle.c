@@ -411,6 +411,21 @@ void mmo_values_u64(const uint8_t *packed, uint64_t off, uint32_t len, int canon
     }
 }
 
+/* Output::values_u128 (src/lib.rs:613-629): len <= 64, out[2i] = low, out[2i+1] = high 64 bits */
+void mmo_values_u128(const uint8_t *packed, uint64_t off, uint32_t len, int canonical,
+                     const uint32_t *pos, uint64_t n_pos, uint64_t *out) {
+    for (uint64_t i = 0; i < n_pos; ++i) {
+        unsigned __int128 a = 0, b = 0;
+        for (uint32_t j = 0; j < len; ++j) {
+            a |= (unsigned __int128)mmo_base(packed, off + pos[i] + j) << (2 * j);
+            b |= (unsigned __int128)(mmo_base(packed, off + pos[i] + (len - 1 - j)) ^ 2u) << (2 * j);
+        }
+        if (canonical && b < a) a = b;
+        out[2 * i] = (uint64_t)a;
+        out[2 * i + 1] = (uint64_t)(a >> 64);
+    }
+}
+
 void mmo_checksum(const uint32_t *v, uint64_t n, uint64_t *weighted, uint64_t *plain) {
     uint64_t a = 0, b = 0;
     for (uint64_t j = 0; j < n; ++j) {

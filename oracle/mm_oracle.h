@@ -112,6 +112,9 @@ uint64_t mmo_read_revcomp_kmer_u64(const uint8_t *packed, uint64_t base_offset, 
 void mmo_values_u64(const uint8_t *packed, uint64_t base_offset, uint32_t len, int canonical,
                     const uint32_t *pos, uint64_t n_pos, uint64_t *out);
 
+void mmo_values_u128(const uint8_t *packed, uint64_t base_offset, uint32_t len, int canonical,
+                     const uint32_t *pos, uint64_t n_pos, uint64_t *out /* 2 per value */);
+
 /* order-sensitive checksum used by the large-size parity tests */
 void mmo_checksum(const uint32_t *v, uint64_t n, uint64_t *weighted, uint64_t *plain);
 

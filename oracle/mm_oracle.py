@@ -65,6 +65,8 @@ def _bind(lib):
     lib.mmo_run_fast.restype = C.c_int64
     lib.mmo_values_u64.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_int, u32p, C.c_uint64, u64p]
     lib.mmo_values_u64.restype = None
+    lib.mmo_values_u128.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_int, u32p, C.c_uint64, u64p]
+    lib.mmo_values_u128.restype = None
     lib.mmo_checksum.argtypes = [u32p, C.c_uint64, u64p, u64p]
     lib.mmo_checksum.restype = None
     return lib
@@ -174,6 +176,15 @@ def values_u64(packed, length, positions, canonical, base_offset=0) -> np.ndarra
     lib().mmo_values_u64(_p(packed, C.c_uint8), base_offset, length, int(canonical),
                          _p(positions, C.c_uint32), len(positions), _p(out, C.c_uint64))
     return out[:len(positions)]
+
+
+def values_u128(packed, length, positions, canonical, base_offset=0) -> np.ndarray:
+    """Returns an (n, 2) uint64 array: low and high halves."""
+    positions = np.ascontiguousarray(positions, dtype=np.uint32)
+    out = np.zeros(max(1, 2 * len(positions)), dtype=np.uint64)
+    lib().mmo_values_u128(_p(packed, C.c_uint8), base_offset, length, int(canonical),
+                          _p(positions, C.c_uint32), len(positions), _p(out, C.c_uint64))
+    return out[:2 * len(positions)].reshape(-1, 2)
 
 
 def checksum(v) -> tuple[int, int]:

@@ -102,6 +102,12 @@ def lib():
                                                  C.c_uint32, C.c_int, vp, C.c_uint64, vp]
         L.mm_values_u64_host.argtypes = [vp, u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, u32p,
                                          C.c_uint64, u64p]
+        L.mm_values_u128_device_async.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_uint64,
+                                                  C.c_uint32, C.c_int, vp, C.c_uint64, vp]
+        L.mm_values_u128_host.argtypes = [vp, u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, u32p,
+                                          C.c_uint64, u64p]
+        L.mm_run_batch_device.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp), u64p, u64p, u64p, vp, vp,
+                                          C.c_uint64, u64p]
         L.mm_pack_ascii_device_async.argtypes = [vp, vp, C.c_uint64, vp]
         L.mm_generate_device_async.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
         _lib = L
@@ -114,7 +120,8 @@ EXPORTED_SYMBOLS = [
     "mm_workspace_sync", "mm_workspace_force_generic", "mm_workspace_set_blocks_per_lane",
     "mm_workspace_enable_timing", "mm_workspace_kernel_time", "mm_workspace_last_path",
     "mm_run_device_async", "mm_run_device", "mm_run_host", "mm_run_host_ascii",
-    "mm_values_u64_device_async", "mm_values_u64_host", "mm_pack_ascii_device_async",
+    "mm_values_u64_device_async", "mm_values_u64_host", "mm_values_u128_device_async",
+    "mm_values_u128_host", "mm_run_batch_device", "mm_pack_ascii_device_async",
     "mm_generate_device_async",
 ]
 
@@ -305,6 +312,19 @@ class Output:
     def values_u64(self) -> np.ndarray:
         return self.pos_and_values_u64()[1]
 
+    def values_u128(self) -> list:
+        """``Output::values_u128`` (src/lib.rs:587-593): Python ints, len <= 64."""
+        pos = np.ascontiguousarray(self.min_pos, dtype=np.uint32)
+        vals = np.zeros(2 * len(pos), dtype=np.uint64)
+        seq = self.seq
+        if isinstance(seq, AsciiSeq):
+            seq = PackedSeqVec.from_ascii(seq.seq)
+        if len(pos):
+            _check(lib().mm_values_u128_host(self._ws.h, _p(seq.data, C.c_uint8), seq.offset, seq.length,
+                                             self.len, int(self.canonical), _p(pos, C.c_uint32),
+                                             len(pos), _p(vals, C.c_uint64)))
+        return [int(vals[2 * i]) | (int(vals[2 * i + 1]) << 64) for i in range(len(pos))]
+
     def pos_and_values_u64(self):
         pos = np.ascontiguousarray(self.min_pos, dtype=np.uint32)
         vals = np.zeros(len(pos), dtype=np.uint64)
@@ -409,6 +429,25 @@ class Builder:
             return cnt.value
         _check(L.mm_run_device_async(*args, C.c_void_p(d_count.data_ptr()) if d_count is not None else None))
         return None
+
+
+def run_batch_device(builder: "Builder", d_seqs, n_bases, out_pos, out_sk=None, base_offsets=None):
+    """Many device-resident sequences (list of torch uint8 CUDA tensors) with one plan; positions
+    are sequence-local, written back to back into ``out_pos``. Returns the n_seqs+1 offsets."""
+    L = lib()
+    ws = builder._ws()
+    plan = builder.plan()
+    n = len(d_seqs)
+    ptrs = (C.c_void_p * max(n, 1))(*[t.data_ptr() for t in d_seqs])
+    nbytes = (C.c_uint64 * max(n, 1))(*[t.numel() for t in d_seqs])
+    lens = (C.c_uint64 * max(n, 1))(*n_bases)
+    offs = (C.c_uint64 * max(n, 1))(*(base_offsets or [0] * n))
+    out_offsets = (C.c_uint64 * (n + 1))()
+    code = L.mm_run_batch_device(plan.h, ws.h, n, ptrs, nbytes, offs, lens, C.c_void_p(out_pos.data_ptr()),
+                                 C.c_void_p(out_sk.data_ptr()) if out_sk is not None else None,
+                                 out_pos.numel(), out_offsets)
+    _check(code)
+    return list(out_offsets)
 
 
 def minimizers(k, w):  # src/lib.rs:240

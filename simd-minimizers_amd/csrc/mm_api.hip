@@ -336,10 +336,13 @@ int mm_workspace_kernel_time(mm_workspace_t *ws, double *total_ms, uint64_t *lau
 
 int mm_workspace_last_path(const mm_workspace_t *ws) { return ws ? ws->last_path : 0; }
 
-int mm_run_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
-                        uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
-                        uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
-                        uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_count) {
+// `append`: keep the running total of the previous launch, so that consecutive runs write their
+// outputs back to back (the kernels take the total as the carry-in of their first tile).
+static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                                 uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
+                                 uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
+                                 uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_count,
+                                 bool append) {
     if (!plan || !ws) return MM_ERR_NULL;
     if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     if (d_out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;  // src/lib.rs:339
@@ -348,7 +351,7 @@ int mm_run_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d
     const uint64_t l = (uint64_t)plan->k + plan->w - 1;
     const uint64_t n_w = n_bases >= l ? n_bases - l + 1 : 0;
     if (win_end > n_w) win_end = n_w;
-    MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
+    if (!append) MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
     if (win_begin < win_end) {
         if (!d_packed) return MM_ERR_NULL;
         mm::RunArgs a;
@@ -410,6 +413,59 @@ int mm_run_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d
     if (d_count)
         MM_HIP(hipMemcpyAsync(d_count, ws->total, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
                               ws->stream));
+    return MM_OK;
+}
+
+int mm_run_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                        uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
+                        uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
+                        uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_count) {
+    return run_device_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin,
+                                 win_end, d_out_pos, d_out_sk, capacity, d_count, false);
+}
+
+int mm_run_batch_device(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_seqs,
+                        const void *const *d_packed, const uint64_t *packed_bytes,
+                        const uint64_t *base_offsets, const uint64_t *n_bases,
+                        uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
+                        uint64_t *out_offsets) {
+    if (!plan || !ws || !out_offsets) return MM_ERR_NULL;
+    if (n_seqs && (!d_packed || !packed_bytes || !n_bases)) return MM_ERR_NULL;
+    MM_HIP(hipSetDevice(ws->device));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        // running totals after each sequence, read back once at the end
+        unsigned long long *h = nullptr;
+        MM_HIP(hipHostMalloc(reinterpret_cast<void **>(&h), (n_seqs + 1) * sizeof(unsigned long long),
+                             hipHostMallocDefault));
+        int r = MM_OK;
+        for (uint64_t s = 0; s < n_seqs && r == MM_OK; ++s) {
+            r = run_device_async_impl(plan, ws, d_packed[s], packed_bytes[s],
+                                      base_offsets ? base_offsets[s] : 0, n_bases[s], 0, UINT64_MAX,
+                                      d_out_pos, d_out_sk, capacity, nullptr, s != 0);
+            if (r == MM_OK &&
+                hipMemcpyAsync(&h[s + 1], ws->total, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                               ws->stream) != hipSuccess)
+                r = MM_ERR_HIP;
+        }
+        if (n_seqs == 0) MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
+        hipError_t e = hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long),
+                                      hipMemcpyDeviceToHost, ws->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ws->stream);
+        if (r == MM_OK && e != hipSuccess) r = hip_fail(e, "batch sync");
+        if (r == MM_OK) {
+            out_offsets[0] = 0;
+            for (uint64_t s = 0; s < n_seqs; ++s) out_offsets[s + 1] = h[s + 1];
+        }
+        hipHostFree(h);
+        if (r) return r;
+        if (ws->h_total[1] == 0) break;
+        if (ws->force_ticket) {
+            g_last_error = "look-back scan timed out in ticket mode";
+            return MM_ERR_HIP;
+        }
+        ws->force_ticket = true;  // redo the whole batch in ticket mode
+    }
+    if (d_out_pos && out_offsets[n_seqs] > capacity) return MM_ERR_CAPACITY;
     return MM_OK;
 }
 
@@ -554,6 +610,51 @@ int mm_values_u64_host(mm_workspace_t *ws, const uint8_t *packed, uint64_t base_
                                    ws->d_out, n_pos, reinterpret_cast<uint64_t *>(ws->d_vals));
     if (r) return r;
     MM_HIP(hipMemcpyAsync(values, ws->d_vals, n_pos * sizeof(uint64_t), hipMemcpyDeviceToHost, ws->stream));
+    MM_HIP(hipStreamSynchronize(ws->stream));
+    return MM_OK;
+}
+
+int mm_values_u128_device_async(mm_workspace_t *ws, const void *d_packed, uint64_t packed_bytes,
+                                uint64_t base_offset, uint64_t n_bases, uint32_t len,
+                                int canonical, const uint32_t *d_pos, uint64_t n_pos,
+                                uint64_t *d_values) {
+    if (!ws) return MM_ERR_NULL;
+    if (len == 0 || len > 64) return MM_ERR_VALUE_LEN;
+    if (n_pos == 0) return MM_OK;
+    if (!d_packed || !d_pos || !d_values) return MM_ERR_NULL;
+    MM_HIP(hipSetDevice(ws->device));
+    mm::SeqView v;
+    int r = make_view(d_packed, packed_bytes, base_offset, n_bases, &v);
+    if (r) return r;
+    if (mm::launch_values_u128(v, len, canonical, d_pos, n_pos,
+                               reinterpret_cast<unsigned long long *>(d_values), ws->stream))
+        return hip_fail(hipGetLastError(), "values_u128");
+    return MM_OK;
+}
+
+int mm_values_u128_host(mm_workspace_t *ws, const uint8_t *packed, uint64_t base_offset,
+                        uint64_t n_bases, uint32_t len, int canonical, const uint32_t *pos,
+                        uint64_t n_pos, uint64_t *values) {
+    if (!ws) return MM_ERR_NULL;
+    if (len == 0 || len > 64) return MM_ERR_VALUE_LEN;
+    if (n_pos == 0) return MM_OK;
+    if (!packed || !pos || !values) return MM_ERR_NULL;
+    MM_HIP(hipSetDevice(ws->device));
+    const uint64_t bytes = (base_offset + n_bases + 3) / 4;
+    uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
+    int r = grow(din, ws->d_in_bytes, bytes + 32, 1);
+    ws->d_in = din;
+    if (r) return r;
+    r = grow(ws->d_out, ws->d_out_elems, n_pos, sizeof(uint32_t));
+    if (r) return r;
+    r = grow(ws->d_vals, ws->d_vals_elems, 2 * n_pos, sizeof(unsigned long long));
+    if (r) return r;
+    MM_HIP(hipMemcpyAsync(ws->d_in, packed, bytes, hipMemcpyHostToDevice, ws->stream));
+    MM_HIP(hipMemcpyAsync(ws->d_out, pos, n_pos * sizeof(uint32_t), hipMemcpyHostToDevice, ws->stream));
+    r = mm_values_u128_device_async(ws, ws->d_in, bytes + 32, base_offset, n_bases, len, canonical,
+                                    ws->d_out, n_pos, reinterpret_cast<uint64_t *>(ws->d_vals));
+    if (r) return r;
+    MM_HIP(hipMemcpyAsync(values, ws->d_vals, 2 * n_pos * sizeof(uint64_t), hipMemcpyDeviceToHost, ws->stream));
     MM_HIP(hipStreamSynchronize(ws->stream));
     return MM_OK;
 }

@@ -43,6 +43,62 @@ int launch_values_u64(SeqView seq, uint32_t len, int canonical, const uint32_t *
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// Output::values_u128 (src/lib.rs:587-629): up to 64 bases per value, stored as {lo, hi}.
+__global__ __launch_bounds__(kBlockThreads) void values_u128_kernel(SeqView seq, uint32_t len,
+                                                                    int canonical,
+                                                                    const uint32_t *__restrict__ pos,
+                                                                    uint64_t n_pos,
+                                                                    unsigned long long *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * kBlockThreads + threadIdx.x;
+    if (i >= n_pos) return;
+    long long p = (long long)seq.base0 + (long long)pos[i];
+    long long q = p >> 4;
+    uint32_t sh = 2u * (uint32_t)(p & 15);
+    unsigned long long w[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) w[t] = load_dword_clamped(seq, q + t);
+    unsigned long long a = w[0] | (w[1] << 32), b = w[2] | (w[3] << 32);
+    unsigned long long lo = sh ? (a >> sh) | (b << (64u - sh)) : a;
+    unsigned long long hi = sh ? (b >> sh) | (w[4] << (64u - sh)) : b;
+    const uint32_t bits = 2u * len;  // 2 .. 128
+    if (bits <= 64) {
+        hi = 0;
+        if (bits < 64) lo &= (1ull << bits) - 1ull;
+    } else if (bits < 128) {
+        hi &= (1ull << (bits - 64u)) - 1ull;
+    }
+    if (canonical) {
+        // reverse the 2-bit groups of the 128-bit value, align to bit 0, complement (code ^ 2)
+        auto revpairs = [](unsigned long long x) {
+            x = __brevll(x);
+            return ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);
+        };
+        unsigned long long rhi = revpairs(lo), rlo = revpairs(hi);  // 128-bit reversal
+        const uint32_t s = 128u - bits;                              // shift right by s (0 .. 126)
+        unsigned long long clo, chi;
+        if (s == 0) { clo = rlo; chi = rhi; }
+        else if (s < 64) { clo = (rlo >> s) | (rhi << (64u - s)); chi = rhi >> s; }
+        else if (s == 64) { clo = rhi; chi = 0; }
+        else { clo = rhi >> (s - 64u); chi = 0; }
+        unsigned long long mlo = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
+        unsigned long long mhi = bits <= 64 ? 0ull : (bits >= 128 ? ~0ull : (1ull << (bits - 64u)) - 1ull);
+        clo ^= 0xAAAAAAAAAAAAAAAAull & mlo;
+        chi ^= 0xAAAAAAAAAAAAAAAAull & mhi;
+        if (chi < hi || (chi == hi && clo < lo)) { lo = clo; hi = chi; }
+    }
+    out[2 * i] = lo;
+    out[2 * i + 1] = hi;
+}
+
+int launch_values_u128(SeqView seq, uint32_t len, int canonical, const uint32_t *d_pos,
+                       uint64_t n_pos, unsigned long long *d_values, hipStream_t stream) {
+    if (n_pos == 0) return 0;
+    uint32_t grid = (uint32_t)((n_pos + kBlockThreads - 1) / kBlockThreads);
+    hipLaunchKernelGGL(values_u128_kernel, dim3(grid), dim3(kBlockThreads), 0, stream, seq, len,
+                       canonical, d_pos, n_pos, d_values);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // one output byte (4 bases) per thread: code = (c >> 1) & 3  (A0 C1 T2 G3, case-insensitive)
 __global__ __launch_bounds__(kBlockThreads) void pack_ascii_kernel(const uint8_t *__restrict__ ascii,
                                                                    uint64_t n,

@@ -38,6 +38,8 @@ int launch_generic(const RunArgs &a, hipStream_t stream);
 // ---- auxiliary kernels (mm_aux.hip)
 int launch_values_u64(SeqView seq, uint32_t len, int canonical, const uint32_t *d_pos,
                       uint64_t n_pos, unsigned long long *d_values, hipStream_t stream);
+int launch_values_u128(SeqView seq, uint32_t len, int canonical, const uint32_t *d_pos,
+                       uint64_t n_pos, unsigned long long *d_values, hipStream_t stream);
 int launch_pack_ascii(const uint8_t *d_ascii, uint64_t n, uint8_t *d_packed, hipStream_t stream);
 int launch_generate(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d_packed,
                     hipStream_t stream);

@@ -430,3 +430,48 @@ def test_full_size_properties(sm, oracle, gpu):
         assert _device_checksum(out, cg) == whole
     finally:
         gpu.force_generic(False)
+
+
+def test_values_u128(sm, oracle, gpu):
+    """Output::values_u128 (src/lib.rs:587-629) for 32 < len <= 64 and small lens."""
+    n = 200_000
+    data = oracle.gen_packed(14, n)
+    ps = sm.PackedSeq(data, 0, n)
+    for k, w, canonical, mode in [(41, 11, True, 0), (64, 5, True, 0), (33, 3, False, 0), (31, 17, True, 1),
+                                  (5, 7, True, 0), (32, 1, True, 0)]:
+        if canonical and (k + w - 1) % 2 == 0:
+            continue
+        pos: list = []
+        out = sm.Builder(k, w, canonical, mode).run(ps, pos)
+        if out.len > 64:
+            continue
+        got = out.values_u128()
+        want = oracle.values_u128(data, out.len, np.array(pos, dtype=np.uint32), canonical)
+        assert got == [int(a) | (int(b) << 64) for a, b in want], (k, w, canonical, mode)
+        if out.len <= 32:
+            assert got == [int(v) for v in out.values_u64()]
+
+
+def test_batch_of_contigs(sm, oracle, gpu):
+    """Independent sequences with one plan (the reference calls run() per contig,
+    bench/src/bin/paper.rs:410-431): sequence-local positions, back to back, with offsets."""
+    import torch
+    lens = [250_001, 17, 30, 31, 99_999, 0, 1_000_003, 64]
+    datas = [oracle.gen_packed(100 + i, max(n, 1)) for i, n in enumerate(lens)]
+    d = [torch.from_numpy(x).cuda() for x in datas]
+    out = torch.zeros(sum(lens) + 16, dtype=torch.int32, device="cuda")
+    sk = torch.zeros_like(out)
+    for k, w, canonical, mode, use_sk in [(21, 11, True, 0, False), (21, 11, False, 0, True), (15, 17, True, 1, False),
+                                          (9, 23, False, 0, False)]:
+        b = sm.Builder(k, w, canonical, mode)
+        offs = sm.run_batch_device(b, d, lens, out, sk if use_sk else None)
+        assert offs[0] == 0 and len(offs) == len(lens) + 1
+        host = out[: offs[-1]].cpu().numpy().view(np.uint32)
+        hsk = sk[: offs[-1]].cpu().numpy().view(np.uint32)
+        for i, n in enumerate(lens):
+            if use_sk:
+                want, wsk = oracle.run(datas[i], n, k, w, canonical=canonical, mode=mode, super_kmers=True)
+                assert np.array_equal(hsk[offs[i]:offs[i + 1]], wsk), (i, k, w)
+            else:
+                want = oracle.run(datas[i], n, k, w, canonical=canonical, mode=mode)
+            assert np.array_equal(host[offs[i]:offs[i + 1]], want), (i, n, k, w)
