@@ -475,3 +475,58 @@ def test_batch_of_contigs(sm, oracle, gpu):
             else:
                 want = oracle.run(datas[i], n, k, w, canonical=canonical, mode=mode)
             assert np.array_equal(host[offs[i]:offs[i + 1]], want), (i, n, k, w)
+
+
+def test_pack_ascii_device(sm, oracle, gpu):
+    """PackedSeqVec::from_ascii on the device (aligned 16-base fast path, tails, odd alignments)."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(2)
+    letters = np.frombuffer(b"ACGTacgt", dtype=np.uint8)
+    for n in (0, 1, 15, 16, 17, 63, 64, 1000, 100_003):
+        for shift in (0, 1, 5):
+            a = letters[rng.integers(0, 8, size=n + shift)]
+            d_a = torch.from_numpy(a.copy()).cuda()
+            d_p = torch.zeros((n + 3) // 4 + 8, dtype=torch.uint8, device="cuda")
+            sm._check(sm.lib().mm_pack_ascii_device_async(gpu.h, C.c_void_p(d_a.data_ptr() + shift), n,
+                                                          C.c_void_p(d_p.data_ptr())))
+            gpu.sync()
+            want = oracle.pack_ascii(a[shift:].tobytes())
+            assert np.array_equal(d_p[: (n + 3) // 4].cpu().numpy(), want[: (n + 3) // 4]), (n, shift)
+
+
+def test_maximum_length(sm, oracle, gpu):
+    """Sequences up to 2^32 - 1 bases (src/sliding_min.rs:96-99): positions above 2^31 are emitted
+    correctly; 2^32 bases is rejected like the reference's assert."""
+    import ctypes as C
+    import torch
+    n, k, w = (1 << 32) - 1, 21, 11
+    d = sm.generate_device(n, 9)
+    cap = int(n * 2.3 / (w + 1))
+    out = torch.empty(cap, dtype=torch.int32, device="cuda")
+    b = sm.canonical_minimizers(k, w)
+    c = b.run_device(d, n, out)
+    assert abs(c / n - 2.0 / (w + 1)) < 1e-3
+    whole = _device_checksum(out, c)
+    # the last megabase against the oracle (positions > 2^32 - 2^20)
+    m = 1_000_000
+    tail_start = n - m
+    tail = oracle.run(oracle.gen_packed(9, m, first_base=tail_start), m, k, w, canonical=True)
+    got_tail = (out[c - len(tail) + 50: c].to(torch.int64) & 0xFFFFFFFF).cpu().numpy() - tail_start
+    assert np.array_equal(got_tail, tail[50:].astype(np.int64))
+    # three window-range shards reproduce it
+    nw = n - (k + w - 1) + 1
+    cuts = [0, nw // 2 - 7, nw - 3, nw]
+    tc, tp, tw = 0, 0, 0
+    for a, e in zip(cuts[:-1], cuts[1:]):
+        cc = b.run_device(d, n, out, win_begin=a, win_end=e)
+        _, plain, weighted = _device_checksum(out, cc)
+        tw = (tw + weighted + tc * plain) & ((1 << 64) - 1)
+        tp += plain
+        tc += cc
+    assert (tc, tp, tw) == whole
+    plan = b.plan()
+    cnt = C.c_uint64()
+    code = sm.lib().mm_run_device(plan.h, gpu.h, C.c_void_p(d.data_ptr()), d.numel(), 0, 1 << 32, 0, sm.U64_MAX,
+                                  C.c_void_p(out.data_ptr()), None, cap, C.byref(cnt))
+    assert code == sm.ERR["LEN_TOO_LARGE"]
