@@ -187,6 +187,24 @@ int mm_run_batch_device(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_se
                         uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
                         uint64_t *out_offsets);
 
+/* Batched short reads (the read-mapping / k-mer-counting shape: millions of 100-300 bp reads, each
+ * an independent Builder::run, src/lib.rs:378): read r is the bases
+ * [base_offset + r * read_stride, + len_r) of one packed device buffer, len_r = d_read_lens[r]
+ * (<= read_len) or read_len when d_read_lens is NULL.  Positions are read-local and written back
+ * to back; d_out_offsets (device, n_reads + 1 entries) delimits the reads.  Minimizer plans with a
+ * reads-mode kernel instance run as ONE launch with one lane per read; other plans (syncmers,
+ * other w, reads too long for a lane's LDS list) take one launch per read - same results. */
+int mm_run_reads_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                              uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
+                              uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
+                              uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
+                              uint64_t *d_count);
+int mm_run_reads_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                        uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
+                        uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
+                        uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
+                        uint64_t *out_count);
+
 /* ------------------------------------------------------------------ input */
 
 /* PackedSeqVec::from_ascii on the device: out byte i/4 |= ((c>>1)&3) << 2(i%4). */

@@ -108,6 +108,10 @@ def lib():
                                           C.c_uint64, u64p]
         L.mm_run_batch_device.argtypes = [vp, vp, C.c_uint64, C.POINTER(vp), u64p, u64p, u64p, vp, vp,
                                           C.c_uint64, u64p]
+        reads_args = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp,
+                      C.c_uint64, vp]
+        L.mm_run_reads_device_async.argtypes = reads_args + [vp]
+        L.mm_run_reads_device.argtypes = reads_args + [u64p]
         L.mm_pack_ascii_device_async.argtypes = [vp, vp, C.c_uint64, vp]
         L.mm_generate_device_async.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
         _lib = L
@@ -121,7 +125,8 @@ EXPORTED_SYMBOLS = [
     "mm_workspace_enable_timing", "mm_workspace_kernel_time", "mm_workspace_last_path",
     "mm_run_device_async", "mm_run_device", "mm_run_host", "mm_run_host_ascii",
     "mm_values_u64_device_async", "mm_values_u64_host", "mm_values_u128_device_async",
-    "mm_values_u128_host", "mm_run_batch_device", "mm_pack_ascii_device_async",
+    "mm_values_u128_host", "mm_run_batch_device", "mm_run_reads_device_async", "mm_run_reads_device",
+    "mm_pack_ascii_device_async",
     "mm_generate_device_async",
 ]
 
@@ -448,6 +453,29 @@ def run_batch_device(builder: "Builder", d_seqs, n_bases, out_pos, out_sk=None, 
                                  out_pos.numel(), out_offsets)
     _check(code)
     return list(out_offsets)
+
+
+def run_reads_device(builder: "Builder", d_packed, n_reads, read_stride, read_len, out_pos, out_offsets,
+                     read_lens=None, base_offset=0, d_count=None, sync=True):
+    """Batched short reads in one packed device buffer (read r at base ``base_offset + r*read_stride``);
+    read-local positions go back to back into ``out_pos`` and ``out_offsets`` (int64/uint64 CUDA
+    tensor, n_reads+1) delimits the reads. Returns the total count when ``sync``."""
+    L = lib()
+    ws = builder._ws()
+    plan = builder.plan()
+    args = [plan.h, ws.h, C.c_void_p(d_packed.data_ptr()), d_packed.numel(), base_offset, n_reads,
+            read_stride, read_len, C.c_void_p(read_lens.data_ptr()) if read_lens is not None else None,
+            C.c_void_p(out_pos.data_ptr()) if out_pos is not None else None,
+            out_pos.numel() if out_pos is not None else 0, C.c_void_p(out_offsets.data_ptr())]
+    if sync:
+        cnt = C.c_uint64(0)
+        code = L.mm_run_reads_device(*args, C.byref(cnt))
+        if code == ERR["CAPACITY"]:
+            raise MinimizerError(code, f"output capacity {args[10]} < {cnt.value}")
+        _check(code)
+        return cnt.value
+    _check(L.mm_run_reads_device_async(*args, C.c_void_p(d_count.data_ptr()) if d_count is not None else None))
+    return None
 
 
 def minimizers(k, w):  # src/lib.rs:240

@@ -469,6 +469,137 @@ int mm_run_batch_device(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_se
     return MM_OK;
 }
 
+// Batched short reads: read r = bases [base_offset + r * read_stride, + len_r) of one packed buffer.
+// Fast path: the reads-mode fused kernel (one lane per read, one launch).  Anything it has no
+// instance for (syncmer modes, other w, reads too long for the LDS lists) runs one launch per read
+// on the same stream: slower, same results.
+static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                                uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
+                                uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
+                                uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
+                                uint64_t *d_count) {
+    if (!plan || !ws || !d_out_offsets) return MM_ERR_NULL;
+    if (n_reads >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    if (!d_out_pos) capacity = 0;
+    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
+    if (n_reads == 0 || read_len == 0) {
+        MM_HIP(hipMemsetAsync(d_out_offsets, 0, (n_reads + 1) * sizeof(uint64_t), ws->stream));
+        if (d_count) MM_HIP(hipMemsetAsync(d_count, 0, sizeof(uint64_t), ws->stream));
+        return MM_OK;
+    }
+    if (!d_packed) return MM_ERR_NULL;
+    const uint64_t span = (n_reads - 1) * (uint64_t)read_stride + read_len;
+    if (span >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    mm::SeqView view;
+    int r = make_view(d_packed, packed_bytes, base_offset, span, &view);
+    if (r) return r;
+
+    bool fast = plan->mode == MM_MINIMIZERS && !ws->force_generic &&
+                mm::fused_reads_supported(plan->w, plan->canonical_windows, (int)plan->ht.canonical);
+    if (fast) {
+        mm::ReadsArgs a;
+        a.seq = view;
+        a.ht = plan->ht;
+        a.k = plan->k;
+        a.w = plan->w;
+        a.canonical_windows = plan->canonical_windows;
+        a.n_reads = n_reads;
+        a.read_stride = read_stride;
+        a.read_len = read_len;
+        a.read_lens = d_read_lens;
+        a.read_offsets = reinterpret_cast<unsigned long long *>(d_out_offsets);
+        a.out.pos = d_out_pos;
+        a.out.sk = nullptr;
+        a.out.cap = capacity;
+        a.out.total = ws->total;
+        a.out.ticket = ws->ticket;
+        a.out.error = reinterpret_cast<uint32_t *>(ws->total + 1);
+        a.use_ticket = (ws->force_ticket || getenv("MM_FORCE_TICKET")) ? 1 : 0;
+        a.timing_start = a.timing_stop = nullptr;
+        r = grow(ws->status, ws->status_words, mm::fused_reads_status_words(a), sizeof(unsigned long long));
+        if (r) return r;
+        a.out.status = ws->status;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ws->timing) {
+            MM_HIP(hipEventCreate(&e0));
+            MM_HIP(hipEventCreate(&e1));
+            a.timing_start = e0;
+            a.timing_stop = e1;
+        }
+        const int lr = mm::launch_fused_reads(a, ws->stream);
+        if (lr == 0) {
+            if (ws->timing) ws->events.emplace_back(e0, e1);
+            ws->last_path = MM_PATH_FUSED;
+        } else {
+            if (e0) hipEventDestroy(e0);
+            if (e1) hipEventDestroy(e1);
+            if (lr == -1) {
+                g_last_error = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
+                return MM_ERR_HIP;
+            }
+            fast = false;  // reads too long for one lane each
+        }
+    }
+    if (!fast) {
+        std::vector<uint32_t> lens;
+        if (d_read_lens) {
+            lens.resize(n_reads);
+            MM_HIP(hipMemcpyAsync(lens.data(), d_read_lens, n_reads * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, ws->stream));
+            MM_HIP(hipStreamSynchronize(ws->stream));
+        }
+        MM_HIP(hipMemsetAsync(d_out_offsets, 0, sizeof(uint64_t), ws->stream));
+        const uint8_t *bytes = static_cast<const uint8_t *>(d_packed);
+        for (uint64_t i = 0; i < n_reads; ++i) {
+            const uint64_t first = base_offset + i * (uint64_t)read_stride;
+            const uint64_t len = d_read_lens ? (lens[i] < read_len ? lens[i] : read_len) : read_len;
+            r = run_device_async_impl(plan, ws, bytes + first / 4, packed_bytes - first / 4, first % 4, len,
+                                      0, UINT64_MAX, d_out_pos, nullptr, capacity, nullptr, i != 0);
+            if (r) return r;
+            MM_HIP(hipMemcpyAsync(d_out_offsets + i + 1, ws->total, sizeof(uint64_t),
+                                  hipMemcpyDeviceToDevice, ws->stream));
+        }
+    }
+    if (d_count)
+        MM_HIP(hipMemcpyAsync(d_count, ws->total, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                              ws->stream));
+    return MM_OK;
+}
+
+int mm_run_reads_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                              uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
+                              uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
+                              uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
+                              uint64_t *d_count) {
+    return run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride,
+                                read_len, d_read_lens, d_out_pos, capacity, d_out_offsets, d_count);
+}
+
+int mm_run_reads_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                        uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
+                        uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
+                        uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
+                        uint64_t *out_count) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int r = run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride,
+                                     read_len, d_read_lens, d_out_pos, capacity, d_out_offsets, nullptr);
+        if (r) return r;
+        MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, ws->stream));
+        MM_HIP(hipStreamSynchronize(ws->stream));
+        if (ws->h_total[1] == 0) break;
+        if (ws->force_ticket) {
+            g_last_error = "look-back scan timed out in ticket mode";
+            return MM_ERR_HIP;
+        }
+        ws->force_ticket = true;
+    }
+    if (out_count) *out_count = ws->h_total[0];
+    if (d_out_pos && ws->h_total[0] > capacity) return MM_ERR_CAPACITY;
+    return MM_OK;
+}
+
 int mm_run_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
                   uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
                   uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos, uint32_t *d_out_sk,

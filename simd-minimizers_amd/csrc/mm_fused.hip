@@ -94,6 +94,10 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.win_begin = (uint32_t)a.win_begin;
     p.win_end = (uint32_t)a.win_end;
     p.list_cap = g.list_cap;
+    p.n_reads = 0;
+    p.read_stride = p.read_len = 0;
+    p.read_lens = nullptr;
+    p.read_offsets = nullptr;
     p.out = a.out;
     p.use_ticket = a.use_ticket ? 1u : 0u;
     {
@@ -114,6 +118,75 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     if (hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
     if (a.timing_start) hipEventRecord(a.timing_start, stream);
     hipLaunchKernelGGL(fn, dim3((uint32_t)g.nblocks), dim3(kFusedThreads), g.lds_bytes, stream, p);
+    if (a.timing_stop) hipEventRecord(a.timing_stop, stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ------------------------------------------------------------------ reads mode
+namespace {
+const FusedReadsInstance *find_reads_instance(uint32_t w, int canonical_windows, int hasher_canonical) {
+    using Getter = const FusedReadsInstance *(*)(int *);
+    static const Getter kGroups[] = {fused_reads_instances_a, fused_reads_instances_b,
+                                     fused_reads_instances_c, fused_reads_instances_d};
+    for (Getter get : kGroups) {
+        int n = 0;
+        const FusedReadsInstance *inst = get(&n);
+        for (int i = 0; i < n; ++i)
+            if (inst[i].w == w && inst[i].canon == (canonical_windows != 0) &&
+                inst[i].hash_rc == (hasher_canonical != 0))
+                return &inst[i];
+    }
+    return nullptr;
+}
+}  // namespace
+
+bool fused_reads_supported(uint32_t w, int canonical_windows, int hasher_canonical) {
+    return find_reads_instance(w, canonical_windows, hasher_canonical) != nullptr;
+}
+
+uint64_t fused_reads_status_words(const ReadsArgs &a) {
+    return (a.n_reads + kFusedThreads - 1) / kFusedThreads + 1;
+}
+
+int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
+    const FusedReadsInstance *inst = find_reads_instance(a.w, a.canonical_windows, (int)a.ht.canonical);
+    if (!inst) return -2;
+    if (a.n_reads == 0) return 0;
+    const uint32_t l = a.k + a.w - 1;
+    const uint32_t max_nw = a.read_len >= l ? a.read_len - l + 1 : 1;
+    const uint32_t nblk = (max_nw + a.w - 1) / a.w;  // every lane must be able to walk its whole read
+    const uint32_t S = nblk * a.w;
+    if (S + a.w > 60000u) return -3;
+    uint32_t cap = (uint32_t)(1.3 * emit_density(a.w, 0) * S) + 8u + a.w;
+    if (cap > S + a.w) cap = S + a.w;
+    const uint32_t lds_bytes = cap * kListStride;
+    if (lds_bytes > 159u * 1024u) return -3;
+    const uint64_t nblocks = (a.n_reads + kFusedThreads - 1) / kFusedThreads;
+
+    FusedParams p;
+    p.seq = a.seq;
+    p.ht = a.ht;
+    p.k = a.k;
+    p.nblk = nblk;
+    p.win_begin = p.win_end = 0;
+    p.list_cap = cap;
+    p.use_ticket = a.use_ticket ? 1u : 0u;
+    p.debug = 0;
+    p.n_reads = (uint32_t)a.n_reads;
+    p.read_stride = a.read_stride;
+    p.read_len = a.read_len;
+    p.read_lens = a.read_lens;
+    p.read_offsets = a.read_offsets;
+    p.out = a.out;
+    if (lds_bytes > 64u * 1024u) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(inst->fn),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return -1;
+    }
+    if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * nblocks, stream) != hipSuccess) return -1;
+    if (hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
+    if (a.timing_start) hipEventRecord(a.timing_start, stream);
+    hipLaunchKernelGGL(inst->fn, dim3((uint32_t)nblocks), dim3(kFusedThreads), lds_bytes, stream, p);
     if (a.timing_stop) hipEventRecord(a.timing_stop, stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -45,6 +45,12 @@ struct FusedParams {
     uint32_t use_ticket; // 1: tile id from an atomic ticket (safe mode), 0: blockIdx.x
     uint32_t debug;      // timing experiments only (MM_DEBUG env): 1 no look-back, 2 no copy-out,
                          // 4 no phase 1
+    // reads mode (READS kernels): one lane per read, reads at a fixed stride in the buffer
+    uint32_t n_reads;
+    uint32_t read_stride;               // bases between the starts of consecutive reads
+    uint32_t read_len;                  // length of every read, or the maximum when read_lens != null
+    const uint32_t *read_lens;          // optional per-read lengths (device)
+    unsigned long long *read_offsets;   // [n_reads + 1] first output slot of every read (device)
     OutParams out;
 };
 
@@ -87,8 +93,10 @@ __device__ __forceinline__ uint32_t select3(uint32_t m, uint32_t a, uint32_t b) 
 // What one lane needs to walk its windows.
 struct LaneCtx {
     const uint2 *tab;        // LDS hash tables
-    uint64_t bw0;            // first window of the tile
-    uint32_t lw;             // first window of the lane, tile-relative
+    long long p0;            // first base of the tile's element 0, dword-array coordinates (>= -1)
+    uint32_t lane_bases;     // first base of this lane's element 0, relative to p0
+    uint32_t wbase;          // value of the lane's window 0 (absolute window index, or 0 for reads)
+    bool no_prev;            // the lane's first window has no predecessor (always emits)
     int rem_valid;           // windows of this lane inside the range (PARTIAL walks only)
     uint8_t *list;           // LDS: this lane's list slot 0 (list mode)
     uint32_t list_bytes;     // list_cap * kListStride (the super-k-mer list follows at +list_bytes)
@@ -106,7 +114,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // Element 0 of a lane is the k-mer one position before its first window (that window is the
     // dedup predecessor).  P0 = first base of the tile's element 0 in dword-array coordinates;
     // it is -1 only for the very first window of an unshifted buffer.
-    const long long P0 = (long long)p.seq.base0 + (long long)ctx.bw0 - 1;
+    const long long P0 = ctx.p0;
     const long long Q0 = P0 >> 4;
     const long long Q0c = Q0 < 0 ? 0 : Q0;
     const int32_t prel0 = (int32_t)(P0 - (Q0c << 4));  // -1 .. 15
@@ -114,7 +122,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // so the halo after the last base needs no clamping.
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(p.seq.d + Q0c), 0, (int)(((long long)p.seq.n_dwords - Q0c) * 4), 0x00020000);
-    const int32_t pb = prel0 + (int32_t)ctx.lw;  // first base of this lane's element 0
+    const int32_t pb = prel0 + (int32_t)ctx.lane_bases;  // first base of this lane's element 0
     // 16-base view starting at tile-relative base position pos >= 0
     auto view = [&](int32_t pos) -> uint32_t {
         const auto d = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((uint32_t)pos >> 4) << 2, 0, 0);
@@ -226,7 +234,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     } else {
         prev = ring_l[0];
     }
-    if (ctx.bw0 + ctx.lw == 0) prev = 0xffffffffu;  // the very first window has no predecessor
+    if (ctx.no_prev) prev = 0xffffffffu;  // no predecessor window: the first window always emits
 
     // ---- blocks 1..nblk: one window per step
     // next free list slot as a 32-bit LDS address (the low half of the flat address of LDS memory)
@@ -240,7 +248,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     asm volatile("v_mov_b32 %0, %1" : "=v"(stride_v) : "s"(kListStride));
     unsigned long long dst = ctx.dst;  // next output slot (DIRECT mode)
     // value of an emitted window: mode 0: (bw0 + lw - 1) + element index; syncmers: bw0 + lw + i
-    const uint32_t wbase = (uint32_t)ctx.bw0 + ctx.lw;
+    const uint32_t wbase = ctx.wbase;
     const uint32_t vbase = wbase - (MODE == 0 ? 1u : 0u);
     for (uint32_t b = 1; b <= nblk; ++b) {
         uint32_t me[NSUB], mo[NSUB], tgw[NSUB];
@@ -411,7 +419,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     return (lp32 - list0) / kListStride + dropped;
 }
 
-template <int W, bool CANON, bool HASH_RC, int MODE, bool SK>
+// READS = false: one sequence (range of windows), lane t walks windows [t*S, (t+1)*S) of the tile.
+// READS = true : a batch of short reads at a fixed stride, lane t walks read (tile*256 + t) alone;
+//                positions are read-local and read_offsets[] delimits the reads in the output.
+template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool READS>
 __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // lane lists
     // static LDS: distinct objects, so table look-ups can be scheduled across the list stores
@@ -436,26 +447,47 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
 
     const uint32_t S = (uint32_t)W * p.nblk;
     const uint32_t NB = kFusedThreads * S;
-    const uint64_t bw0 = (uint64_t)p.win_begin + (uint64_t)bid * NB;  // first window of the tile
-    const uint32_t nvalid =
-        (uint32_t)(((uint64_t)p.win_end - bw0) < NB ? ((uint64_t)p.win_end - bw0) : NB);
-    const bool partial = nvalid < NB;
+    const uint64_t bw0 = READS ? 0ull : (uint64_t)p.win_begin + (uint64_t)bid * NB;  // first window of the tile
+    const uint32_t nvalid = READS ? NB
+        : (uint32_t)(((uint64_t)p.win_end - bw0) < NB ? ((uint64_t)p.win_end - bw0) : NB);
+    const bool partial = READS || nvalid < NB;
 
     LaneCtx ctx;
     ctx.tab = s_tab;
-    ctx.bw0 = bw0;
-    ctx.lw = (uint32_t)tid * S;
-    ctx.rem_valid = (int)nvalid - (int)ctx.lw;
     ctx.list = smem + 2u * (uint32_t)tid;
     ctx.list_bytes = p.list_cap * kListStride;
     ctx.dst = 0;
+    bool lane_active, lane_in = false;  // lane_in: the lane owns a read (which may have no window)
+    const uint32_t read0 = bid * kFusedThreads;  // READS: first read of the tile
+    if (READS) {
+        const uint32_t r = read0 + (uint32_t)tid;
+        lane_in = r < p.n_reads;
+        const uint32_t len = lane_in ? (p.read_lens ? p.read_lens[r] : p.read_len) : 0u;
+        const uint32_t l = p.k + (uint32_t)W - 1u;
+        const uint32_t nw = len >= l ? len - l + 1u : 0u;
+        lane_active = nw != 0u;
+        ctx.p0 = (long long)p.seq.base0 + (long long)read0 * p.read_stride - 1;
+        ctx.lane_bases = (uint32_t)tid * p.read_stride;
+        ctx.wbase = 0;
+        ctx.no_prev = true;
+        ctx.rem_valid = (int)(nw < S ? nw : S);
+    } else {
+        const uint32_t lw = (uint32_t)tid * S;  // first window of the lane, tile-relative
+        lane_active = lw < nvalid;
+        ctx.p0 = (long long)p.seq.base0 + (long long)bw0 - 1;
+        ctx.lane_bases = lw;
+        ctx.wbase = (uint32_t)bw0 + lw;
+        ctx.no_prev = (bw0 + lw == 0);
+        ctx.rem_valid = (int)nvalid - (int)lw;
+    }
 
     // ---------------------------------------------------------------- phase 1
     uint32_t my_count = 0;
-    if (ctx.lw < nvalid && !(p.debug & 4u)) {
+    if (lane_active && !(p.debug & 4u)) {
         bool over = false;
-        my_count = partial ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over)
-                           : lane_walk<W, CANON, HASH_RC, MODE, SK, false, false>(p, ctx, over);
+        if (READS) my_count = lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over);
+        else my_count = partial ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over)
+                                : lane_walk<W, CANON, HASH_RC, MODE, SK, false, false>(p, ctx, over);
         if (over) s_overflow = 1;  // benign race: every writer stores 1
     }
 
@@ -482,6 +514,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     __syncthreads();
     const unsigned long long run0 = s_excl + wave_base;  // first output slot of this wave
     const uint32_t excl = incl - my_count;
+    if (READS && lane_in) p.read_offsets[read0 + (uint32_t)tid] = run0 + excl;
 
     if (!overflow) {
         // Copy the 64 lists of this wave's lanes, in lane order (= window order).  Entry c of
@@ -491,7 +524,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
             const uint32_t tid0 = (uint32_t)wave * kWave;
             const uint8_t *rd = smem + (uint32_t)lane * kListStride + 2u * tid0;
             const uint32_t list_bytes = ctx.list_bytes;
-            const uint32_t vb0 = (uint32_t)bw0 + tid0 * S - (MODE == 0 ? 1u : 0u);
+            const uint32_t vb0 = (READS ? 0u : (uint32_t)bw0 + tid0 * S) - (MODE == 0 ? 1u : 0u);
             // Output window of this wave as a bounds-checked buffer: stores past the caller's
             // capacity are dropped by the hardware, offsets stay 32-bit.
             const unsigned long long room = p.out.cap > run0 ? p.out.cap - run0 : 0ull;
@@ -504,7 +537,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
             for (uint32_t L = 0; L < kWave; ++L) {
                 const uint32_t n = __builtin_amdgcn_readlane(my_count, L);
                 const uint32_t off = __builtin_amdgcn_readlane(excl, L);
-                const uint32_t vb = vb0 + L * S;
+                const uint32_t vb = READS ? vb0 : vb0 + L * S;
                 for (uint32_t c = lane; c < n; c += kWave) {  // n <= list_cap; usually one pass
                     const uint8_t *q = rd + 2u * L + (c - lane) * kListStride;
                     const uint32_t ent = *reinterpret_cast<const uint16_t *>(q);
@@ -516,14 +549,17 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
                 }
             }
         }
-    } else if (ctx.lw < nvalid) {
+    } else if (lane_active) {
         // some list overflowed: walk the tile again, now storing straight to the output
         ctx.dst = run0 + excl;
         bool over;
-        if (partial) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true>(p, ctx, over);
+        if (READS || partial) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true>(p, ctx, over);
         else lane_walk<W, CANON, HASH_RC, MODE, SK, true, false>(p, ctx, over);
     }
-    if (tid == 0 && bid == gridDim.x - 1) *p.out.total = s_excl + block_total;
+    if (tid == 0 && bid == gridDim.x - 1) {
+        *p.out.total = s_excl + block_total;
+        if (READS) p.read_offsets[p.n_reads] = s_excl + block_total;
+    }
 }
 
 }  // namespace mm

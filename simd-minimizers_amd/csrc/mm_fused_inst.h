@@ -16,8 +16,8 @@ struct FusedInstance {
 #define MM_FUSED_INST(W, C, R)                                                              \
     {                                                                                       \
         W, C, R, {                                                                          \
-            &fused_kernel<W, C, R, 0, false>, &fused_kernel<W, C, R, 1, false>,             \
-                &fused_kernel<W, C, R, 2, false>, &fused_kernel<W, C, R, 0, true>           \
+            &fused_kernel<W, C, R, 0, false, false>, &fused_kernel<W, C, R, 1, false, false>, \
+                &fused_kernel<W, C, R, 2, false, false>, &fused_kernel<W, C, R, 0, true, false> \
         }                                                                                   \
     }
 
@@ -30,5 +30,19 @@ const FusedInstance *fused_instances_f(int *count);
 const FusedInstance *fused_instances_g(int *count);
 const FusedInstance *fused_instances_h(int *count);
 const FusedInstance *fused_instances_i(int *count);
+
+// reads-mode instances (minimizers only), mm_fused_inst_reads_*.hip
+struct FusedReadsInstance {
+    uint32_t w;
+    bool canon;
+    bool hash_rc;
+    FusedKernelFn fn;
+};
+#define MM_READS_INST(W, C, R) \
+    { W, C, R, &fused_kernel<W, C, R, 0, false, true> }
+const FusedReadsInstance *fused_reads_instances_a(int *count);
+const FusedReadsInstance *fused_reads_instances_b(int *count);
+const FusedReadsInstance *fused_reads_instances_c(int *count);
+const FusedReadsInstance *fused_reads_instances_d(int *count);
 
 }  // namespace mm

@@ -1,0 +1,28 @@
+// Reads-mode instantiations of the fused kernel (one lane per short read, minimizer positions);
+// same window sizes as the sequence-mode list: 1..16, odd 17..33, 41, 51, canonical and forward.
+#include "mm_fused_impl.h"
+#include "mm_fused_inst.h"
+
+namespace mm {
+
+const FusedReadsInstance *fused_reads_instances_d(int *count) {
+    static const FusedReadsInstance kInst[] = {
+        MM_READS_INST(41, false, false),
+        MM_READS_INST(33, false, false),
+        MM_READS_INST(29, false, false),
+        MM_READS_INST(25, false, false),
+        MM_READS_INST(21, false, false),
+        MM_READS_INST(17, false, false),
+        MM_READS_INST(15, false, false),
+        MM_READS_INST(12, false, false),
+        MM_READS_INST(11, false, false),
+        MM_READS_INST(8, false, false),
+        MM_READS_INST(7, false, false),
+        MM_READS_INST(4, false, false),
+        MM_READS_INST(3, false, false),
+    };
+    *count = (int)(sizeof(kInst) / sizeof(kInst[0]));
+    return kInst;
+}
+
+}  // namespace mm

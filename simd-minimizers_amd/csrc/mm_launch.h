@@ -30,6 +30,25 @@ bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_c
 uint64_t fused_status_words(const RunArgs &a);
 int launch_fused(const RunArgs &a, hipStream_t stream);
 
+// ---- reads mode of the fused family: a batch of short reads at a fixed stride, one lane per read
+struct ReadsArgs {
+    SeqView seq;
+    HashTables ht;
+    uint32_t k, w;
+    int canonical_windows;
+    uint64_t n_reads;
+    uint32_t read_stride, read_len;
+    const uint32_t *read_lens;           // device, optional
+    unsigned long long *read_offsets;    // device, n_reads + 1
+    OutParams out;
+    int use_ticket;
+    hipEvent_t timing_start, timing_stop;
+};
+bool fused_reads_supported(uint32_t w, int canonical_windows, int hasher_canonical);
+uint64_t fused_reads_status_words(const ReadsArgs &a);
+// returns 0, -1 (HIP failure), -2 (no instance), -3 (reads too long for the LDS lists)
+int launch_fused_reads(const ReadsArgs &a, hipStream_t stream);
+
 // ---- generic family (mm_generic.hip): any k / w
 uint64_t generic_scratch_bytes(uint64_t round_windows, uint32_t w);
 uint64_t generic_status_words(uint64_t round_windows);

@@ -530,3 +530,84 @@ def test_maximum_length(sm, oracle, gpu):
     code = sm.lib().mm_run_device(plan.h, gpu.h, C.c_void_p(d.data_ptr()), d.numel(), 0, 1 << 32, 0, sm.U64_MAX,
                                   C.c_void_p(out.data_ptr()), None, cap, C.byref(cnt))
     assert code == sm.ERR["LEN_TOO_LARGE"]
+
+
+FUSED_W_ALL = list(range(1, 17)) + list(range(17, 34, 2)) + [41, 51]
+
+
+def _check_reads(sm, oracle, k, w, canonical, mode, n_reads, stride, read_len, lens, base_offset, seed):
+    import torch
+    span = (n_reads - 1) * stride + read_len if n_reads else 0
+    data = oracle.gen_packed(seed, base_offset + span + 64)
+    d = torch.from_numpy(data).cuda()
+    d_lens = torch.from_numpy(lens.astype(np.int32)).cuda() if lens is not None else None
+    cap = max(1, n_reads * max(1, read_len))
+    out = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    offs = torch.full((n_reads + 1,), -1, dtype=torch.int64, device="cuda")
+    b = sm.Builder(k, w, canonical, mode)
+    total = sm.run_reads_device(b, d, n_reads, stride, read_len, out, offs, read_lens=d_lens,
+                                base_offset=base_offset)
+    h_offs = offs.cpu().numpy()
+    host = out[:total].cpu().numpy().view(np.uint32)
+    assert h_offs[0] == 0 and h_offs[-1] == total
+    for r in range(n_reads):
+        n = int(lens[r]) if lens is not None else read_len
+        want = oracle.run(data, n, k, w, canonical=canonical, mode=mode, base_offset=base_offset + r * stride)
+        got = host[h_offs[r]:h_offs[r + 1]]
+        assert np.array_equal(got, want), (k, w, canonical, r, n, got[:8], want[:8])
+    return total
+
+
+def test_reads_mode(sm, oracle, gpu):
+    """Batched short reads (one lane per read, one launch): every read equals an independent run
+    of the oracle on that read (src/lib.rs:378 called once per read)."""
+    rng = np.random.default_rng(11)
+    # fixed-length reads, strides that are not multiples of 4 / 16, non-zero buffer offsets
+    for k, w, canonical in [(21, 11, True), (15, 5, True), (31, 19, True), (21, 11, False), (9, 10, False),
+                            (5, 7, False), (13, 15, True)]:
+        for n_reads, stride, read_len, off in [(1, 150, 150, 0), (700, 151, 150, 3), (257, 160, 101, 17),
+                                               (300, 250, 250, 0)]:
+            _check_reads(sm, oracle, k, w, canonical, 0, n_reads, stride, read_len, None, off, 5)
+            assert gpu.last_path() == 1
+    # variable lengths, including reads shorter than l (no window) and of length exactly l
+    for k, w, canonical in [(21, 11, True), (7, 5, False)]:
+        l = k + w - 1
+        n_reads = 1000
+        lens = rng.integers(0, 301, size=n_reads)
+        lens[:6] = [0, l - 1, l, l + 1, 300, 1]
+        _check_reads(sm, oracle, k, w, canonical, 0, n_reads, 304, 300, lens, 5, 6)
+    # plans without a reads-mode instance take one launch per read: same results
+    _check_reads(sm, oracle, 15, 17, True, 1, 40, 150, 150, None, 2, 7)   # closed syncmers
+    _check_reads(sm, oracle, 12, 18, True, 0, 40, 150, 149, None, 0, 8)   # w without an instance
+    assert gpu.last_path() == 2
+    lens = rng.integers(0, 200, size=30)
+    _check_reads(sm, oracle, 12, 18, True, 0, 30, 200, 199, lens, 1, 9)
+    # every window size with an instance
+    for canonical in (True, False):
+        for w in FUSED_W_ALL:
+            k = 20 if (canonical and w % 2 == 0) else 21
+            _check_reads(sm, oracle, k, w, canonical, 0, 300, 153, 151, None, 1, 10 + w)
+            assert gpu.last_path() == 1
+    # zero reads
+    _check_reads(sm, oracle, 21, 11, True, 0, 0, 150, 150, None, 0, 1)
+
+
+def test_reads_mode_dense_and_long(sm, oracle, gpu):
+    """Low-complexity reads (every window emits -> list overflow -> direct redo) and reads too
+    long for the LDS lists (fallback to one launch per read)."""
+    import torch
+    n_reads, stride, read_len = 520, 152, 150
+    nbytes = (n_reads * stride + 64) // 4
+    for fill in (0x00, 0xFF, 0x1B):
+        data = np.full(nbytes, fill, dtype=np.uint8)
+        d = torch.from_numpy(data).cuda()
+        for k, w, canonical in [(21, 11, True), (21, 11, False)]:
+            out = torch.zeros(n_reads * read_len, dtype=torch.int32, device="cuda")
+            offs = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
+            total = sm.run_reads_device(sm.Builder(k, w, canonical, 0), d, n_reads, stride, read_len, out, offs)
+            h_offs = offs.cpu().numpy()
+            host = out[:total].cpu().numpy().view(np.uint32)
+            for r in (0, 1, 255, 256, 519):
+                want = oracle.run(data, read_len, k, w, canonical=canonical, base_offset=r * stride)
+                assert np.array_equal(host[h_offs[r]:h_offs[r + 1]], want), (fill, k, w, r)
+    _check_reads(sm, oracle, 21, 11, True, 0, 6, 70_000, 69_999, None, 0, 3)
