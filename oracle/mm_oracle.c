@@ -382,6 +382,106 @@ int64_t mmo_run(const uint8_t *packed, uint64_t off, uint64_t n, uint32_t k, uin
     return m;
 }
 
+/* ------------------------------------------------- skip-ambiguous windows */
+
+static inline int amb_bit(const uint8_t *amb, uint64_t i) { return (amb[i >> 3] >> (i & 7)) & 1; }
+
+/* PackedNSeqVec::from_ascii (packed-seq, not in tree; [INFERRED]): lossy 2-bit code for every
+ * character, ambiguity bit for everything that is not ACGT / acgt. */
+void mmo_pack_ascii_n(const uint8_t *ascii, uint64_t n, uint8_t *packed, uint8_t *amb) {
+    mmo_pack_ascii(ascii, n, packed);
+    memset(amb, 0, (size_t)((n + 7) / 8));
+    for (uint64_t i = 0; i < n; ++i) {
+        uint8_t c = ascii[i] & 0xDF; /* upper case */
+        if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) amb[i >> 3] |= (uint8_t)(1u << (i & 7));
+    }
+}
+
+/* src/minimizers.rs:203-212: zip the position stream with the l-mer ambiguity stream
+ * (par_iter_kmer_ambiguity(l, ..)) and blend SKIPPED in.  The min computation itself runs on
+ * the lossy codes, exactly as for a plain PackedSeq. */
+int64_t mmo_window_positions_skip_ambiguous(const uint8_t *packed, uint64_t off, const uint8_t *amb,
+                                            uint64_t amb_off, uint64_t n, uint32_t k, uint32_t w,
+                                            const mmo_hasher *h, int canonical, uint32_t *out) {
+    int64_t r = mmo_window_positions(packed, off, n, k, w, h, canonical, MMO_STREAMING, out);
+    if (r <= 0) return r;
+    const uint64_t l = (uint64_t)k + w - 1, nw = (uint64_t)r;
+    uint64_t cnt = 0; /* ambiguous bases in the current window */
+    for (uint64_t j = 0; j < l; ++j) cnt += (uint64_t)amb_bit(amb, amb_off + j);
+    for (uint64_t i = 0; i < nw; ++i) {
+        if (cnt) out[i] = MMO_SKIPPED;
+        if (i + 1 < nw) {
+            cnt += (uint64_t)amb_bit(amb, amb_off + i + l);
+            cnt -= (uint64_t)amb_bit(amb, amb_off + i);
+        }
+    }
+    return r;
+}
+
+uint64_t mmo_collect_and_dedup_skip(const uint32_t *in, uint64_t n, int skip_max, int rule,
+                                    uint32_t *out) {
+    uint64_t m = 0;
+    int have_prec = 0;
+    uint32_t prec = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t cur = in[i];
+        if (rule == 0) {
+            /* dedup.rs:147-155: mask = (cur == predecessor) | (cur == SKIPPED) */
+            const int dup = i > 0 && cur == in[i - 1];
+            if (!dup && !(skip_max && cur == MMO_SKIPPED)) out[m++] = cur;
+        } else {
+            /* dedup.rs:41-48: prec only moves when something is emitted */
+            if ((!have_prec || cur != prec) && !(skip_max && cur == MMO_SKIPPED)) {
+                out[m++] = cur;
+                prec = cur;
+                have_prec = 1;
+            }
+        }
+    }
+    return m;
+}
+
+int64_t mmo_run_skip_ambiguous(const uint8_t *packed, uint64_t off, const uint8_t *amb,
+                               uint64_t amb_off, uint64_t n, uint32_t k, uint32_t w,
+                               const mmo_hasher *h, int canonical, int mode, int rule,
+                               uint32_t *out_pos, uint64_t cap) {
+    int e = check_params(n, k, w, h, canonical);
+    if (e) return e;
+    if (mode < 0 || mode > 2) return MMO_ERR_BAD_MODE;
+    if (mode == MMO_OPEN_SYNCMERS && w % 2 == 0) return MMO_ERR_OPEN_EVEN_W;
+    uint64_t l = (uint64_t)k + w - 1;
+    if (n < l) return 0;
+    uint64_t nw = n - l + 1;
+    uint32_t *win = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nw);
+    uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nw);
+    if (!win || !tmp) {
+        free(win);
+        free(tmp);
+        return MMO_ERR_CAPACITY;
+    }
+    int64_t m = mmo_window_positions_skip_ambiguous(packed, off, amb, amb_off, n, k, w, h, canonical, win);
+    if (m >= 0) {
+        if (mode == MMO_MINIMIZERS) {
+            m = (int64_t)mmo_collect_and_dedup_skip(win, nw, 1, rule, tmp); /* src/lib.rs:476-477 */
+        } else {
+            /* src/syncmers.rs:113-120: SKIPPED never equals a window index; :154-164 tail keeps x < SKIPPED */
+            const int open = mode == MMO_OPEN_SYNCMERS;
+            uint64_t c = 0;
+            for (uint64_t i = 0; i < nw; ++i) {
+                const uint64_t p = win[i];
+                if (p == MMO_SKIPPED) continue;
+                if (open ? (p == i + w / 2) : (p == i || p == i + w - 1)) tmp[c++] = (uint32_t)i;
+            }
+            m = (int64_t)c;
+        }
+        if ((uint64_t)m > cap) m = MMO_ERR_CAPACITY;
+        else memcpy(out_pos, tmp, sizeof(uint32_t) * (size_t)m);
+    }
+    free(win);
+    free(tmp);
+    return m;
+}
+
 /* ---------------------------------------------------------------- values */
 
 /* packed-seq Seq::read_kmer: base j of the k-mer at bits 2j (little-endian), len <= 32. */

@@ -115,6 +115,32 @@ void mmo_values_u64(const uint8_t *packed, uint64_t base_offset, uint32_t len, i
 void mmo_values_u128(const uint8_t *packed, uint64_t base_offset, uint32_t len, int canonical,
                      const uint32_t *pos, uint64_t n_pos, uint64_t *out /* 2 per value */);
 
+/* ---- skip-ambiguous windows (PackedNSeq): src/minimizers.rs:18-19,169-214, src/lib.rs:451-496.
+ * A PackedNSeq is a PackedSeq plus one ambiguity bit per base (packed-seq 5.0.0 BitSeq, not in
+ * tree; [INFERRED] layout: base i at bit i%8 of byte i/8, set for every non-ACGT character,
+ * while the 2-bit code of such a character is the lossy (c>>1)&3).  A window with any ambiguous
+ * base among its l = k+w-1 bases yields SKIPPED = u32::MAX-1 instead of a position. */
+#define MMO_SKIPPED 0xFFFFFFFEu
+void mmo_pack_ascii_n(const uint8_t *ascii, uint64_t n, uint8_t *packed /* ceil(n/4) */,
+                      uint8_t *amb /* ceil(n/8) */);
+/* per-window stream of canonical_minimizers_skip_ambiguous_windows (src/minimizers.rs:169-214):
+ * the window's position, or MMO_SKIPPED where the l-mer holds an ambiguous base (:203-212) */
+int64_t mmo_window_positions_skip_ambiguous(const uint8_t *packed, uint64_t base_offset,
+                                            const uint8_t *amb, uint64_t amb_offset, uint64_t n,
+                                            uint32_t k, uint32_t w, const mmo_hasher *h,
+                                            int canonical_windows, uint32_t *out /* n_w */);
+/* collect_and_dedup_into::<SKIP_MAX> on one lane's stream.  rule 0 = the AVX2/NEON kernels
+ * (src/intrinsics/dedup.rs:133-159: compare with the IMMEDIATE predecessor, then drop SKIPPED),
+ * rule 1 = the portable kernel and the scalar tail (src/intrinsics/dedup.rs:28-50,
+ * src/collect.rs:243: compare with the LAST EMITTED value).  Pinned by src/test.rs:358-399. */
+uint64_t mmo_collect_and_dedup_skip(const uint32_t *in, uint64_t n, int skip_max, int rule,
+                                    uint32_t *out);
+/* Builder::run_skip_ambiguous_windows (src/lib.rs:451-496): modes 0/1/2 as mmo_run. */
+int64_t mmo_run_skip_ambiguous(const uint8_t *packed, uint64_t base_offset, const uint8_t *amb,
+                               uint64_t amb_offset, uint64_t n, uint32_t k, uint32_t w,
+                               const mmo_hasher *h, int canonical_windows, int mode, int rule,
+                               uint32_t *out_pos, uint64_t cap);
+
 /* order-sensitive checksum used by the large-size parity tests */
 void mmo_checksum(const uint32_t *v, uint64_t n, uint64_t *weighted, uint64_t *plain);
 

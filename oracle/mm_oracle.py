@@ -67,6 +67,16 @@ def _bind(lib):
     lib.mmo_values_u64.restype = None
     lib.mmo_values_u128.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_int, u32p, C.c_uint64, u64p]
     lib.mmo_values_u128.restype = None
+    lib.mmo_pack_ascii_n.argtypes = [u8p, C.c_uint64, u8p, u8p]
+    lib.mmo_pack_ascii_n.restype = None
+    lib.mmo_window_positions_skip_ambiguous.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64, C.c_uint64,
+                                                        C.c_uint32, C.c_uint32, hp, C.c_int, u32p]
+    lib.mmo_window_positions_skip_ambiguous.restype = C.c_int64
+    lib.mmo_collect_and_dedup_skip.argtypes = [u32p, C.c_uint64, C.c_int, C.c_int, u32p]
+    lib.mmo_collect_and_dedup_skip.restype = C.c_uint64
+    lib.mmo_run_skip_ambiguous.argtypes = [u8p, C.c_uint64, u8p, C.c_uint64, C.c_uint64, C.c_uint32,
+                                           C.c_uint32, hp, C.c_int, C.c_int, C.c_int, u32p, C.c_uint64]
+    lib.mmo_run_skip_ambiguous.restype = C.c_int64
     lib.mmo_checksum.argtypes = [u32p, C.c_uint64, u64p, u64p]
     lib.mmo_checksum.restype = None
     return lib
@@ -185,6 +195,58 @@ def values_u128(packed, length, positions, canonical, base_offset=0) -> np.ndarr
     lib().mmo_values_u128(_p(packed, C.c_uint8), base_offset, length, int(canonical),
                           _p(positions, C.c_uint32), len(positions), _p(out, C.c_uint64))
     return out[:2 * len(positions)].reshape(-1, 2)
+
+
+SKIPPED = 0xFFFFFFFE
+
+
+def pack_ascii_n(seq: bytes):
+    """PackedNSeqVec::from_ascii: (packed 2-bit codes, ambiguity bits)."""
+    a = np.frombuffer(seq, dtype=np.uint8)
+    packed = np.zeros((len(a) + 3) // 4 + 16, dtype=np.uint8)
+    amb = np.zeros((len(a) + 7) // 8 + 16, dtype=np.uint8)
+    if len(a):
+        lib().mmo_pack_ascii_n(_p(np.ascontiguousarray(a), C.c_uint8), len(a), _p(packed, C.c_uint8),
+                               _p(amb, C.c_uint8))
+    return packed, amb
+
+
+def window_positions_skip_ambiguous(packed, amb, n, k, w, hasher=None, canonical=True, base_offset=0,
+                                    amb_offset=0):
+    if hasher is None:
+        hasher = default_hasher(canonical)
+    l = k + w - 1
+    nw = max(0, n - l + 1)
+    out = np.zeros(max(1, nw), dtype=np.uint32)
+    r = lib().mmo_window_positions_skip_ambiguous(_p(packed, C.c_uint8), base_offset, _p(amb, C.c_uint8),
+                                                  amb_offset, n, k, w, C.byref(hasher), int(canonical),
+                                                  _p(out, C.c_uint32))
+    if r < 0:
+        raise ValueError(f"oracle error {r}")
+    return out[:r].copy()
+
+
+def collect_and_dedup_skip(stream, skip_max: bool, rule: int = 0):
+    stream = np.ascontiguousarray(stream, dtype=np.uint32)
+    out = np.zeros(max(1, len(stream)), dtype=np.uint32)
+    m = lib().mmo_collect_and_dedup_skip(_p(stream, C.c_uint32), len(stream), int(skip_max), rule,
+                                         _p(out, C.c_uint32))
+    return out[:m].copy()
+
+
+def run_skip_ambiguous(packed, amb, n, k, w, hasher=None, canonical=True, mode=MINIMIZERS, rule=0,
+                       base_offset=0, amb_offset=0):
+    """Builder::run_skip_ambiguous_windows (src/lib.rs:451-496)."""
+    if hasher is None:
+        hasher = default_hasher(canonical)
+    cap = max(1, n)
+    pos = np.zeros(cap, dtype=np.uint32)
+    r = lib().mmo_run_skip_ambiguous(_p(packed, C.c_uint8), base_offset, _p(amb, C.c_uint8), amb_offset, n,
+                                     k, w, C.byref(hasher), int(canonical), mode, rule,
+                                     _p(pos, C.c_uint32), cap)
+    if r < 0:
+        raise ValueError(f"oracle error {r}")
+    return pos[:r].copy()
 
 
 def checksum(v) -> tuple[int, int]:

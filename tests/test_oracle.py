@@ -161,3 +161,73 @@ def test_fast_port_equals_run(oracle):
             got = oracle.run_fast(data, n, k, w, canonical=canon, threads=threads)
             assert np.array_equal(got, want), (k, w, canon, threads)
     assert len(oracle.run_fast(data, 20, 21, 11, canonical=True, threads=4)) == 0
+
+
+# ------------------------------------------------- skip-ambiguous windows (PackedNSeq)
+def test_reference_skip_max_collector_vectors(oracle):
+    """src/test.rs:358-399: collect_and_dedup_into::<SKIP_MAX> known answers (both dedup rules)."""
+    ref = json.load(open(os.path.join(GOLD, "reference_vectors.json")))
+    for case in ref["collect_and_dedup_skip_max"]:
+        for rule in (0, 1):
+            assert list(oracle.collect_and_dedup_skip(case["in"], False, rule)) == case["out_keep"], case["source"]
+            assert list(oracle.collect_and_dedup_skip(case["in"], True, rule)) == case["out_skip"], case["source"]
+
+
+def _random_ascii_with_n(rng, n, frac, runs=False):
+    a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+    if n and frac > 0:
+        if runs:
+            for _ in range(max(1, int(n * frac / 20))):
+                s = int(rng.integers(0, n))
+                a[s:s + int(rng.integers(1, 40))] = ord("N")
+        else:
+            a[rng.integers(0, n, size=max(1, int(n * frac)))] = ord("N")
+    return a.tobytes()
+
+
+def test_skip_ambiguous_properties(oracle):
+    """The reference's own test (src/test.rs:428-482): no output equals SKIPPED and no k-mer at an
+    output position holds an ambiguous base — plus the definition: the output is the adjacent-dedup
+    of the positions of the windows without an ambiguous base, and both dedup rules agree."""
+    rng = np.random.default_rng(4)
+    for n, frac, runs in [(100, 0.01, False), (100, 0.05, False), (400, 0.03, True), (64, 0.0, False)]:
+        seq = _random_ascii_with_n(rng, n, frac, runs)
+        packed, amb = oracle.pack_ascii_n(seq)
+        isn = np.frombuffer(seq, dtype=np.uint8) == ord("N")
+        for k in range(1, 65, 3):
+            for w in range(1, 64, 2):
+                l = k + w - 1
+                if l % 2 == 0 or l > 64:
+                    continue
+                pos = oracle.run_skip_ambiguous(packed, amb, n, k, w)
+                assert np.array_equal(pos, oracle.run_skip_ambiguous(packed, amb, n, k, w, rule=1))
+                assert not np.any(pos == oracle.SKIPPED)
+                for p in pos:
+                    assert not isn[p:p + k].any()
+                # definition
+                plain = oracle.window_positions(packed, n, k, w, oracle.default_hasher(True), True,
+                                                flavour=oracle.NAIVE)
+                want, prev_clean, prev = [], False, None
+                for i, p in enumerate(plain):
+                    clean = not isn[i:i + l].any()
+                    if clean and (not prev_clean or p != prev):
+                        want.append(int(p))
+                    prev_clean, prev = clean, p
+                assert list(pos) == want, (n, k, w)
+                # syncmers: window indices of clean windows only
+                for mode, keep in ((1, lambda i, p: p == i or p == i + w - 1), (2, lambda i, p: p == i + w // 2)):
+                    if mode == 2 and w % 2 == 0:
+                        continue
+                    got = oracle.run_skip_ambiguous(packed, amb, n, k, w, mode=mode)
+                    want = [i for i, p in enumerate(plain) if not isn[i:i + l].any() and keep(i, int(p))]
+                    assert list(got) == want, (n, k, w, mode)
+
+
+def test_skip_ambiguous_without_n_equals_plain(oracle):
+    rng = np.random.default_rng(5)
+    seq = _random_ascii_with_n(rng, 5000, 0.0)
+    packed, amb = oracle.pack_ascii_n(seq)
+    assert not amb.any()
+    for k, w, mode in [(21, 11, 0), (15, 17, 1), (15, 17, 2), (5, 7, 0)]:
+        assert np.array_equal(oracle.run_skip_ambiguous(packed, amb, 5000, k, w, mode=mode),
+                              oracle.run(packed, 5000, k, w, canonical=True, mode=mode))
