@@ -205,11 +205,61 @@ int mm_run_reads_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d
                         uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
                         uint64_t *out_count);
 
+/* --------------------------------------------------------------- PackedNSeq */
+
+/* Builder::run_skip_ambiguous_windows (src/lib.rs:451-496) on canonical_minimizers /
+ * canonical_closed_syncmers / canonical_open_syncmers plans
+ * (canonical_minimizers_skip_ambiguous_windows, src/minimizers.rs:169-214): a window with an
+ * ambiguous base among its l = k+w-1 bases yields SKIPPED = u32::MAX-1 (src/minimizers.rs:18),
+ * which the collectors then drop (collect_and_dedup_into::<true>, src/collect.rs:128-285 with
+ * SKIP_MAX; src/syncmers.rs:113-120,154-164).  A PackedNSeq crosses the ABI as two arrays: the
+ * PackedSeq bytes (2-bit codes; an ambiguous character carries the lossy code (c>>1)&3) and the
+ * ambiguity bits, base i at bit (amb_offset + i) % 8 of byte (amb_offset + i) / 8 (packed-seq 5.0.0
+ * BitSeq, not in the reference tree: layout inferred).  Non-canonical plans return
+ * MM_ERR_HASHER_NOT_CANONICAL (assert src/minimizers.rs:176); there is no super-k-mer flavour. */
+int mm_run_skip_ambiguous_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                                       uint64_t packed_bytes, uint64_t base_offset, const void *d_amb,
+                                       uint64_t amb_bytes, uint64_t amb_offset, uint64_t n_bases,
+                                       uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
+                                       uint64_t capacity, uint64_t *d_count);
+int mm_run_skip_ambiguous_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                                 uint64_t packed_bytes, uint64_t base_offset, const void *d_amb,
+                                 uint64_t amb_bytes, uint64_t amb_offset, uint64_t n_bases,
+                                 uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
+                                 uint64_t capacity, uint64_t *out_count);
+int mm_run_skip_ambiguous_host(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed,
+                               uint64_t base_offset, const uint8_t *amb, uint64_t amb_offset,
+                               uint64_t n_bases, uint32_t *out_pos, uint64_t capacity,
+                               uint64_t *out_count);
+/* PackedNSeqVec::from_ascii (call site src/test.rs:436) then the run, from a host ASCII buffer. */
+int mm_run_skip_ambiguous_host_ascii(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *ascii,
+                                     uint64_t n_bases, uint32_t *out_pos, uint64_t capacity,
+                                     uint64_t *out_count);
+/* Batched short reads with ambiguity bits (same layout rules as mm_run_reads_device; read r's
+ * ambiguity bits start at bit amb_offset + r * read_stride). */
+int mm_run_reads_skip_ambiguous_device_async(const mm_plan_t *plan, mm_workspace_t *ws,
+                                             const void *d_packed, uint64_t packed_bytes,
+                                             uint64_t base_offset, const void *d_amb, uint64_t amb_bytes,
+                                             uint64_t amb_offset, uint64_t n_reads, uint32_t read_stride,
+                                             uint32_t read_len, const uint32_t *d_read_lens,
+                                             uint32_t *d_out_pos, uint64_t capacity,
+                                             uint64_t *d_out_offsets, uint64_t *d_count);
+int mm_run_reads_skip_ambiguous_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                                       uint64_t packed_bytes, uint64_t base_offset, const void *d_amb,
+                                       uint64_t amb_bytes, uint64_t amb_offset, uint64_t n_reads,
+                                       uint32_t read_stride, uint32_t read_len,
+                                       const uint32_t *d_read_lens, uint32_t *d_out_pos,
+                                       uint64_t capacity, uint64_t *d_out_offsets, uint64_t *out_count);
+
 /* ------------------------------------------------------------------ input */
 
 /* PackedSeqVec::from_ascii on the device: out byte i/4 |= ((c>>1)&3) << 2(i%4). */
 int mm_pack_ascii_device_async(mm_workspace_t *ws, const uint8_t *d_ascii, uint64_t n_bases,
                                uint8_t *d_packed /* ceil(n/4) bytes */);
+/* PackedNSeqVec::from_ascii on the device: the packed bytes as above plus one ambiguity bit per
+ * base (set for every character that is not ACGT / acgt), d_amb = ceil(n/8) bytes. */
+int mm_pack_ascii_n_device_async(mm_workspace_t *ws, const uint8_t *d_ascii, uint64_t n_bases,
+                                 uint8_t *d_packed /* ceil(n/4) bytes */, uint8_t *d_amb);
 /* Deterministic synthetic PackedSeq generator G of BASELINE.md §4, written on the device. */
 int mm_generate_device_async(mm_workspace_t *ws, uint64_t seed, uint64_t first_base,
                              uint64_t n_bases, uint8_t *d_packed /* ceil(n/4) bytes */);

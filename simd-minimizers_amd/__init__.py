@@ -112,6 +112,18 @@ def lib():
                       C.c_uint64, vp]
         L.mm_run_reads_device_async.argtypes = reads_args + [vp]
         L.mm_run_reads_device.argtypes = reads_args + [u64p]
+        skip_args = [vp, vp, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, C.c_uint64, C.c_uint64,
+                     C.c_uint64, C.c_uint64, vp, C.c_uint64]
+        L.mm_run_skip_ambiguous_device_async.argtypes = skip_args + [vp]
+        L.mm_run_skip_ambiguous_device.argtypes = skip_args + [u64p]
+        L.mm_run_skip_ambiguous_host.argtypes = [vp, vp, u8p, C.c_uint64, u8p, C.c_uint64, C.c_uint64, u32p,
+                                                 C.c_uint64, u64p]
+        L.mm_run_skip_ambiguous_host_ascii.argtypes = [vp, vp, u8p, C.c_uint64, u32p, C.c_uint64, u64p]
+        reads_skip_args = [vp, vp, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, C.c_uint64, C.c_uint64,
+                           C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, vp]
+        L.mm_run_reads_skip_ambiguous_device_async.argtypes = reads_skip_args + [vp]
+        L.mm_run_reads_skip_ambiguous_device.argtypes = reads_skip_args + [u64p]
+        L.mm_pack_ascii_n_device_async.argtypes = [vp, vp, C.c_uint64, vp, vp]
         L.mm_pack_ascii_device_async.argtypes = [vp, vp, C.c_uint64, vp]
         L.mm_generate_device_async.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
         _lib = L
@@ -126,7 +138,9 @@ EXPORTED_SYMBOLS = [
     "mm_run_device_async", "mm_run_device", "mm_run_host", "mm_run_host_ascii",
     "mm_values_u64_device_async", "mm_values_u64_host", "mm_values_u128_device_async",
     "mm_values_u128_host", "mm_run_batch_device", "mm_run_reads_device_async", "mm_run_reads_device",
-    "mm_pack_ascii_device_async",
+    "mm_run_skip_ambiguous_device_async", "mm_run_skip_ambiguous_device", "mm_run_skip_ambiguous_host",
+    "mm_run_skip_ambiguous_host_ascii", "mm_run_reads_skip_ambiguous_device_async",
+    "mm_run_reads_skip_ambiguous_device", "mm_pack_ascii_n_device_async", "mm_pack_ascii_device_async",
     "mm_generate_device_async",
 ]
 
@@ -195,6 +209,35 @@ class PackedSeqVec(PackedSeq):
     def random(n: int, seed: int = 0) -> "PackedSeqVec":
         rng = np.random.default_rng(seed)
         return PackedSeqVec.from_codes(rng.integers(0, 4, size=n, dtype=np.uint8))
+
+
+class PackedNSeq:
+    """packed-seq ``PackedNSeq``: a PackedSeq view plus one ambiguity bit per base (bit i%8 of byte
+    i/8 of ``amb``, with its own bit offset)."""
+
+    def __init__(self, seq: PackedSeq, amb: np.ndarray, amb_offset: int = 0):
+        self.seq, self.amb, self.amb_offset = seq, amb, amb_offset
+
+    def __len__(self):
+        return len(self.seq)
+
+    def as_slice(self) -> "PackedNSeq":
+        return self
+
+    def slice(self, start: int, end: int) -> "PackedNSeq":
+        return PackedNSeq(self.seq.slice(start, end), self.amb, self.amb_offset + start)
+
+
+class PackedNSeqVec(PackedNSeq):
+    """packed-seq ``PackedNSeqVec`` (call site src/test.rs:436)."""
+
+    @staticmethod
+    def from_ascii(seq: bytes) -> "PackedNSeqVec":
+        a = np.frombuffer(bytes(seq), dtype=np.uint8)
+        up = a & 0xDF
+        isn = ~((up == 65) | (up == 67) | (up == 71) | (up == 84))
+        amb = np.concatenate([np.packbits(isn, bitorder="little"), np.zeros(16, dtype=np.uint8)])
+        return PackedNSeqVec(PackedSeqVec.from_ascii(seq), amb, 0)
 
 
 class AsciiSeq:
@@ -413,6 +456,59 @@ class Builder:
         m = cnt.value
         return pos[:m], (sk[:m] if want_sk else None)
 
+    # -- PackedNSeq: skip windows with ambiguous bases (src/lib.rs:451-496) --
+    def run_skip_ambiguous_windows(self, nseq, min_pos: list) -> Output:
+        """``Builder::run_skip_ambiguous_windows`` (canonical builders only). ``nseq`` is a
+        ``PackedNSeq`` or, as a convenience, an ``AsciiSeq`` (packed on the device)."""
+        L = lib()
+        ws = self._ws()
+        plan = self.plan()
+        n = len(nseq)
+        lwin = self.k + self.w - 1
+        cap = max(1, n - lwin + 1) if n >= lwin else 1
+        pos = np.zeros(cap, dtype=np.uint32)
+        cnt = C.c_uint64()
+        if isinstance(nseq, AsciiSeq):
+            a = np.frombuffer(nseq.seq, dtype=np.uint8)
+            _check(L.mm_run_skip_ambiguous_host_ascii(plan.h, ws.h, _p(a, C.c_uint8) if n else None, n,
+                                                      _p(pos, C.c_uint32), cap, C.byref(cnt)))
+            seq = PackedSeqVec.from_ascii(nseq.seq)
+        else:
+            seq = nseq.seq
+            _check(L.mm_run_skip_ambiguous_host(plan.h, ws.h, _p(seq.data, C.c_uint8), seq.offset,
+                                                _p(nseq.amb, C.c_uint8), nseq.amb_offset, n,
+                                                _p(pos, C.c_uint32), cap, C.byref(cnt)))
+        out = list(map(int, pos[:cnt.value]))
+        if self.mode == MM_MINIMIZERS:
+            while out and min_pos and out[0] == min_pos[-1]:
+                out = out[1:]
+        min_pos.extend(out)
+        return Output(self, seq, min_pos)
+
+    def run_skip_ambiguous_windows_once(self, nseq) -> list:
+        out: list = []
+        self.run_skip_ambiguous_windows(nseq, out)
+        return out
+
+    def run_skip_ambiguous_device(self, d_packed, d_amb, n_bases: int, out_pos, base_offset: int = 0,
+                                  amb_offset: int = 0, win_begin: int = 0, win_end: int = U64_MAX,
+                                  sync: bool = True, d_count=None):
+        """Device-resident PackedNSeq (torch uint8 CUDA tensors for the codes and the ambiguity bits)."""
+        L = lib()
+        cap = out_pos.numel() if out_pos is not None else 0
+        args = [self.plan().h, self._ws().h, C.c_void_p(d_packed.data_ptr()), d_packed.numel(), base_offset,
+                C.c_void_p(d_amb.data_ptr()), d_amb.numel(), amb_offset, n_bases, win_begin, win_end,
+                C.c_void_p(out_pos.data_ptr()) if out_pos is not None else None, cap]
+        if sync:
+            cnt = C.c_uint64()
+            code = L.mm_run_skip_ambiguous_device(*args, C.byref(cnt))
+            if code == ERR["CAPACITY"]:
+                raise MinimizerError(code, f"output capacity {cap} < {cnt.value}")
+            _check(code)
+            return cnt.value
+        _check(L.mm_run_skip_ambiguous_device_async(*args, C.c_void_p(d_count.data_ptr()) if d_count is not None else None))
+        return None
+
     # -- device-resident sequences (torch uint8 CUDA tensors) -----------
     def run_device(self, d_packed, n_bases: int, out_pos, out_sk=None, base_offset: int = 0,
                    win_begin: int = 0, win_end: int = U64_MAX, sync: bool = True, d_count=None):
@@ -456,25 +552,30 @@ def run_batch_device(builder: "Builder", d_seqs, n_bases, out_pos, out_sk=None, 
 
 
 def run_reads_device(builder: "Builder", d_packed, n_reads, read_stride, read_len, out_pos, out_offsets,
-                     read_lens=None, base_offset=0, d_count=None, sync=True):
+                     read_lens=None, base_offset=0, d_count=None, sync=True, d_amb=None, amb_offset=0):
     """Batched short reads in one packed device buffer (read r at base ``base_offset + r*read_stride``);
     read-local positions go back to back into ``out_pos`` and ``out_offsets`` (int64/uint64 CUDA
     tensor, n_reads+1) delimits the reads. Returns the total count when ``sync``."""
     L = lib()
     ws = builder._ws()
     plan = builder.plan()
-    args = [plan.h, ws.h, C.c_void_p(d_packed.data_ptr()), d_packed.numel(), base_offset, n_reads,
-            read_stride, read_len, C.c_void_p(read_lens.data_ptr()) if read_lens is not None else None,
-            C.c_void_p(out_pos.data_ptr()) if out_pos is not None else None,
-            out_pos.numel() if out_pos is not None else 0, C.c_void_p(out_offsets.data_ptr())]
+    cap = out_pos.numel() if out_pos is not None else 0
+    args = [plan.h, ws.h, C.c_void_p(d_packed.data_ptr()), d_packed.numel(), base_offset]
+    if d_amb is not None:  # PackedNSeq reads: skip windows with ambiguous bases
+        args += [C.c_void_p(d_amb.data_ptr()), d_amb.numel(), amb_offset]
+    args += [n_reads, read_stride, read_len, C.c_void_p(read_lens.data_ptr()) if read_lens is not None else None,
+             C.c_void_p(out_pos.data_ptr()) if out_pos is not None else None, cap,
+             C.c_void_p(out_offsets.data_ptr())]
+    fsync, fasync = ((L.mm_run_reads_skip_ambiguous_device, L.mm_run_reads_skip_ambiguous_device_async)
+                     if d_amb is not None else (L.mm_run_reads_device, L.mm_run_reads_device_async))
     if sync:
         cnt = C.c_uint64(0)
-        code = L.mm_run_reads_device(*args, C.byref(cnt))
+        code = fsync(*args, C.byref(cnt))
         if code == ERR["CAPACITY"]:
-            raise MinimizerError(code, f"output capacity {args[10]} < {cnt.value}")
+            raise MinimizerError(code, f"output capacity {cap} < {cnt.value}")
         _check(code)
         return cnt.value
-    _check(L.mm_run_reads_device_async(*args, C.c_void_p(d_count.data_ptr()) if d_count is not None else None))
+    _check(fasync(*args, C.c_void_p(d_count.data_ptr()) if d_count is not None else None))
     return None
 
 

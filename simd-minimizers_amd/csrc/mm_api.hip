@@ -97,6 +97,11 @@ struct mm_workspace {
     uint64_t d_out_elems = 0;
     uint32_t *d_sk = nullptr;
     uint64_t d_sk_elems = 0;
+    // skip-ambiguous path: window ambiguity bits, staged ambiguity bits of the host entry points
+    uint32_t *wamb = nullptr;
+    uint64_t wamb_dwords = 0;
+    void *d_amb = nullptr;
+    uint64_t d_amb_bytes = 0;
     unsigned long long *d_vals = nullptr;
     uint64_t d_vals_elems = 0;
     // knobs / diagnostics
@@ -291,6 +296,8 @@ void mm_workspace_destroy(mm_workspace_t *ws) {
     if (ws->d_ascii) hipFree(ws->d_ascii);
     if (ws->d_out) hipFree(ws->d_out);
     if (ws->d_sk) hipFree(ws->d_sk);
+    if (ws->wamb) hipFree(ws->wamb);
+    if (ws->d_amb) hipFree(ws->d_amb);
     if (ws->d_vals) hipFree(ws->d_vals);
     if (ws->own_stream && ws->stream) hipStreamDestroy(ws->stream);
     delete ws;
@@ -336,16 +343,53 @@ int mm_workspace_kernel_time(mm_workspace_t *ws, double *total_ms, uint64_t *lau
 
 int mm_workspace_last_path(const mm_workspace_t *ws) { return ws ? ws->last_path : 0; }
 
+// Ambiguity bits of a PackedNSeq as they cross the ABI (null d_amb = plain PackedSeq).
+struct AmbArgs {
+    const void *d_amb;
+    uint64_t bytes;
+    uint64_t bit_offset;
+};
+
+// Fills ws->wamb with the window ambiguity bits of windows [win_begin - 1, win_end) of a
+// sequence / buffer span of `span_bases` bases whose windows are l bases long.
+static int prepare_window_ambiguity(mm_workspace_t *ws, const AmbArgs &amb, uint64_t span_bases,
+                                    uint32_t l, uint64_t win_begin, uint64_t win_end,
+                                    uint32_t *out_dwords) {
+    if (!amb.d_amb) return MM_ERR_NULL;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(amb.d_amb);
+    const uint64_t byte_shift = a & 3u;
+    const uint64_t bit0 = amb.bit_offset + 8 * byte_shift;
+    const uint64_t n_dwords = (byte_shift + amb.bytes + 3) / 4;
+    if (n_dwords == 0 || n_dwords >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    if ((bit0 + span_bases + 31) / 32 > n_dwords) return MM_ERR_CAPACITY;
+    const uint64_t need = (win_end + 31) / 32 + 2;
+    int r = grow(ws->wamb, ws->wamb_dwords, need, sizeof(uint32_t));
+    if (r) return r;
+    // the two pad dwords are read by the one-block-ahead prefetch of the last lanes
+    MM_HIP(hipMemsetAsync(ws->wamb + (need - 2), 0, 2 * sizeof(uint32_t), ws->stream));
+    if (mm::launch_window_ambiguity(reinterpret_cast<const uint32_t *>(a - byte_shift), (uint32_t)n_dwords,
+                                    bit0, l, win_begin, win_end, ws->wamb, ws->stream))
+        return hip_fail(hipGetLastError(), "window_ambiguity");
+    *out_dwords = (uint32_t)need;
+    return MM_OK;
+}
+
 // `append`: keep the running total of the previous launch, so that consecutive runs write their
 // outputs back to back (the kernels take the total as the carry-in of their first tile).
 static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
                                  uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
                                  uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
                                  uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_count,
-                                 bool append) {
+                                 bool append, const AmbArgs *amb = nullptr) {
     if (!plan || !ws) return MM_ERR_NULL;
     if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     if (d_out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;  // src/lib.rs:339
+    if (amb) {
+        // run_skip_ambiguous_windows exists on canonical builders only and has no super-k-mer
+        // flavour (src/lib.rs:451-496; assert src/minimizers.rs:176)
+        if (!plan->canonical_windows) return MM_ERR_HASHER_NOT_CANONICAL;
+        if (d_out_sk) return MM_ERR_BAD_MODE;
+    }
     if (!d_out_pos) capacity = 0;
     MM_HIP(hipSetDevice(ws->device));
     const uint64_t l = (uint64_t)plan->k + plan->w - 1;
@@ -375,6 +419,13 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
         a.scratch = nullptr;
         a.generic_round_windows = 0;
         a.timing_start = a.timing_stop = nullptr;
+        a.wamb = nullptr;
+        a.wamb_dwords = 0;
+        if (amb) {
+            r = prepare_window_ambiguity(ws, *amb, n_bases, (uint32_t)l, win_begin, win_end, &a.wamb_dwords);
+            if (r) return r;
+            a.wamb = ws->wamb;
+        }
         const bool fused = !ws->force_generic &&
                            mm::fused_supported(plan->k, plan->w, plan->canonical_windows,
                                                (int)plan->ht.canonical);
@@ -477,9 +528,10 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
                                 uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
                                 uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
                                 uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
-                                uint64_t *d_count) {
+                                uint64_t *d_count, const AmbArgs *amb = nullptr) {
     if (!plan || !ws || !d_out_offsets) return MM_ERR_NULL;
     if (n_reads >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    if (amb && !plan->canonical_windows) return MM_ERR_HASHER_NOT_CANONICAL;
     if (!d_out_pos) capacity = 0;
     MM_HIP(hipSetDevice(ws->device));
     MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
@@ -517,6 +569,14 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
         a.out.error = reinterpret_cast<uint32_t *>(ws->total + 1);
         a.use_ticket = (ws->force_ticket || getenv("MM_FORCE_TICKET")) ? 1 : 0;
         a.timing_start = a.timing_stop = nullptr;
+        a.wamb = nullptr;
+        a.wamb_dwords = 0;
+        const uint64_t l = (uint64_t)plan->k + plan->w - 1;
+        if (amb && span >= l) {
+            r = prepare_window_ambiguity(ws, *amb, span, (uint32_t)l, 0, span - l + 1, &a.wamb_dwords);
+            if (r) return r;
+            a.wamb = ws->wamb;
+        }
         r = grow(ws->status, ws->status_words, mm::fused_reads_status_words(a), sizeof(unsigned long long));
         if (r) return r;
         a.out.status = ws->status;
@@ -554,8 +614,11 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
         for (uint64_t i = 0; i < n_reads; ++i) {
             const uint64_t first = base_offset + i * (uint64_t)read_stride;
             const uint64_t len = d_read_lens ? (lens[i] < read_len ? lens[i] : read_len) : read_len;
+            AmbArgs ra;
+            if (amb) ra = AmbArgs{amb->d_amb, amb->bytes, amb->bit_offset + i * (uint64_t)read_stride};
             r = run_device_async_impl(plan, ws, bytes + first / 4, packed_bytes - first / 4, first % 4, len,
-                                      0, UINT64_MAX, d_out_pos, nullptr, capacity, nullptr, i != 0);
+                                      0, UINT64_MAX, d_out_pos, nullptr, capacity, nullptr, i != 0,
+                                      amb ? &ra : nullptr);
             if (r) return r;
             MM_HIP(hipMemcpyAsync(d_out_offsets + i + 1, ws->total, sizeof(uint64_t),
                                   hipMemcpyDeviceToDevice, ws->stream));
@@ -576,14 +639,15 @@ int mm_run_reads_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const v
                                 read_len, d_read_lens, d_out_pos, capacity, d_out_offsets, d_count);
 }
 
-int mm_run_reads_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
-                        uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
-                        uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
-                        uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
-                        uint64_t *out_count) {
+static int run_reads_sync(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                          uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
+                          uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
+                          uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
+                          uint64_t *out_count, const AmbArgs *amb) {
+    if (!ws) return MM_ERR_NULL;
     for (int attempt = 0; attempt < 2; ++attempt) {
         int r = run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride,
-                                     read_len, d_read_lens, d_out_pos, capacity, d_out_offsets, nullptr);
+                                     read_len, d_read_lens, d_out_pos, capacity, d_out_offsets, nullptr, amb);
         if (r) return r;
         MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long),
                               hipMemcpyDeviceToHost, ws->stream));
@@ -600,13 +664,57 @@ int mm_run_reads_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d
     return MM_OK;
 }
 
-int mm_run_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
-                  uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
-                  uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos, uint32_t *d_out_sk,
-                  uint64_t capacity, uint64_t *out_count) {
+int mm_run_reads_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                        uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
+                        uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
+                        uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
+                        uint64_t *out_count) {
+    return run_reads_sync(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride, read_len,
+                          d_read_lens, d_out_pos, capacity, d_out_offsets, out_count, nullptr);
+}
+
+int mm_run_reads_skip_ambiguous_device_async(const mm_plan_t *plan, mm_workspace_t *ws,
+                                             const void *d_packed, uint64_t packed_bytes,
+                                             uint64_t base_offset, const void *d_amb, uint64_t amb_bytes,
+                                             uint64_t amb_offset, uint64_t n_reads, uint32_t read_stride,
+                                             uint32_t read_len, const uint32_t *d_read_lens,
+                                             uint32_t *d_out_pos, uint64_t capacity,
+                                             uint64_t *d_out_offsets, uint64_t *d_count) {
+    const AmbArgs amb{d_amb, amb_bytes, amb_offset};
+    return run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride,
+                                read_len, d_read_lens, d_out_pos, capacity, d_out_offsets, d_count, &amb);
+}
+
+int mm_run_reads_skip_ambiguous_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                                       uint64_t packed_bytes, uint64_t base_offset, const void *d_amb,
+                                       uint64_t amb_bytes, uint64_t amb_offset, uint64_t n_reads,
+                                       uint32_t read_stride, uint32_t read_len,
+                                       const uint32_t *d_read_lens, uint32_t *d_out_pos,
+                                       uint64_t capacity, uint64_t *d_out_offsets, uint64_t *out_count) {
+    const AmbArgs amb{d_amb, amb_bytes, amb_offset};
+    return run_reads_sync(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride, read_len,
+                          d_read_lens, d_out_pos, capacity, d_out_offsets, out_count, &amb);
+}
+
+// ---- PackedNSeq: Builder::run_skip_ambiguous_windows (src/lib.rs:451-496)
+int mm_run_skip_ambiguous_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                                       uint64_t packed_bytes, uint64_t base_offset, const void *d_amb,
+                                       uint64_t amb_bytes, uint64_t amb_offset, uint64_t n_bases,
+                                       uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
+                                       uint64_t capacity, uint64_t *d_count) {
+    const AmbArgs amb{d_amb, amb_bytes, amb_offset};
+    return run_device_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin,
+                                 win_end, d_out_pos, nullptr, capacity, d_count, false, &amb);
+}
+
+static int run_device_sync(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                           uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
+                           uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos, uint32_t *d_out_sk,
+                           uint64_t capacity, uint64_t *out_count, const AmbArgs *amb) {
+    if (!ws) return MM_ERR_NULL;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        int r = mm_run_device_async(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin,
-                                    win_end, d_out_pos, d_out_sk, capacity, nullptr);
+        int r = run_device_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin,
+                                      win_end, d_out_pos, d_out_sk, capacity, nullptr, false, amb);
         if (r) return r;
         MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long),
                               hipMemcpyDeviceToHost, ws->stream));
@@ -625,10 +733,28 @@ int mm_run_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packe
     return MM_OK;
 }
 
+int mm_run_skip_ambiguous_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                                 uint64_t packed_bytes, uint64_t base_offset, const void *d_amb,
+                                 uint64_t amb_bytes, uint64_t amb_offset, uint64_t n_bases,
+                                 uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
+                                 uint64_t capacity, uint64_t *out_count) {
+    const AmbArgs amb{d_amb, amb_bytes, amb_offset};
+    return run_device_sync(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin, win_end,
+                           d_out_pos, nullptr, capacity, out_count, &amb);
+}
+
+int mm_run_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                  uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
+                  uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos, uint32_t *d_out_sk,
+                  uint64_t capacity, uint64_t *out_count) {
+    return run_device_sync(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin, win_end,
+                           d_out_pos, d_out_sk, capacity, out_count, nullptr);
+}
+
 static int run_host_common(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
                            uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
                            uint32_t *out_pos, uint32_t *out_sk, uint64_t capacity,
-                           uint64_t *out_count) {
+                           uint64_t *out_count, const AmbArgs *amb = nullptr) {
     const uint64_t l = (uint64_t)plan->k + plan->w - 1;
     const uint64_t n_w = n_bases >= l ? n_bases - l + 1 : 0;
     uint64_t cap = out_pos ? (capacity < n_w ? capacity : n_w) : 0;
@@ -639,8 +765,8 @@ static int run_host_common(const mm_plan_t *plan, mm_workspace_t *ws, const void
         if (r) return r;
     }
     uint64_t count = 0;
-    r = mm_run_device(plan, ws, d_packed, packed_bytes, base_offset, n_bases, 0, UINT64_MAX,
-                      cap ? ws->d_out : nullptr, (out_sk && cap) ? ws->d_sk : nullptr, cap, &count);
+    r = run_device_sync(plan, ws, d_packed, packed_bytes, base_offset, n_bases, 0, UINT64_MAX,
+                        cap ? ws->d_out : nullptr, (out_sk && cap) ? ws->d_sk : nullptr, cap, &count, amb);
     if (out_count) *out_count = count;
     if (r == MM_ERR_CAPACITY) return r;
     if (r) return r;
@@ -698,6 +824,76 @@ int mm_run_host_ascii(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *
     }
     return run_host_common(plan, ws, ws->d_in, bytes + 16, 0, n_bases, out_pos, out_sk, capacity,
                            out_count);
+}
+
+int mm_run_skip_ambiguous_host(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed,
+                               uint64_t base_offset, const uint8_t *amb, uint64_t amb_offset,
+                               uint64_t n_bases, uint32_t *out_pos, uint64_t capacity,
+                               uint64_t *out_count) {
+    if (!plan || !ws) return MM_ERR_NULL;
+    if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    if (!plan->canonical_windows) return MM_ERR_HASHER_NOT_CANONICAL;
+    MM_HIP(hipSetDevice(ws->device));
+    const uint64_t bytes = (base_offset + n_bases + 3) / 4;
+    const uint64_t abytes = (amb_offset + n_bases + 7) / 8;
+    uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
+    int r = grow(din, ws->d_in_bytes, bytes + 16, 1);
+    ws->d_in = din;
+    if (r) return r;
+    uint8_t *damb = reinterpret_cast<uint8_t *>(ws->d_amb);
+    r = grow(damb, ws->d_amb_bytes, abytes + 16, 1);
+    ws->d_amb = damb;
+    if (r) return r;
+    if (n_bases) {
+        if (!packed || !amb) return MM_ERR_NULL;
+        MM_HIP(hipMemcpyAsync(ws->d_in, packed, bytes, hipMemcpyHostToDevice, ws->stream));
+        MM_HIP(hipMemcpyAsync(ws->d_amb, amb, abytes, hipMemcpyHostToDevice, ws->stream));
+    }
+    const AmbArgs a{ws->d_amb, abytes + 16, amb_offset};
+    return run_host_common(plan, ws, ws->d_in, bytes + 16, base_offset, n_bases, out_pos, nullptr,
+                           capacity, out_count, &a);
+}
+
+int mm_run_skip_ambiguous_host_ascii(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *ascii,
+                                     uint64_t n_bases, uint32_t *out_pos, uint64_t capacity,
+                                     uint64_t *out_count) {
+    if (!plan || !ws) return MM_ERR_NULL;
+    if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    if (!plan->canonical_windows) return MM_ERR_HASHER_NOT_CANONICAL;
+    MM_HIP(hipSetDevice(ws->device));
+    const uint64_t bytes = (n_bases + 3) / 4, abytes = (n_bases + 7) / 8;
+    uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
+    int r = grow(din, ws->d_in_bytes, bytes + 16, 1);
+    ws->d_in = din;
+    if (r) return r;
+    uint8_t *damb = reinterpret_cast<uint8_t *>(ws->d_amb);
+    r = grow(damb, ws->d_amb_bytes, abytes + 16, 1);
+    ws->d_amb = damb;
+    if (r) return r;
+    uint8_t *dasc = reinterpret_cast<uint8_t *>(ws->d_ascii);
+    r = grow(dasc, ws->d_ascii_bytes, n_bases + 16, 1);
+    ws->d_ascii = dasc;
+    if (r) return r;
+    if (n_bases) {
+        if (!ascii) return MM_ERR_NULL;
+        MM_HIP(hipMemcpyAsync(ws->d_ascii, ascii, n_bases, hipMemcpyHostToDevice, ws->stream));
+        if (mm::launch_pack_ascii_n(dasc, n_bases, din, damb, ws->stream))
+            return hip_fail(hipGetLastError(), "pack_ascii_n");
+    }
+    const AmbArgs a{ws->d_amb, abytes + 16, 0};
+    return run_host_common(plan, ws, ws->d_in, bytes + 16, 0, n_bases, out_pos, nullptr, capacity,
+                           out_count, &a);
+}
+
+int mm_pack_ascii_n_device_async(mm_workspace_t *ws, const uint8_t *d_ascii, uint64_t n_bases,
+                                 uint8_t *d_packed, uint8_t *d_amb) {
+    if (!ws) return MM_ERR_NULL;
+    if (n_bases == 0) return MM_OK;
+    if (!d_ascii || !d_packed || !d_amb) return MM_ERR_NULL;
+    MM_HIP(hipSetDevice(ws->device));
+    if (mm::launch_pack_ascii_n(d_ascii, n_bases, d_packed, d_amb, ws->stream))
+        return hip_fail(hipGetLastError(), "pack_ascii_n");
+    return MM_OK;
 }
 
 int mm_values_u64_device_async(mm_workspace_t *ws, const void *d_packed, uint64_t packed_bytes,

@@ -155,6 +155,152 @@ int launch_pack_ascii(const uint8_t *d_ascii, uint64_t n, uint8_t *d_packed, hip
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ------------------------------------------------------------------ PackedNSeq
+// Window ambiguity bits for the skip-ambiguous path (src/minimizers.rs:203-212: the stream
+// par_iter_kmer_ambiguity(l, ..) zipped with the positions): bit i of `out` = some base of
+// window i, i.e. of bases [i, i + l), is ambiguous.  One output dword (32 windows) per thread:
+//   window j of the dword is ambiguous iff an N sits in [32t + j, 32t + j + l):
+//   l >= 32: the bases [32t+32, 32t+l) are common to all 32 windows; otherwise only an N at bit
+//   b of the first dword (windows j <= b) or at bit r of the 32 bits from 32t+l on (windows
+//   j > r) matters.   l < 32: OR of l shifted copies of a 64-bit view.
+__device__ __forceinline__ uint32_t bit_view32(const uint32_t *__restrict__ a, uint32_t n_dwords,
+                                               unsigned long long bit) {
+    const unsigned long long idx = bit >> 5;
+    const uint32_t sh = (uint32_t)bit & 31u;
+    const uint32_t lo = idx < n_dwords ? a[idx] : 0u;
+    const uint32_t hi = idx + 1 < n_dwords ? a[idx + 1] : 0u;
+    return sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void window_ambiguity_kernel(
+    const uint32_t *__restrict__ amb, uint32_t amb_dwords, unsigned long long bit0, uint32_t l,
+    uint64_t first_dword, uint64_t end_dword, uint32_t *__restrict__ out) {
+    const uint64_t t = first_dword + (uint64_t)blockIdx.x * kBlockThreads + threadIdx.x;
+    if (t >= end_dword) return;
+    const unsigned long long b = bit0 + 32ull * t;
+    uint32_t r;
+    if (l < 32u) {
+        const unsigned long long v =
+            (unsigned long long)bit_view32(amb, amb_dwords, b) |
+            ((unsigned long long)bit_view32(amb, amb_dwords, b + 32) << 32);
+        unsigned long long acc = 0;
+        for (uint32_t s = 0; s < l; ++s) acc |= v >> s;
+        r = (uint32_t)acc;
+    } else {
+        uint32_t any = 0;
+        for (uint32_t done = 32; done < l; done += 32) {
+            uint32_t v = bit_view32(amb, amb_dwords, b + done);
+            if (l - done < 32u) v &= (1u << (l - done)) - 1u;
+            any |= v;
+        }
+        if (any) {
+            r = 0xffffffffu;
+        } else {
+            const uint32_t a0 = bit_view32(amb, amb_dwords, b);
+            const uint32_t a1 = bit_view32(amb, amb_dwords, b + l);
+            const uint32_t left = a0 ? (0xffffffffu >> __clz(a0)) : 0u;          // windows j <= msb(a0)
+            const uint32_t right = a1 ? ~((2u << (__ffs(a1) - 1)) - 1u) : 0u;    // windows j > lsb(a1)
+            r = left | right;
+        }
+    }
+    out[t] = r;
+}
+
+int launch_window_ambiguity(const uint32_t *d_amb, uint32_t amb_dwords, uint64_t bit0, uint32_t l,
+                            uint64_t win_begin, uint64_t win_end, uint32_t *d_out, hipStream_t stream) {
+    if (win_begin >= win_end) return 0;
+    // one extra window in front: the dedup predecessor of win_begin
+    const uint64_t first = (win_begin ? win_begin - 1 : 0) / 32, end = (win_end + 31) / 32;
+    uint32_t grid = (uint32_t)((end - first + kBlockThreads - 1) / kBlockThreads);
+    hipLaunchKernelGGL(window_ambiguity_kernel, dim3(grid), dim3(kBlockThreads), 0, stream, d_amb,
+                       amb_dwords, (unsigned long long)bit0, l, first, end, d_out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// PackedNSeqVec::from_ascii (packed-seq; call site src/test.rs:436): lossy 2-bit codes plus one
+// ambiguity bit per base (set for everything that is not ACGT / acgt).
+// bit 7 of every byte of the result is set where the byte of x is NOT one of A C G T (any case)
+__device__ __forceinline__ uint32_t non_acgt4(uint32_t x) {
+    x &= 0xDFDFDFDFu;  // upper case
+    uint32_t is = 0;
+#pragma unroll
+    for (uint32_t c : {0x41414141u, 0x43434343u, 0x47474747u, 0x54545454u}) {
+        const uint32_t z = x ^ c;  // zero byte <=> match
+        const uint32_t t = ((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z;
+        is |= ~t;
+    }
+    return ~is & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t movemask4(uint32_t m) {  // bit 7 of byte i -> bit i
+    const uint32_t b = m >> 7;
+    return (b | (b >> 7) | (b >> 14) | (b >> 21)) & 0xfu;
+}
+
+// fast path: 32 bases per thread from two aligned 16-byte loads
+__global__ __launch_bounds__(kBlockThreads) void pack_ascii_n32_kernel(const uint4 *__restrict__ ascii16,
+                                                                       uint64_t n_groups,
+                                                                       uint2 *__restrict__ packed64,
+                                                                       uint32_t *__restrict__ amb32) {
+    uint64_t g = (uint64_t)blockIdx.x * kBlockThreads + threadIdx.x;
+    if (g >= n_groups) return;
+    const uint4 a = ascii16[2 * g], b = ascii16[2 * g + 1];
+    uint2 p;
+    p.x = pack4(a.x) | (pack4(a.y) << 8) | (pack4(a.z) << 16) | (pack4(a.w) << 24);
+    p.y = pack4(b.x) | (pack4(b.y) << 8) | (pack4(b.z) << 16) | (pack4(b.w) << 24);
+    packed64[g] = p;
+    amb32[g] = movemask4(non_acgt4(a.x)) | (movemask4(non_acgt4(a.y)) << 4) |
+               (movemask4(non_acgt4(a.z)) << 8) | (movemask4(non_acgt4(a.w)) << 12) |
+               (movemask4(non_acgt4(b.x)) << 16) | (movemask4(non_acgt4(b.y)) << 20) |
+               (movemask4(non_acgt4(b.z)) << 24) | (movemask4(non_acgt4(b.w)) << 28);
+}
+
+// general path / tail: 8 bases per thread -> two packed bytes and one ambiguity byte
+__global__ __launch_bounds__(kBlockThreads) void pack_ascii_n_kernel(const uint8_t *__restrict__ ascii,
+                                                                     uint64_t first_group, uint64_t n,
+                                                                     uint8_t *__restrict__ packed,
+                                                                     uint8_t *__restrict__ amb) {
+    const uint64_t g = first_group + (uint64_t)blockIdx.x * kBlockThreads + threadIdx.x;
+    if (8 * g >= n) return;
+    uint32_t pk = 0, am = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        const uint64_t i = 8 * g + j;
+        if (i < n) {
+            const uint32_t c = ascii[i];
+            pk |= ((c >> 1) & 3u) << (2 * j);
+            const uint32_t u = c & 0xDFu;
+            am |= (uint32_t)!(u == 'A' || u == 'C' || u == 'G' || u == 'T') << j;
+        }
+    }
+    packed[2 * g] = (uint8_t)pk;
+    if (8 * g + 4 < n) packed[2 * g + 1] = (uint8_t)(pk >> 8);
+    amb[g] = (uint8_t)am;
+}
+
+int launch_pack_ascii_n(const uint8_t *d_ascii, uint64_t n, uint8_t *d_packed, uint8_t *d_amb,
+                        hipStream_t stream) {
+    if (n == 0) return 0;
+    uint64_t done_groups8 = 0;  // groups of 8 bases finished by the fast path
+    const bool aligned = (reinterpret_cast<uintptr_t>(d_ascii) % 16 == 0) &&
+                         (reinterpret_cast<uintptr_t>(d_packed) % 8 == 0) &&
+                         (reinterpret_cast<uintptr_t>(d_amb) % 4 == 0);
+    if (aligned && n >= 32) {
+        const uint64_t groups = n / 32;
+        uint32_t grid = (uint32_t)((groups + kBlockThreads - 1) / kBlockThreads);
+        hipLaunchKernelGGL(pack_ascii_n32_kernel, dim3(grid), dim3(kBlockThreads), 0, stream,
+                           reinterpret_cast<const uint4 *>(d_ascii), groups,
+                           reinterpret_cast<uint2 *>(d_packed), reinterpret_cast<uint32_t *>(d_amb));
+        done_groups8 = groups * 4;
+    }
+    const uint64_t groups8 = (n + 7) / 8;
+    if (done_groups8 < groups8) {
+        uint32_t grid = (uint32_t)((groups8 - done_groups8 + kBlockThreads - 1) / kBlockThreads);
+        hipLaunchKernelGGL(pack_ascii_n_kernel, dim3(grid), dim3(kBlockThreads), 0, stream, d_ascii,
+                           done_groups8, n, d_packed, d_amb);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 __device__ __forceinline__ unsigned long long splitmix_final(unsigned long long z) {
     z ^= z >> 30;
     z *= 0xBF58476D1CE4E5B9ull;

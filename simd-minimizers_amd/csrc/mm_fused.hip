@@ -98,6 +98,8 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.read_stride = p.read_len = 0;
     p.read_lens = nullptr;
     p.read_offsets = nullptr;
+    p.wamb = a.wamb;
+    p.wamb_dwords = a.wamb_dwords;
     p.out = a.out;
     p.use_ticket = a.use_ticket ? 1u : 0u;
     {
@@ -177,6 +179,8 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.read_len = a.read_len;
     p.read_lens = a.read_lens;
     p.read_offsets = a.read_offsets;
+    p.wamb = a.wamb;
+    p.wamb_dwords = a.wamb_dwords;
     p.out = a.out;
     if (lds_bytes > 64u * 1024u) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(inst->fn),

@@ -51,6 +51,10 @@ struct FusedParams {
     uint32_t read_len;                  // length of every read, or the maximum when read_lens != null
     const uint32_t *read_lens;          // optional per-read lengths (device)
     unsigned long long *read_offsets;   // [n_reads + 1] first output slot of every read (device)
+    // skip-ambiguous windows (PackedNSeq, src/minimizers.rs:169-214): bit g set = the window that
+    // starts at base g (relative to the first base of the sequence / buffer span) is skipped
+    const uint32_t *wamb;               // null for a plain PackedSeq
+    uint32_t wamb_dwords;
     OutParams out;
 };
 
@@ -101,12 +105,13 @@ struct LaneCtx {
     uint8_t *list;           // LDS: this lane's list slot 0 (list mode)
     uint32_t list_bytes;     // list_cap * kListStride (the super-k-mer list follows at +list_bytes)
     unsigned long long dst;  // first output slot of this lane (DIRECT mode)
+    uint32_t abase;          // bit of the lane's window 0 in FusedParams::wamb (AMBI walks)
 };
 
 // One lane walks its S windows.  List mode: appends emitted 16-bit values to the lane's LDS
 // list (entries past the capacity are dropped but counted).  DIRECT mode: stores final values
 // to HBM from ctx.dst on.  Returns the number of emitted windows.
-template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool DIRECT, bool PARTIAL>
+template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool DIRECT, bool PARTIAL, bool AMBI = false>
 __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCtx &ctx, bool &overflowed) {
     constexpr int NSUB = (W + 15) / 16;  // 16-base view words per W-block
     const uint32_t nblk = p.nblk;
@@ -236,6 +241,24 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     }
     if (ctx.no_prev) prev = 0xffffffffu;  // no predecessor window: the first window always emits
 
+    // skip-ambiguous windows: one bit per window, 32-window views prefetched one block ahead.
+    // A skipped window emits nothing and (like the SIMD collector, src/intrinsics/dedup.rs:147-155)
+    // never equals its successor, so the first clean window after it always emits.
+    static_assert(!AMBI || PARTIAL, "AMBI walks use the flag path");
+    constexpr int NSUBA = AMBI ? (W + 31) / 32 : 1;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(AMBI ? p.wamb : p.seq.d), 0, AMBI ? (int)(p.wamb_dwords * 4u) : 0, 0x00020000);
+    auto aview = [&](uint32_t bit) -> uint32_t {
+        const auto d = __builtin_amdgcn_raw_buffer_load_b64(arsrc, (bit >> 5) << 2, 0, 0);
+        return __builtin_amdgcn_alignbit(d[1], d[0], bit & 31u);
+    };
+    uint32_t aw[NSUBA], aw_next[NSUBA];
+    if (AMBI) {
+#pragma unroll
+        for (int g = 0; g < NSUBA; ++g) aw_next[g] = aview(ctx.abase + 32u * (uint32_t)g);
+        if (MODE == 0 && !ctx.no_prev && (aview(ctx.abase - 1u) & 1u)) prev = 0xffffffffu;
+    }
+
     // ---- blocks 1..nblk: one window per step
     // next free list slot as a 32-bit LDS address (the low half of the flat address of LDS memory)
     const uint32_t list0 = (uint32_t)reinterpret_cast<uintptr_t>(ctx.list);
@@ -271,6 +294,13 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             va[g] = view(pos_in + 16 * g);
             vr[g] = view(pos_out + 16 * g);
             if (CANON) v2[g] = view(pos_r2 + 16 * g);
+        }
+        if (AMBI) {
+#pragma unroll
+            for (int g = 0; g < NSUBA; ++g) {
+                aw[g] = aw_next[g];
+                aw_next[g] = aview(ctx.abase + b * (uint32_t)W + 32u * (uint32_t)g);
+            }
         }
         if (!DIRECT) {
             // keep a whole block of appends inside the list: a lane that is about to run out of
@@ -378,15 +408,17 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 }
             } else {
                 bool flag;
+                const bool skipped = AMBI && ((aw[AMBI ? (j >> 5) : 0] >> (j & 31)) & 1u);
                 if (MODE == 0) {
                     flag = (uint16_t)sel != (uint16_t)prev;
-                    prev = sel;
+                    prev = skipped ? 0xffffffffu : sel;
                 } else if (MODE == 1) {
                     flag = ((uint16_t)sel == (uint16_t)(i + 1u)) | ((uint16_t)sel == (uint16_t)e);
                 } else {
                     flag = (uint16_t)sel == (uint16_t)(i + 1u + (uint32_t)(W / 2));
                 }
                 if (PARTIAL) flag = flag && ((int)i < ctx.rem_valid);
+                if (AMBI) flag = flag && !skipped;
                 if (flag) {
                     if (DIRECT) {
                         if (dst < p.out.cap) {
@@ -432,6 +464,10 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     __shared__ uint32_t s_wave_tot[kFusedWaves];
     __shared__ unsigned long long s_excl;
 
+    // kernels that also carry the skip-ambiguous walk: canonical windows, positions only (the
+    // reference offers run_skip_ambiguous_windows on canonical builders without super-k-mers,
+    // src/lib.rs:451-496)
+    constexpr bool kAmbi = CANON && !SK;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     // Tile id.  Default: blockIdx.x (workgroups are dispatched in index order on gfx950, which
     // the look-back needs for forward progress; its spins are bounded and report a violation,
@@ -471,6 +507,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         ctx.wbase = 0;
         ctx.no_prev = true;
         ctx.rem_valid = (int)(nw < S ? nw : S);
+        ctx.abase = r * p.read_stride;
     } else {
         const uint32_t lw = (uint32_t)tid * S;  // first window of the lane, tile-relative
         lane_active = lw < nvalid;
@@ -479,13 +516,15 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         ctx.wbase = (uint32_t)bw0 + lw;
         ctx.no_prev = (bw0 + lw == 0);
         ctx.rem_valid = (int)nvalid - (int)lw;
+        ctx.abase = (uint32_t)bw0 + lw;
     }
 
     // ---------------------------------------------------------------- phase 1
     uint32_t my_count = 0;
     if (lane_active && !(p.debug & 4u)) {
         bool over = false;
-        if (READS) my_count = lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over);
+        if (kAmbi && p.wamb) my_count = lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi>(p, ctx, over);
+        else if (READS) my_count = lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over);
         else my_count = partial ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over)
                                 : lane_walk<W, CANON, HASH_RC, MODE, SK, false, false>(p, ctx, over);
         if (over) s_overflow = 1;  // benign race: every writer stores 1
@@ -553,7 +592,8 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         // some list overflowed: walk the tile again, now storing straight to the output
         ctx.dst = run0 + excl;
         bool over;
-        if (READS || partial) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true>(p, ctx, over);
+        if (kAmbi && p.wamb) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true, kAmbi>(p, ctx, over);
+        else if (READS || partial) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true>(p, ctx, over);
         else lane_walk<W, CANON, HASH_RC, MODE, SK, true, false>(p, ctx, over);
     }
     if (tid == 0 && bid == gridDim.x - 1) {

@@ -42,14 +42,21 @@ __global__ __launch_bounds__(kBlockThreads) void generic_hash_kernel(
     }
 }
 
+constexpr uint32_t kSkipped = 0xFFFFFFFEu;
+
 // ------------------------------------------------------ per-window position
 // One window per lane: leftmost / rightmost argmin of (hash & 0xffff0000) over w k-mers.
 __global__ __launch_bounds__(kBlockThreads) void generic_window_kernel(
     SeqView seq, uint32_t k, uint32_t w, int canonical_windows, uint64_t km_begin,
     const uint32_t *__restrict__ hash, uint64_t win_first, uint64_t win_end,
-    uint32_t *__restrict__ winpos /* [win_end - win_first] */) {
+    uint32_t *__restrict__ winpos /* [win_end - win_first] */,
+    const uint32_t *__restrict__ wamb /* skip-ambiguous: bit i = window i is skipped; or null */) {
     uint64_t i = win_first + (uint64_t)blockIdx.x * kBlockThreads + threadIdx.x;
     if (i >= win_end) return;
+    if (wamb && ((wamb[i >> 5] >> (i & 31)) & 1u)) {
+        winpos[i - win_first] = kSkipped;  // SKIPPED, src/minimizers.rs:18
+        return;
+    }
     const uint32_t *h = hash + (i - km_begin);
     uint32_t best = h[0] & 0xffff0000u;
     uint32_t left = 0, right = 0;
@@ -89,7 +96,7 @@ constexpr uint32_t kWinPerBlockC = kBlockThreads * kWinPerLaneC;
 __global__ __launch_bounds__(kBlockThreads) void generic_compact_kernel(
     uint32_t w, uint32_t mode, uint64_t win_first /* window index of winpos[0] */,
     uint64_t win_begin /* first window to emit */, uint64_t win_end,
-    const uint32_t *__restrict__ winpos, OutParams out) {
+    const uint32_t *__restrict__ winpos, OutParams out, int skip /* drop SKIPPED windows */) {
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_wave_tot[kWavesPerBlock];
     __shared__ unsigned long long s_excl;
@@ -116,6 +123,8 @@ __global__ __launch_bounds__(kBlockThreads) void generic_compact_kernel(
             if (mode == 0) f = !have_prev || p != prev;
             else if (mode == 1) f = (p == (uint32_t)i) || (p == (uint32_t)i + w - 1);
             else f = (p == (uint32_t)i + w / 2);
+            // src/intrinsics/dedup.rs:147-155: differs from its predecessor and is not SKIPPED
+            if (skip && p == kSkipped) f = false;
         }
         vals[j] = (mode == 0) ? p : (uint32_t)i;
         flags |= (uint32_t)f << j;
@@ -173,13 +182,13 @@ int launch_generic(const RunArgs &a, hipStream_t stream) {
         uint64_t n_w = we - win_first;
         uint32_t g2 = (uint32_t)((n_w + kBlockThreads - 1) / kBlockThreads);
         hipLaunchKernelGGL(generic_window_kernel, dim3(g2), dim3(kBlockThreads), 0, stream, a.seq,
-                           a.k, a.w, a.canonical_windows, km_begin, hash, win_first, we, winpos);
+                           a.k, a.w, a.canonical_windows, km_begin, hash, win_first, we, winpos, a.wamb);
         uint32_t g3 = (uint32_t)((we - wb + kWinPerBlockC - 1) / kWinPerBlockC);
         if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * g3, stream) != hipSuccess)
             return -1;
         if (hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
         hipLaunchKernelGGL(generic_compact_kernel, dim3(g3), dim3(kBlockThreads), 0, stream, a.w,
-                           a.mode, win_first, wb, we, winpos, a.out);
+                           a.mode, win_first, wb, we, winpos, a.out, a.wamb ? 1 : 0);
     }
     if (a.timing_stop) hipEventRecord(a.timing_stop, stream);
     return hipGetLastError() == hipSuccess ? 0 : -1;

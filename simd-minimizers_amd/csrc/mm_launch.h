@@ -15,6 +15,9 @@ struct RunArgs {
     uint32_t mode;  // 0 minimizers, 1 closed syncmers, 2 open syncmers
     uint64_t win_begin, win_end;
     OutParams out;
+    // skip-ambiguous windows: bit i set = window i holds an ambiguous base (null = plain PackedSeq)
+    const uint32_t *wamb;
+    uint32_t wamb_dwords;
     // fused path
     uint32_t nblk;  // w-blocks per lane (0 = default)
     int use_ticket; // tile ids from an atomic ticket instead of blockIdx.x (safe mode)
@@ -40,6 +43,8 @@ struct ReadsArgs {
     uint32_t read_stride, read_len;
     const uint32_t *read_lens;           // device, optional
     unsigned long long *read_offsets;    // device, n_reads + 1
+    const uint32_t *wamb;                // window ambiguity bits over the whole buffer span (or null)
+    uint32_t wamb_dwords;
     OutParams out;
     int use_ticket;
     hipEvent_t timing_start, timing_stop;
@@ -60,6 +65,11 @@ int launch_values_u64(SeqView seq, uint32_t len, int canonical, const uint32_t *
 int launch_values_u128(SeqView seq, uint32_t len, int canonical, const uint32_t *d_pos,
                        uint64_t n_pos, unsigned long long *d_values, hipStream_t stream);
 int launch_pack_ascii(const uint8_t *d_ascii, uint64_t n, uint8_t *d_packed, hipStream_t stream);
+int launch_pack_ascii_n(const uint8_t *d_ascii, uint64_t n, uint8_t *d_packed, uint8_t *d_amb,
+                        hipStream_t stream);
+// bit i of d_out = window i (bases [i, i+l)) holds an ambiguous base; windows [win_begin-1, win_end)
+int launch_window_ambiguity(const uint32_t *d_amb, uint32_t amb_dwords, uint64_t bit0, uint32_t l,
+                            uint64_t win_begin, uint64_t win_end, uint32_t *d_out, hipStream_t stream);
 int launch_generate(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d_packed,
                     hipStream_t stream);
 

@@ -611,3 +611,130 @@ def test_reads_mode_dense_and_long(sm, oracle, gpu):
                 want = oracle.run(data, read_len, k, w, canonical=canonical, base_offset=r * stride)
                 assert np.array_equal(host[h_offs[r]:h_offs[r + 1]], want), (fill, k, w, r)
     _check_reads(sm, oracle, 21, 11, True, 0, 6, 70_000, 69_999, None, 0, 3)
+
+
+# ------------------------------------------------- skip-ambiguous windows (PackedNSeq)
+def _ascii_with_n(rng, n, frac, runs):
+    a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+    if n and frac > 0:
+        if runs:
+            for _ in range(max(1, int(n * frac / 30))):
+                s = int(rng.integers(0, n))
+                a[s:s + int(rng.integers(1, 60))] = ord("N")
+        else:
+            a[rng.integers(0, n, size=max(1, int(n * frac)))] = ord("N")
+    return a
+
+
+def test_skip_ambiguous_small_sweep(sm, oracle, gpu):
+    """The reference's skip_ambiguous test shape (src/test.rs:428-482: 100 bases, 1% N, all odd
+    l <= 64) plus lengths around l, against the oracle; fused and generic families; PackedNSeq
+    and ASCII entry points; slices with non-zero base / ambiguity offsets."""
+    rng = np.random.default_rng(21)
+    for n, frac, runs in [(100, 0.01, False), (100, 0.06, False), (333, 0.05, True)]:
+        a = _ascii_with_n(rng, n, frac, runs)
+        nseq = sm.PackedNSeqVec.from_ascii(a.tobytes())
+        packed, amb = oracle.pack_ascii_n(a.tobytes())
+        assert np.array_equal(nseq.amb[: (n + 7) // 8], amb[: (n + 7) // 8])
+        for k in range(1, 65, 2):
+            for w in range(1, 64, 3):
+                l = k + w - 1
+                if l % 2 == 0 or l > 64:
+                    continue
+                for mode in (0, 1, 2):
+                    if mode == 2 and w % 2 == 0:
+                        continue
+                    b = sm.Builder(k, w, True, mode)
+                    want = list(map(int, oracle.run_skip_ambiguous(packed, amb, n, k, w, mode=mode)))
+                    for force_generic in (False, True):
+                        gpu.force_generic(force_generic)
+                        assert b.run_skip_ambiguous_windows_once(nseq) == want, (n, k, w, mode, force_generic)
+                    gpu.force_generic(False)
+                    if mode == 0:
+                        assert b.run_skip_ambiguous_windows_once(sm.AsciiSeq(a.tobytes())) == want
+                        s0, s1 = 3, n - 2
+                        sl = nseq.slice(s0, s1)
+                        want_sl = list(map(int, oracle.run_skip_ambiguous(packed, amb, s1 - s0, k, w,
+                                                                          base_offset=s0, amb_offset=s0)))
+                        assert b.run_skip_ambiguous_windows_once(sl) == want_sl, (n, k, w, "slice")
+    # forward plans are rejected like the reference's assert (src/minimizers.rs:176)
+    with pytest.raises(sm.MinimizerError) as e:
+        sm.minimizers(5, 7).run_skip_ambiguous_windows_once(nseq)
+    assert e.value.code == sm.ERR["HASHER_NOT_CANONICAL"]
+
+
+@pytest.mark.parametrize("k,w,mode", [(21, 11, 0), (31, 51, 0), (15, 17, 1), (15, 17, 2), (12, 18, 0), (7, 5, 0)])
+def test_skip_ambiguous_large_device(sm, oracle, gpu, k, w, mode):
+    """4 Mbp with isolated Ns, N runs (assembly gaps), Ns at both ends; device-resident input packed
+    by mm_pack_ascii_n_device_async; whole run, window-range shards, fused vs generic."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(k * 100 + w)
+    n = 4_000_003
+    a = _ascii_with_n(rng, n, 0.002, False)
+    for s in rng.integers(0, n - 70_000, size=12):
+        a[s:s + int(rng.integers(1, 70_000))] = ord("n")
+    a[:3] = ord("N")
+    a[-2:] = ord("N")
+    d_a = torch.from_numpy(a).cuda()
+    d_p = torch.zeros((n + 3) // 4 + 64, dtype=torch.uint8, device="cuda")
+    d_m = torch.zeros((n + 7) // 8 + 64, dtype=torch.uint8, device="cuda")
+    sm._check(sm.lib().mm_pack_ascii_n_device_async(gpu.h, C.c_void_p(d_a.data_ptr()), n,
+                                                    C.c_void_p(d_p.data_ptr()), C.c_void_p(d_m.data_ptr())))
+    gpu.sync()
+    packed, amb = oracle.pack_ascii_n(a.tobytes())
+    assert np.array_equal(d_p[: (n + 3) // 4].cpu().numpy(), packed[: (n + 3) // 4])
+    assert np.array_equal(d_m[: (n + 7) // 8].cpu().numpy(), amb[: (n + 7) // 8])
+    want = oracle.run_skip_ambiguous(packed, amb, n, k, w, mode=mode)
+    b = sm.Builder(k, w, True, mode)
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    c = b.run_skip_ambiguous_device(d_p, d_m, n, out)
+    assert gpu.last_path() == (sm.PATH_GENERIC if w == 18 else sm.PATH_FUSED)
+    assert np.array_equal(out[:c].cpu().numpy().view(np.uint32), want)
+    # window-range shards concatenate to the whole (seam rule for minimizers: drop an equal head)
+    nw = n - (k + w - 1) + 1
+    cuts = [0, nw // 3 + 5, 2 * nw // 3 - 7, nw]
+    parts = []
+    for s, e in zip(cuts[:-1], cuts[1:]):
+        cc = b.run_skip_ambiguous_device(d_p, d_m, n, out, win_begin=s, win_end=e)
+        part = out[:cc].cpu().numpy().view(np.uint32)
+        if mode == 0 and parts and len(part) and len(parts[-1]) and part[0] == parts[-1][-1]:
+            part = part[1:]
+        parts.append(part.copy())
+    assert np.array_equal(np.concatenate(parts), want)
+    gpu.force_generic(True)
+    try:
+        c = b.run_skip_ambiguous_device(d_p, d_m, n, out)
+        assert gpu.last_path() == sm.PATH_GENERIC
+        assert np.array_equal(out[:c].cpu().numpy().view(np.uint32), want)
+    finally:
+        gpu.force_generic(False)
+
+
+def test_skip_ambiguous_reads(sm, oracle, gpu):
+    """Reads with Ns in one launch: each read equals run_skip_ambiguous_windows on that read."""
+    import torch
+    rng = np.random.default_rng(31)
+    for k, w, n_reads, stride, read_len, off in [(21, 11, 900, 151, 150, 0), (15, 5, 300, 160, 101, 3),
+                                                 (31, 19, 300, 250, 250, 1), (12, 18, 40, 150, 150, 2)]:
+        span = n_reads * stride + 64 + off
+        a = _ascii_with_n(rng, span, 0.004, False)
+        for s in rng.integers(0, span - 100, size=20):
+            a[s:s + int(rng.integers(1, 90))] = ord("N")
+        packed, amb = oracle.pack_ascii_n(a.tobytes())
+        d_p, d_m = torch.from_numpy(packed).cuda(), torch.from_numpy(amb).cuda()
+        lens = rng.integers(0, read_len + 1, size=n_reads)
+        for use_lens in (False, True):
+            d_lens = torch.from_numpy(lens.astype(np.int32)).cuda() if use_lens else None
+            out = torch.zeros(n_reads * read_len, dtype=torch.int32, device="cuda")
+            offs = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
+            total = sm.run_reads_device(sm.canonical_minimizers(k, w), d_p, n_reads, stride, read_len, out, offs,
+                                        read_lens=d_lens, base_offset=off, d_amb=d_m, amb_offset=off)
+            ho = offs.cpu().numpy()
+            hp = out[:total].cpu().numpy().view(np.uint32)
+            assert ho[-1] == total
+            for r in range(n_reads):
+                m = int(lens[r]) if use_lens else read_len
+                want = oracle.run_skip_ambiguous(packed, amb, m, k, w, base_offset=off + r * stride,
+                                                 amb_offset=off + r * stride)
+                assert np.array_equal(hp[ho[r]:ho[r + 1]], want), (k, w, r, m)
