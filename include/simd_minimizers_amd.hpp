@@ -35,6 +35,14 @@ struct PackedSeq {
     uint64_t len;
     PackedSeq slice(uint64_t b, uint64_t e) const { return PackedSeq{data, offset + b, e - b}; }
 };
+// packed-seq PackedNSeq: a PackedSeq plus one ambiguity bit per base (bit (amb_offset+i)%8 of byte
+// (amb_offset+i)/8 of `amb`)
+struct PackedNSeq {
+    PackedSeq seq;
+    const uint8_t *amb;
+    uint64_t amb_offset;
+    PackedNSeq slice(uint64_t b, uint64_t e) const { return PackedNSeq{seq.slice(b, e), amb, amb_offset + b}; }
+};
 // packed-seq AsciiSeq: ACTG / actg characters
 struct AsciiSeq {
     const uint8_t *data;
@@ -126,6 +134,31 @@ class Builder {  // src/lib.rs:225-230
         min_pos.insert(min_pos.end(), pos.begin() + first, pos.begin() + n);
         if (sk_) sk_->insert(sk_->end(), sk.begin() + first, sk.begin() + n);
         return Output<CANONICAL>(SYNCMER ? k_ + w_ - 1 : k_, seq, &min_pos, &ws);
+    }
+    // src/lib.rs:451-496: canonical builders only; windows with an ambiguous base are skipped
+    Output<CANONICAL> run_skip_ambiguous_windows(PackedNSeq nseq, std::vector<uint32_t> &min_pos) const {
+        static_assert(CANONICAL, "run_skip_ambiguous_windows() is only defined for canonical builders");
+        Workspace &ws = ws_ ? *ws_ : Workspace::thread_default();
+        mm_plan_t *plan = nullptr;
+        check(mm_plan_create(&plan, k_, w_, CANONICAL, (mm_mode_t)SYNCMER, has_hasher_ ? &hasher_ : nullptr));
+        const uint64_t l = (uint64_t)k_ + w_ - 1;
+        const uint64_t cap = nseq.seq.len >= l ? nseq.seq.len - l + 1 : 0;
+        std::vector<uint32_t> pos(cap ? cap : 1);
+        uint64_t n = 0;
+        int r = mm_run_skip_ambiguous_host(plan, ws.get(), nseq.seq.data, nseq.seq.offset, nseq.amb,
+                                           nseq.amb_offset, nseq.seq.len, pos.data(), cap, &n);
+        mm_plan_destroy(plan);
+        check(r);
+        size_t first = 0;
+        if (SYNCMER == 0)
+            while (first < n && !min_pos.empty() && pos[first] == min_pos.back()) ++first;
+        min_pos.insert(min_pos.end(), pos.begin() + first, pos.begin() + n);
+        return Output<CANONICAL>(SYNCMER ? k_ + w_ - 1 : k_, nseq.seq, &min_pos, &ws);
+    }
+    std::vector<uint32_t> run_skip_ambiguous_windows_once(PackedNSeq nseq) const {
+        std::vector<uint32_t> v;
+        run_skip_ambiguous_windows(nseq, v);
+        return v;
     }
     std::vector<uint32_t> run_once(PackedSeq seq) const {  // src/lib.rs:364
         std::vector<uint32_t> v;

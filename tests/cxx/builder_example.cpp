@@ -42,6 +42,21 @@ int main() {
     } catch (const Error &e) {
         if (e.code != MM_ERR_EVEN_L) return 7;
     }
+    // skip-ambiguous windows (src/test.rs:428-482): no k-mer at an output position holds an N
+    {
+        const char *nseq_ascii = "ACGTGCTCAGNGACTCAGAGGATTACAGCTAGCTANCGATCGATTTAGC";
+        const size_t n = strlen(nseq_ascii);
+        auto pk = pack(nseq_ascii);
+        std::vector<uint8_t> amb((n + 7) / 8 + 16, 0);
+        for (size_t i = 0; i < n; ++i)
+            if (nseq_ascii[i] == 'N') amb[i / 8] |= (uint8_t)(1u << (i % 8));
+        auto p = canonical_minimizers(5, 7).run_skip_ambiguous_windows_once(
+            PackedNSeq{PackedSeq{pk.data(), 0, n}, amb.data(), 0});
+        if (p.empty()) return 8;
+        for (uint32_t x : p)
+            for (uint32_t j = 0; j < 5; ++j)
+                if (nseq_ascii[x + j] == 'N') return 9;
+    }
     printf("builder_example ok\n");
     return 0;
 }
