@@ -426,26 +426,9 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
             if (r) return r;
             a.wamb = ws->wamb;
         }
-        const bool fused = !ws->force_generic &&
-                           mm::fused_supported(plan->k, plan->w, plan->canonical_windows,
-                                               (int)plan->ht.canonical);
-        uint64_t need_status;
-        if (fused) {
-            need_status = mm::fused_status_words(a);
-        } else {
-            const uint64_t nwin = win_end - win_begin;
-            a.generic_round_windows = nwin < (1ull << 24) ? nwin : (1ull << 24);
-            need_status = mm::generic_status_words(a.generic_round_windows);
-            uint64_t need_scratch = mm::generic_scratch_bytes(a.generic_round_windows, plan->w);
-            uint8_t *sp = reinterpret_cast<uint8_t *>(ws->scratch);
-            r = grow(sp, ws->scratch_bytes, need_scratch, 1);
-            ws->scratch = sp;
-            if (r) return r;
-            a.scratch = ws->scratch;
-        }
-        r = grow(ws->status, ws->status_words, need_status, sizeof(unsigned long long));
-        if (r) return r;
-        a.out.status = ws->status;
+        bool fused = !ws->force_generic &&
+                     mm::fused_supported(plan->k, plan->w, plan->canonical_windows,
+                                         (int)plan->ht.canonical);
         if (ws->timing) {
             hipEvent_t e0, e1;
             MM_HIP(hipEventCreate(&e0));
@@ -454,7 +437,34 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
             a.timing_start = e0;
             a.timing_stop = e1;
         }
-        int lr = fused ? mm::launch_fused(a, ws->stream) : mm::launch_generic(a, ws->stream);
+        int lr = 0;
+        if (fused) {
+            r = grow(ws->status, ws->status_words, mm::fused_status_words(a), sizeof(unsigned long long));
+            if (r) return r;
+            a.out.status = ws->status;
+            lr = mm::launch_fused(a, ws->stream);
+            if (lr == -2) {
+                // no prebuilt instance and the run-time specialisation is unavailable: generic family
+                g_last_error = std::string("fused kernel unavailable, generic family used: ") +
+                               mm::fused_unavailable_reason();
+                fused = false;
+            }
+        }
+        if (!fused) {
+            const uint64_t nwin = win_end - win_begin;
+            a.generic_round_windows = nwin < (1ull << 24) ? nwin : (1ull << 24);
+            uint64_t need_scratch = mm::generic_scratch_bytes(a.generic_round_windows, plan->w);
+            uint8_t *sp = reinterpret_cast<uint8_t *>(ws->scratch);
+            r = grow(sp, ws->scratch_bytes, need_scratch, 1);
+            ws->scratch = sp;
+            if (r) return r;
+            a.scratch = ws->scratch;
+            r = grow(ws->status, ws->status_words, mm::generic_status_words(a.generic_round_windows),
+                     sizeof(unsigned long long));
+            if (r) return r;
+            a.out.status = ws->status;
+            lr = mm::launch_generic(a, ws->stream);
+        }
         if (lr != 0) {
             g_last_error = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
             return MM_ERR_HIP;

@@ -8,6 +8,7 @@
 #include "mm_launch.h"
 
 #include <cstdlib>
+#include <string>
 
 namespace mm {
 
@@ -53,38 +54,99 @@ struct Geometry {
     uint64_t nblocks;
 };
 
+constexpr uint32_t kMaxLdsBytes = 159u * 1024u;  // 160 KB per CU minus the static tables
+
 Geometry geometry(const RunArgs &a) {
     Geometry g;
     g.nblk = legal_nblk(a.w, a.mode, a.nblk);
-    g.S = a.w * g.nblk;
+    const uint32_t lists = (a.out.sk && a.mode == 0) ? 2u : 1u;
+    for (;;) {
+        g.S = a.w * g.nblk;
+        // Lane list capacity: 1.3 x the expected number of emitted windows + 8 (> 5 sigma on random
+        // sequence; denser tiles take the in-kernel redo path) + one W-block of head-room, because
+        // the kernel checks the remaining room once per W-block.
+        uint32_t cap = (uint32_t)(1.3 * emit_density(a.w, a.mode) * g.S) + 8u + a.w;
+        if (cap > g.S + a.w) cap = g.S + a.w;
+        g.list_cap = cap;
+        g.lds_bytes = cap * kListStride * lists;
+        // large w (run-time specialised kernels): shorten the lanes until the lists fit the LDS
+        if (g.lds_bytes <= kMaxLdsBytes || g.nblk == 1) break;
+        g.nblk = g.nblk > 2 ? g.nblk * 3 / 4 : 1;
+    }
     g.NB = kFusedThreads * g.S;
-    // Lane list capacity: 1.3 x the expected number of emitted windows + 8 (> 5 sigma on random
-    // sequence; denser tiles take the in-kernel redo path) + one W-block of head-room, because
-    // the kernel checks the remaining room once per W-block.
-    uint32_t cap = (uint32_t)(1.3 * emit_density(a.w, a.mode) * g.S) + 8u + a.w;
-    if (cap > g.S + a.w) cap = g.S + a.w;
-    g.list_cap = cap;
-    g.lds_bytes = cap * kListStride * ((a.out.sk && a.mode == 0) ? 2u : 1u);
     const uint64_t nwin = a.win_end - a.win_begin;
     g.nblocks = (nwin + g.NB - 1) / g.NB;
     return g;
 }
 
+// A kernel to launch: a prebuilt instance (host symbol) or a run-time specialisation (module
+// function, mm_jit.hip).
+struct KernelRef {
+    KernelFn host = nullptr;
+    hipFunction_t mod = nullptr;
+    explicit operator bool() const { return host || mod; }
+};
+
+thread_local std::string t_jit_error;
+
+KernelRef resolve_kernel(uint32_t w, int canonical_windows, int hasher_canonical, uint32_t mode, bool sk) {
+    KernelRef kr;
+    if (mode > 2) return kr;
+    if (const Instance *inst = find_instance(w, canonical_windows, hasher_canonical)) {
+        kr.host = inst->fn[(mode == 0 && sk) ? 3 : mode];
+        return kr;
+    }
+    kr.mod = jit_fused_kernel(w, canonical_windows != 0, hasher_canonical != 0, (int)mode, mode == 0 && sk,
+                              false, &t_jit_error);
+    return kr;
+}
+
+int launch_kernel(const KernelRef &kr, uint32_t grid, uint32_t lds_bytes, hipStream_t stream, FusedParams &p,
+                  hipEvent_t ev0, hipEvent_t ev1) {
+    if (kr.host) {
+        if (lds_bytes > 64u * 1024u &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kr.host),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return -1;
+        if (ev0) hipEventRecord(ev0, stream);
+        hipLaunchKernelGGL(kr.host, dim3(grid), dim3(kFusedThreads), lds_bytes, stream, p);
+        if (ev1) hipEventRecord(ev1, stream);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    if (lds_bytes > 64u * 1024u)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kr.mod),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    (void)hipGetLastError();
+    void *args[] = {&p};
+    if (ev0) hipEventRecord(ev0, stream);
+    const hipError_t e = hipModuleLaunchKernel(kr.mod, grid, 1, 1, kFusedThreads, 1, 1, lds_bytes, stream, args,
+                                               nullptr);
+    if (ev1) hipEventRecord(ev1, stream);
+    return e == hipSuccess ? 0 : -1;
+}
+
 }  // namespace
 
+const char *fused_unavailable_reason() { return t_jit_error.c_str(); }
+
+// True when launch_fused can be attempted: a prebuilt instance exists, or the window size is in
+// the range of the run-time specialisation (the compile itself happens at the first launch; if it
+// fails launch_fused returns -2 and the caller takes the generic family).
 bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_canonical) {
     (void)k;
-    return find_instance(w, canonical_windows, hasher_canonical) != nullptr;
+    if (find_instance(w, canonical_windows, hasher_canonical)) return true;
+    return jit_enabled() && w >= 1 && w <= kJitMaxW;
 }
 
 uint64_t fused_status_words(const RunArgs &a) { return geometry(a).nblocks + 1; }
 
 int launch_fused(const RunArgs &a, hipStream_t stream) {
-    const Instance *inst = find_instance(a.w, a.canonical_windows, (int)a.ht.canonical);
-    if (!inst) return -2;
     const Geometry g = geometry(a);
     if (g.nblocks == 0) return 0;
-    if (g.lds_bytes > 159u * 1024u) return -3;
+    if (g.lds_bytes > kMaxLdsBytes) return -2;
+    const KernelRef kr = resolve_kernel(a.w, a.canonical_windows, (int)a.ht.canonical, a.mode,
+                                        a.out.sk != nullptr);
+    if (!kr) return -2;
 
     FusedParams p;
     p.seq = a.seq;
@@ -106,22 +168,10 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         const char *dbg = getenv("MM_DEBUG");
         p.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
     }
-    if (a.mode > 2) return -2;
-    KernelFn fn = inst->fn[(a.mode == 0 && a.out.sk) ? 3 : a.mode];
-
-    if (g.lds_bytes > 64u * 1024u) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)g.lds_bytes) != hipSuccess)
-            return -1;
-    }
     if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * g.nblocks, stream) != hipSuccess)
         return -1;
     if (hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
-    if (a.timing_start) hipEventRecord(a.timing_start, stream);
-    hipLaunchKernelGGL(fn, dim3((uint32_t)g.nblocks), dim3(kFusedThreads), g.lds_bytes, stream, p);
-    if (a.timing_stop) hipEventRecord(a.timing_stop, stream);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_kernel(kr, (uint32_t)g.nblocks, g.lds_bytes, stream, p, a.timing_start, a.timing_stop);
 }
 
 // ------------------------------------------------------------------ reads mode
@@ -143,7 +193,8 @@ const FusedReadsInstance *find_reads_instance(uint32_t w, int canonical_windows,
 }  // namespace
 
 bool fused_reads_supported(uint32_t w, int canonical_windows, int hasher_canonical) {
-    return find_reads_instance(w, canonical_windows, hasher_canonical) != nullptr;
+    if (find_reads_instance(w, canonical_windows, hasher_canonical)) return true;
+    return jit_enabled() && w >= 1 && w <= kJitMaxW;
 }
 
 uint64_t fused_reads_status_words(const ReadsArgs &a) {
@@ -151,8 +202,6 @@ uint64_t fused_reads_status_words(const ReadsArgs &a) {
 }
 
 int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
-    const FusedReadsInstance *inst = find_reads_instance(a.w, a.canonical_windows, (int)a.ht.canonical);
-    if (!inst) return -2;
     if (a.n_reads == 0) return 0;
     const uint32_t l = a.k + a.w - 1;
     const uint32_t max_nw = a.read_len >= l ? a.read_len - l + 1 : 1;
@@ -164,6 +213,13 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     const uint32_t lds_bytes = cap * kListStride;
     if (lds_bytes > 159u * 1024u) return -3;
     const uint64_t nblocks = (a.n_reads + kFusedThreads - 1) / kFusedThreads;
+    KernelRef kr;
+    if (const FusedReadsInstance *inst = find_reads_instance(a.w, a.canonical_windows, (int)a.ht.canonical))
+        kr.host = inst->fn;
+    else
+        kr.mod = jit_fused_kernel(a.w, a.canonical_windows != 0, a.ht.canonical != 0, 0, false, true,
+                                  &t_jit_error);
+    if (!kr) return -2;
 
     FusedParams p;
     p.seq = a.seq;
@@ -182,17 +238,9 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.wamb = a.wamb;
     p.wamb_dwords = a.wamb_dwords;
     p.out = a.out;
-    if (lds_bytes > 64u * 1024u) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(inst->fn),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return -1;
-    }
     if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * nblocks, stream) != hipSuccess) return -1;
     if (hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
-    if (a.timing_start) hipEventRecord(a.timing_start, stream);
-    hipLaunchKernelGGL(inst->fn, dim3((uint32_t)nblocks), dim3(kFusedThreads), lds_bytes, stream, p);
-    if (a.timing_stop) hipEventRecord(a.timing_stop, stream);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_kernel(kr, (uint32_t)nblocks, lds_bytes, stream, p, a.timing_start, a.timing_stop);
 }
 
 }  // namespace mm

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 #include "mm_common.h"
 
 namespace mm {
@@ -31,7 +33,10 @@ struct RunArgs {
 // ---- fused family (mm_fused_*.hip): one kernel, specialised per w
 bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_canonical);
 uint64_t fused_status_words(const RunArgs &a);
+// returns 0, -1 (HIP failure) or -2 (no kernel for this plan: take the generic family;
+// fused_unavailable_reason() says why)
 int launch_fused(const RunArgs &a, hipStream_t stream);
+const char *fused_unavailable_reason();
 
 // ---- reads mode of the fused family: a batch of short reads at a fixed stride, one lane per read
 struct ReadsArgs {
@@ -53,6 +58,12 @@ bool fused_reads_supported(uint32_t w, int canonical_windows, int hasher_canonic
 uint64_t fused_reads_status_words(const ReadsArgs &a);
 // returns 0, -1 (HIP failure), -2 (no instance), -3 (reads too long for the LDS lists)
 int launch_fused_reads(const ReadsArgs &a, hipStream_t stream);
+
+// ---- run-time specialisation (mm_jit.hip): window sizes without a prebuilt instance
+constexpr uint32_t kJitMaxW = 128;  // ring registers: 256 VGPRs + AGPRs still hold W = 128 without scratch
+bool jit_enabled();                 // MM_JIT=0 switches it off (then such w take the generic family)
+hipFunction_t jit_fused_kernel(uint32_t w, bool canon, bool hash_rc, int mode, bool sk, bool reads,
+                               std::string *err);
 
 // ---- generic family (mm_generic.hip): any k / w
 uint64_t generic_scratch_bytes(uint64_t round_windows, uint32_t w);

@@ -176,6 +176,29 @@ def test_revcomp_metamorphic(sm, oracle, gpu):
                 assert np.array_equal(fv, rv[::-1])
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_revcomp_metamorphic_syncmers(sm, oracle, gpu, mode):
+    """src/test.rs:642-711 (canonical_syncmers_positions_and_values): canonical closed / open syncmers
+    of a sequence and of its reverse complement mirror each other: pos_fwd[i] + pos_rc[-1-i] ==
+    len - (k+w-1), and the l-mer values are equal in reverse order (l <= 32)."""
+    rng = np.random.default_rng(6)
+    for k, w in [(5, 7), (3, 5), (15, 17), (11, 11), (9, 23), (1, 1), (25, 7)]:
+        l = k + w - 1
+        assert l % 2 == 1 and l <= 32 and w % 2 == 1
+        for n in (0, 31, 50, 200, 4097):
+            ps = sm.PackedSeqVec.random(n, seed=int(rng.integers(1 << 30)))
+            rc = ps.to_revcomp()
+            b = sm.Builder(k, w, True, mode)
+            fp: list = []
+            rp: list = []
+            fv = b.run(ps, fp).values_u64()
+            rv = b.run(rc, rp).values_u64()
+            assert len(fp) == len(rp), (k, w, n)
+            for x, y in zip(fp, reversed(rp)):
+                assert x + y == n - l, (k, w, n, x, y)
+            assert np.array_equal(fv, rv[::-1])
+
+
 def test_append_semantics(sm, gpu):
     """`run` appends; a leading duplicate of out_vec.last() is dropped (src/collect.rs:265-271)."""
     ps = sm.PackedSeqVec.from_ascii(b"ACGTGCTCAGAGACTCAGAGGA")
@@ -582,10 +605,18 @@ def test_reads_mode(sm, oracle, gpu):
         _check_reads(sm, oracle, k, w, canonical, 0, n_reads, 304, 300, lens, 5, 6)
     # plans without a reads-mode instance take one launch per read: same results
     _check_reads(sm, oracle, 15, 17, True, 1, 40, 150, 150, None, 2, 7)   # closed syncmers
-    _check_reads(sm, oracle, 12, 18, True, 0, 40, 150, 149, None, 0, 8)   # w without an instance
-    assert gpu.last_path() == 2
-    lens = rng.integers(0, 200, size=30)
-    _check_reads(sm, oracle, 12, 18, True, 0, 30, 200, 199, lens, 1, 9)
+    # a w without a prebuilt instance: specialised at run time (one launch) or, with MM_JIT=0, one
+    # launch per read through the generic family
+    _check_reads(sm, oracle, 12, 18, True, 0, 40, 150, 149, None, 0, 8)
+    assert gpu.last_path() == 1
+    os.environ["MM_JIT"] = "0"
+    try:
+        _check_reads(sm, oracle, 12, 18, True, 0, 40, 150, 149, None, 0, 8)
+        assert gpu.last_path() == 2
+        lens = rng.integers(0, 200, size=30)
+        _check_reads(sm, oracle, 12, 18, True, 0, 30, 200, 199, lens, 1, 9)
+    finally:
+        del os.environ["MM_JIT"]
     # every window size with an instance
     for canonical in (True, False):
         for w in FUSED_W_ALL:
@@ -693,7 +724,7 @@ def test_skip_ambiguous_large_device(sm, oracle, gpu, k, w, mode):
     b = sm.Builder(k, w, True, mode)
     out = torch.zeros(n, dtype=torch.int32, device="cuda")
     c = b.run_skip_ambiguous_device(d_p, d_m, n, out)
-    assert gpu.last_path() == (sm.PATH_GENERIC if w == 18 else sm.PATH_FUSED)
+    assert gpu.last_path() == sm.PATH_FUSED  # w = 18: specialised at run time
     assert np.array_equal(out[:c].cpu().numpy().view(np.uint32), want)
     # window-range shards concatenate to the whole (a shard dedups against the window before it)
     nw = n - (k + w - 1) + 1
@@ -739,3 +770,50 @@ def test_skip_ambiguous_reads(sm, oracle, gpu):
                 want = oracle.run_skip_ambiguous(packed, amb, m, k, w, base_offset=off + r * stride,
                                                  amb_offset=off + r * stride)
                 assert np.array_equal(hp[ho[r]:ho[r + 1]], want), (k, w, r, m)
+
+
+# ------------------------------------------------- run-time specialisation (any w <= 128)
+@pytest.mark.parametrize("k,w,canonical", [(12, 18, True), (21, 20, False), (31, 35, True), (14, 64, True),
+                                            (16, 100, True), (9, 128, False)])
+def test_runtime_specialised_window_sizes(sm, oracle, gpu, k, w, canonical):
+    """Window sizes without a prebuilt instance run the same fused kernel, compiled with hiprtc at
+    first use (mm_jit.hip): minimizers, super-k-mers, syncmers, window ranges, reads mode — all
+    against the oracle; with MM_JIT=0 the generic family gives the same answers."""
+    import torch
+    n = 300_011
+    data = oracle.gen_packed(40 + w, n)
+    ps = sm.PackedSeq(data, 0, n)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    sk = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for mode in (0, 1, 2):
+        if mode == 2 and w % 2 == 0:
+            continue
+        want = oracle.run(data, n, k, w, canonical=canonical, mode=mode)
+        b = sm.Builder(k, w, canonical, mode)
+        c = b.run_device(d, n, out)
+        assert gpu.last_path() == sm.PATH_FUSED, sm.lib().mm_last_error()
+        assert np.array_equal(out[:c].cpu().numpy().view(np.uint32), want), (k, w, mode)
+        os.environ["MM_JIT"] = "0"
+        try:
+            c = b.run_device(d, n, out)
+            assert gpu.last_path() == sm.PATH_GENERIC
+            assert np.array_equal(out[:c].cpu().numpy().view(np.uint32), want), (k, w, mode, "generic")
+        finally:
+            del os.environ["MM_JIT"]
+    # super-k-mers and a window range
+    want, wsk = oracle.run(data, n, k, w, canonical=canonical, super_kmers=True)
+    b = sm.Builder(k, w, canonical, 0)
+    c = b.run_device(d, n, out, out_sk=sk)
+    assert gpu.last_path() == sm.PATH_FUSED
+    assert np.array_equal(out[:c].cpu().numpy().view(np.uint32), want)
+    assert np.array_equal(sk[:c].cpu().numpy().view(np.uint32), wsk)
+    nw = n - (k + w - 1) + 1
+    parts = []
+    for s0, s1 in [(0, nw // 2 + 3), (nw // 2 + 3, nw)]:
+        cc = b.run_device(d, n, out, win_begin=s0, win_end=s1)
+        parts.append(out[:cc].cpu().numpy().view(np.uint32).copy())
+    assert np.array_equal(np.concatenate(parts), want)
+    # reads mode
+    _check_reads(sm, oracle, k, w, canonical, 0, 300, 400, 397, None, 1, 60 + w)
+    assert gpu.last_path() == sm.PATH_FUSED
