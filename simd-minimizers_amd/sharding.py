@@ -73,3 +73,55 @@ def run_sharded(compute: Callable[[int, int], np.ndarray], n_windows: int, group
         if rank == gather_to:
             gathered = np.concatenate([p[:c].cpu().numpy().view(np.uint32) for p, c in zip(parts, counts)])
     return local, counts, gathered
+
+
+def run_contigs_sharded(compute_contig: Callable[[int], np.ndarray], lengths: Sequence[int], group=None,
+                        gather_to: int | None = None):
+    """Independent sequences (contigs) spread over ranks, greedy longest first (SURVEY.md §8d config 4:
+    the reference calls ``run`` once per sequence, bench/src/bin/paper.rs:410-431, so positions are
+    contig-local).
+
+    ``compute_contig(i)`` produces contig i's positions on this rank (on the GPU box it wraps
+    ``run_batch_device`` / ``Builder.run_device``).  Returns ``(mine, local, counts, gathered)``:
+    the contig indices of this rank, their positions, the per-contig counts of ALL contigs
+    (all-gather of one int64 per contig — the only collective the path needs), and on rank
+    ``gather_to`` the list of per-contig position arrays in contig order (None elsewhere).
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    placement = assign_contigs(lengths, world)
+    mine = placement[rank]
+    local = [np.ascontiguousarray(compute_contig(i), dtype=np.uint32) for i in mine]
+    n = len(lengths)
+    counts = np.zeros(n, dtype=np.int64)
+    for i, p in zip(mine, local):
+        counts[i] = len(p)
+    if world == 1:
+        return mine, local, counts.tolist(), (local if gather_to == 0 else None)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    ct = torch.from_numpy(counts).to(dev)
+    dist.all_reduce(ct, op=dist.ReduceOp.SUM, group=group)  # disjoint supports: sum == gather
+    counts = ct.cpu().numpy()
+    gathered = None
+    if gather_to is not None:
+        per_rank = [int(sum(counts[i] for i in placement[r])) for r in range(world)]
+        m = max(per_rank) if per_rank else 0
+        buf = torch.zeros(max(m, 1), dtype=torch.int32, device=dev)
+        if local:
+            cat = np.concatenate(local) if sum(len(p) for p in local) else np.zeros(0, dtype=np.uint32)
+            buf[: len(cat)] = torch.from_numpy(cat.view(np.int32)).to(dev)
+        parts = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf, group=group)
+        if rank == gather_to:
+            gathered = [None] * n
+            for r in range(world):
+                flat = parts[r].cpu().numpy().view(np.uint32)
+                off = 0
+                for i in placement[r]:
+                    gathered[i] = flat[off: off + int(counts[i])].copy()
+                    off += int(counts[i])
+    return mine, local, counts.tolist(), gathered

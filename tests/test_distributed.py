@@ -72,3 +72,42 @@ def test_shard_helpers():
     assert sorted(i for lst in a for i in lst) == list(range(12))
     loads = [sum([248, 242, 201, 193, 182, 172, 160, 146, 150, 134, 135, 133][i] for i in lst) for lst in a]
     assert max(loads) - min(loads) < 60
+
+
+def _contig_worker(rank, world, port, lengths, k, w, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mm_oracle as o
+    from simd_minimizers_amd import sharding
+
+    def compute_contig(i):
+        return o.run(o.gen_packed(100 + i, max(1, lengths[i])), lengths[i], k, w, canonical=True)
+
+    mine, local, counts, gathered = sharding.run_contigs_sharded(compute_contig, lengths, gather_to=0)
+    if rank == 0:
+        ok = all(np.array_equal(gathered[i], compute_contig(i)) for i in range(len(lengths)))
+        q.put((mine, counts, ok))
+    dist.destroy_process_group()
+
+
+def test_two_rank_contig_sharding():
+    """Config 4's shape: contigs placed greedily on ranks, contig-local positions, counts exchanged,
+    positions gathered to a root in contig order."""
+    lengths = [5003, 40, 12001, 0, 777, 9000, 31, 2500]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + 211
+    procs = [ctx.Process(target=_contig_worker, args=(r, 2, port, lengths, 31, 51, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    mine, counts, ok = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ok and len(counts) == len(lengths) and counts[3] == 0 and counts[1] == 0 and counts[0] > 0
+    assert 0 < len(mine) < len(lengths)
