@@ -72,8 +72,9 @@ def cpu_baseline():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=20,
+                    help="untimed steps; the GPU needs about a dozen 2 ms launches after idle to reach steady clocks")
     ap.add_argument("--bases", type=int, default=N_BASES, help="bases per GPU (default: 3.1 Gbp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -10,6 +10,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef MM_LB_FIRST
+#define MM_LB_FIRST 1  // 64-status chunks of the first look-back hop (1 measured best; then 4, 16)
+#endif
+
 namespace mm {
 
 constexpr int kBlockThreads = 256;
@@ -110,36 +114,47 @@ __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long l
         return carry_in;
     }
     if (lane == 0) st_status(&status[bid], kFlagAgg | (block_total & kValMask));
+    // Look back over 64, then 256, then 1024 predecessors per hop (all loads of a hop in flight
+    // together): when many tiles finish at about the same time none of the nearest ones has its
+    // inclusive prefix yet, and one 64-wide hop per memory round trip would serialise the scan.
     unsigned long long excl = 0;
     long long j = (long long)bid - 1;
+    int chunks = MM_LB_FIRST;
     while (true) {
-        long long idx = j - lane;
-        unsigned long long s;
-        if (idx >= 0) {
-            s = ld_status(&status[idx]);
-            // bounded: a predecessor that never shows up (dispatch-order violation) must not
-            // hang the GPU; the launch is then reported as failed and redone in ticket mode
-            for (uint32_t spins = 0; (s >> 62) == 0; ++spins) {
-                if (spins > kMaxLookbackSpins) {
-                    *error = 1u;
-                    s = kFlagIncl;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-                s = ld_status(&status[idx]);
-            }
-        } else {
-            s = kFlagIncl;  // virtual predecessor of block 0 (never reached: block 0 is inclusive)
-        }
-        unsigned long long incl_mask = __ballot((s >> 62) == 2);
-        int first = incl_mask ? __builtin_ctzll(incl_mask) : kWave;
-        unsigned long long v = (lane <= first) ? (s & kValMask) : 0ull;
-        // wave reduce (64-bit)
+        unsigned long long s[16];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
-        excl += v;
-        if (incl_mask) break;
-        j -= kWave;
+        for (int c = 0; c < 16; ++c) {
+            const long long idx = j - 64ll * c - lane;
+            s[c] = (c < chunks && idx >= 0) ? ld_status(&status[idx]) : kFlagIncl;
+        }
+        bool done = false;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < chunks && !done) {
+                const long long idx = j - 64ll * c - lane;
+                // bounded: a predecessor that never shows up (dispatch-order violation) must not
+                // hang the GPU; the launch is then reported as failed and redone in ticket mode
+                for (uint32_t spins = 0; (s[c] >> 62) == 0; ++spins) {
+                    if (spins > kMaxLookbackSpins) {
+                        *error = 1u;
+                        s[c] = kFlagIncl;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    s[c] = ld_status(&status[idx]);
+                }
+                const unsigned long long incl_mask = __ballot((s[c] >> 62) == 2);
+                const int first = incl_mask ? __builtin_ctzll(incl_mask) : kWave;
+                unsigned long long v = (lane <= first) ? (s[c] & kValMask) : 0ull;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);  // wave reduce (64-bit)
+                excl += v;
+                if (incl_mask) done = true;
+            }
+        }
+        if (done) break;
+        j -= 64ll * chunks;
+        chunks = chunks >= 4 ? 16 : chunks * 4;
     }
     if (lane == 0) st_status(&status[bid], kFlagIncl | ((excl + block_total) & kValMask));
     return excl;

@@ -8,7 +8,9 @@
 #include "mm_launch.h"
 
 #include <cstdlib>
+#include <cstdio>
 #include <string>
+#include <vector>
 
 namespace mm {
 
@@ -54,6 +56,7 @@ struct Geometry {
     uint64_t nblocks;
 };
 
+
 constexpr uint32_t kMaxLdsBytes = 159u * 1024u;  // 160 KB per CU minus the static tables
 
 Geometry geometry(const RunArgs &a) {
@@ -92,7 +95,9 @@ thread_local std::string t_jit_error;
 KernelRef resolve_kernel(uint32_t w, int canonical_windows, int hasher_canonical, uint32_t mode, bool sk) {
     KernelRef kr;
     if (mode > 2) return kr;
-    if (const Instance *inst = find_instance(w, canonical_windows, hasher_canonical)) {
+    const bool force_jit = getenv("MM_JIT_FORCE") != nullptr;  // tuning experiments
+    const Instance *inst = force_jit ? nullptr : find_instance(w, canonical_windows, hasher_canonical);
+    if (inst) {
         kr.host = inst->fn[(mode == 0 && sk) ? 3 : mode];
         return kr;
     }
@@ -171,6 +176,25 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * g.nblocks, stream) != hipSuccess)
         return -1;
     if (hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
+    p.trace = nullptr;
+    if (const char *tr = getenv("MM_TRACE")) {
+        // timing experiment: per-tile timestamps dumped to the file MM_TRACE (synchronous)
+        unsigned long long *d_tr = nullptr;
+        const size_t bytes = sizeof(unsigned long long) * 6 * g.nblocks;
+        if (hipMalloc(reinterpret_cast<void **>(&d_tr), bytes) != hipSuccess) return -1;
+        hipMemsetAsync(d_tr, 0, bytes, stream);
+        p.trace = d_tr;
+        int r = launch_kernel(kr, (uint32_t)g.nblocks, g.lds_bytes, stream, p, a.timing_start, a.timing_stop);
+        hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h(6 * g.nblocks);
+        hipMemcpy(h.data(), d_tr, bytes, hipMemcpyDeviceToHost);
+        hipFree(d_tr);
+        if (FILE *f = fopen(tr, "wb")) {
+            fwrite(h.data(), 1, bytes, f);
+            fclose(f);
+        }
+        return r;
+    }
     return launch_kernel(kr, (uint32_t)g.nblocks, g.lds_bytes, stream, p, a.timing_start, a.timing_stop);
 }
 
@@ -237,6 +261,7 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.read_offsets = a.read_offsets;
     p.wamb = a.wamb;
     p.wamb_dwords = a.wamb_dwords;
+    p.trace = nullptr;
     p.out = a.out;
     if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * nblocks, stream) != hipSuccess) return -1;
     if (hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;

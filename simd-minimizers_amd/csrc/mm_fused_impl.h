@@ -27,6 +27,13 @@
 #pragma once
 #include "mm_common.h"
 
+#ifndef MM_STORE_AUX
+#define MM_STORE_AUX 2  // cache policy bits of the copy-out stores: slc (streaming), measured +1 %
+#endif
+#ifndef MM_PREFETCH_BLOCKS
+#define MM_PREFETCH_BLOCKS 2
+#endif
+
 namespace mm {
 
 // Byte distance between consecutive entries of one lane's list: 258 u16 slots per plane
@@ -55,6 +62,8 @@ struct FusedParams {
     // starts at base g (relative to the first base of the sequence / buffer span) is skipped
     const uint32_t *wamb;               // null for a plain PackedSeq
     uint32_t wamb_dwords;
+    // timing experiments (MM_TRACE): 4 timestamps per tile (start, phase 1 done, look-back done, end)
+    unsigned long long *trace;
     OutParams out;
 };
 
@@ -106,6 +115,7 @@ struct LaneCtx {
     uint32_t list_bytes;     // list_cap * kListStride (the super-k-mer list follows at +list_bytes)
     unsigned long long dst;  // first output slot of this lane (DIRECT mode)
     uint32_t abase;          // bit of the lane's window 0 in FusedParams::wamb (AMBI walks)
+    uint32_t nblk;           // W-blocks this lane walks (tile-specific in the staggered prologue)
 };
 
 // One lane walks its S windows.  List mode: appends emitted 16-bit values to the lane's LDS
@@ -114,14 +124,18 @@ struct LaneCtx {
 template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool DIRECT, bool PARTIAL, bool AMBI = false>
 __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCtx &ctx, bool &overflowed) {
     constexpr int NSUB = (W + 15) / 16;  // 16-base view words per W-block
-    const uint32_t nblk = p.nblk;
+    const uint32_t nblk = ctx.nblk;
 
     // Element 0 of a lane is the k-mer one position before its first window (that window is the
     // dedup predecessor).  P0 = first base of the tile's element 0 in dword-array coordinates;
     // it is -1 only for the very first window of an unshifted buffer.
     const long long P0 = ctx.p0;
     const long long Q0 = P0 >> 4;
-    const long long Q0c = Q0 < 0 ? 0 : Q0;
+    // (tile-uniform; pinned to SGPRs so that the buffer descriptor below is scalar and the loads
+    // need no per-lane descriptor loop)
+    const long long Q0v = Q0 < 0 ? 0 : Q0;
+    const long long Q0c = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)Q0v >> 32)) << 32) |
+                                      __builtin_amdgcn_readfirstlane((uint32_t)Q0v));
     const int32_t prel0 = (int32_t)(P0 - (Q0c << 4));  // -1 .. 15
     // Bounds-checked view of the packed sequence from dword Q0c on: dwords past the end read as 0,
     // so the halo after the last base needs no clamping.
@@ -138,6 +152,15 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         const bool neg = pos < 0;
         const auto d = __builtin_amdgcn_raw_buffer_load_b64(rsrc, neg ? 0u : (((uint32_t)pos >> 4) << 2), 0, 0);
         return __builtin_amdgcn_alignbit(neg ? d[0] : d[1], neg ? 0u : d[0], 2u * ((uint32_t)pos & 15u));
+    };
+
+    // the same in two steps, for loads issued two W-blocks ahead of their use
+    using RawView = decltype(__builtin_amdgcn_raw_buffer_load_b64(rsrc, 0, 0, 0));
+    auto raw = [&](int32_t pos) -> RawView {
+        return __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((uint32_t)pos >> 4) << 2, 0, 0);
+    };
+    auto aligned = [&](const RawView &d, int32_t pos) -> uint32_t {
+        return __builtin_amdgcn_alignbit(d[1], d[0], 2u * ((uint32_t)pos & 15u));
     };
 
     const uint32_t rot_l = (32u - p.ht.rot) & 31u;  // alignbit amount for rotl(x, rot)
@@ -169,6 +192,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     asm volatile("v_mov_b32 %0, 0xffff0000" : "=v"(kmask));
 
     uint32_t va[NSUB], vr[NSUB], v2[NSUB];  // views of the block being processed
+    constexpr int PFD = MM_PREFETCH_BLOCKS;  // global loads run PFD W-blocks ahead of their use
+    RawView qa[PFD - 1][NSUB], qr[PFD - 1][NSUB], q2[PFD - 1][NSUB];  // raw dwords of blocks b+2 .. b+PFD
 #pragma unroll
     for (int g = 0; g < NSUB; ++g) {
         va[g] = view(pos_in + 16 * g);
@@ -193,6 +218,17 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             vr[g] = view(pos_out + 16 * g);
             if (CANON) v2[g] = view(pb + 1 + 16 * g);
         }
+        // ... and the raw dwords of block 2: global loads run two W-blocks ahead of their use, so
+        // that a burst of copy-out stores of a neighbouring workgroup in the CU's memory pipeline
+        // does not stall the walk
+#pragma unroll
+        for (int d = 0; d < PFD - 1; ++d)
+#pragma unroll
+            for (int g = 0; g < NSUB; ++g) {
+                qa[d][g] = raw(pos_in + (d + 1) * W + 16 * g);
+                qr[d][g] = raw(pos_out + (d + 1) * W + 16 * g);
+                if (CANON) q2[d][g] = raw(pb + 1 + (d + 1) * W + 16 * g);
+            }
 #pragma unroll
         for (int j = 0; j < W; ++j) {
             const uint32_t h = HASH_RC ? fw + rc : fw;
@@ -288,12 +324,22 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         pos_in += W;
         pos_out += W;
         pos_r2 += W;
-        // prefetch the views of the next block (a harmless over-read after the last block)
+        // views of the next block from the dwords loaded one block ago; issue the loads of the
+        // block after it (a harmless over-read after the last block)
 #pragma unroll
         for (int g = 0; g < NSUB; ++g) {
-            va[g] = view(pos_in + 16 * g);
-            vr[g] = view(pos_out + 16 * g);
-            if (CANON) v2[g] = view(pos_r2 + 16 * g);
+            va[g] = aligned(qa[0][g], pos_in + 16 * g);
+            vr[g] = aligned(qr[0][g], pos_out + 16 * g);
+            if (CANON) v2[g] = aligned(q2[0][g], pos_r2 + 16 * g);
+#pragma unroll
+            for (int d = 0; d + 1 < PFD - 1; ++d) {
+                qa[d][g] = qa[d + 1][g];
+                qr[d][g] = qr[d + 1][g];
+                if (CANON) q2[d][g] = q2[d + 1][g];
+            }
+            qa[PFD - 2][g] = raw(pos_in + (PFD - 1) * W + 16 * g);
+            qr[PFD - 2][g] = raw(pos_out + (PFD - 1) * W + 16 * g);
+            if (CANON) q2[PFD - 2][g] = raw(pos_r2 + (PFD - 1) * W + 16 * g);
         }
         if (AMBI) {
 #pragma unroll
@@ -480,9 +526,19 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     else if (tid < 20) s_tab[tid] = p.ht.t_in[tid - 16];
     __syncthreads();
     const uint32_t bid = __builtin_amdgcn_readfirstlane(s_bid);  // keep tile scalars in SGPRs
+    if (p.trace && tid == 0) {
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.trace[6 * (size_t)bid + 0] = wall_clock64();
+        p.trace[6 * (size_t)bid + 4] = ((unsigned long long)xcc << 32) | hw;
+    }
 
-    const uint32_t S = (uint32_t)W * p.nblk;
+    const uint32_t nblk_t = p.nblk;
+    const uint32_t S = (uint32_t)W * nblk_t;
     const uint32_t NB = kFusedThreads * S;
+    // (one 32 x 32 -> 64-bit product: stays on the scalar unit, so everything derived from the tile
+    // origin - the buffer descriptors of the sequence loads above all - lives in SGPRs)
     const uint64_t bw0 = READS ? 0ull : (uint64_t)p.win_begin + (uint64_t)bid * NB;  // first window of the tile
     const uint32_t nvalid = READS ? NB
         : (uint32_t)(((uint64_t)p.win_end - bw0) < NB ? ((uint64_t)p.win_end - bw0) : NB);
@@ -493,6 +549,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     ctx.list = smem + 2u * (uint32_t)tid;
     ctx.list_bytes = p.list_cap * kListStride;
     ctx.dst = 0;
+    ctx.nblk = nblk_t;
     bool lane_active, lane_in = false;  // lane_in: the lane owns a read (which may have no window)
     const uint32_t read0 = bid * kFusedThreads;  // READS: first read of the tile
     if (READS) {
@@ -531,10 +588,12 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     }
 
     // ---------------------------------------------------------------- phase 2
+    if (p.trace && tid == 0) p.trace[6 * (size_t)bid + 1] = wall_clock64();
     const uint32_t incl = wave_scan_dpp(my_count);
     const uint32_t wave_total = __builtin_amdgcn_readlane(incl, kWave - 1);
     if (lane == 0) s_wave_tot[wave] = wave_total;
     __syncthreads();
+    if (p.trace && tid == 0) p.trace[6 * (size_t)bid + 5] = wall_clock64();
     uint32_t wave_base = 0, block_total = 0;
 #pragma unroll
     for (int v = 0; v < kFusedWaves; ++v) {
@@ -549,6 +608,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
             (p.debug & 1u) ? (unsigned long long)bid * (NB / 6u)
                            : lookback_exclusive(p.out.status, bid, block_total, carry, p.out.error);
         if (lane == 0) s_excl = ex;
+        if (p.trace && lane == 0) p.trace[6 * (size_t)bid + 2] = wall_clock64();
     }
     __syncthreads();
     const unsigned long long run0 = s_excl + wave_base;  // first output slot of this wave
@@ -559,32 +619,67 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         // Copy the 64 lists of this wave's lanes, in lane order (= window order).  Entry c of
         // lane t sits at smem + c * kListStride + 2 * t, so lane `c` of the copying wave reads
         // entry c of list L: conflict-free, and the stores of one list are contiguous.
+        // Eight lists are in flight at a time (LDS reads first, then the stores); lanes past a
+        // list's end get an out-of-range offset, which the bounds-checked store drops.
         if (!(p.debug & 2u)) {
             const uint32_t tid0 = (uint32_t)wave * kWave;
             const uint8_t *rd = smem + (uint32_t)lane * kListStride + 2u * tid0;
             const uint32_t list_bytes = ctx.list_bytes;
             const uint32_t vb0 = (READS ? 0u : (uint32_t)bw0 + tid0 * S) - (MODE == 0 ? 1u : 0u);
-            // Output window of this wave as a bounds-checked buffer: stores past the caller's
-            // capacity are dropped by the hardware, offsets stay 32-bit.
-            const unsigned long long room = p.out.cap > run0 ? p.out.cap - run0 : 0ull;
-            const uint32_t room_bytes = room > 0x3fffffffull ? 0xfffffffcu : (uint32_t)room * 4u;
+            // Output window of this wave as a bounds-checked buffer (wave-uniform, so the
+            // descriptor lives in SGPRs): stores past the caller's capacity are dropped by the
+            // hardware, offsets stay 32-bit.
+            const uint32_t r_lo = __builtin_amdgcn_readfirstlane((uint32_t)run0);
+            const uint32_t r_hi = __builtin_amdgcn_readfirstlane((uint32_t)(run0 >> 32));
+            const unsigned long long run0_u = ((unsigned long long)r_hi << 32) | r_lo;
+            const unsigned long long room = p.out.cap > run0_u ? p.out.cap - run0_u : 0ull;
+            // (64-bit compares run on the vector unit; pin the result to an SGPR so that the per-list
+            // descriptor arithmetic below stays on the scalar unit)
+            const uint32_t room32 = __builtin_amdgcn_readfirstlane(room > 0x3fffffffull ? 0x3fffffffu : (uint32_t)room);
+            const uint32_t room_bytes = room32 * 4u;
             const __amdgpu_buffer_rsrc_t opos =
-                __builtin_amdgcn_make_buffer_rsrc(p.out.pos + run0, 0, (int)room_bytes, 0x00020000);
+                __builtin_amdgcn_make_buffer_rsrc(p.out.pos + run0_u, 0, (int)room_bytes, 0x00020000);
             const __amdgpu_buffer_rsrc_t osk = __builtin_amdgcn_make_buffer_rsrc(
-                SK ? p.out.sk + run0 : p.out.pos + run0, 0, (int)room_bytes, 0x00020000);
-#pragma unroll 4
-            for (uint32_t L = 0; L < kWave; ++L) {
-                const uint32_t n = __builtin_amdgcn_readlane(my_count, L);
-                const uint32_t off = __builtin_amdgcn_readlane(excl, L);
-                const uint32_t vb = READS ? vb0 : vb0 + L * S;
-                for (uint32_t c = lane; c < n; c += kWave) {  // n <= list_cap; usually one pass
-                    const uint8_t *q = rd + 2u * L + (c - lane) * kListStride;
-                    const uint32_t ent = *reinterpret_cast<const uint16_t *>(q);
-                    __builtin_amdgcn_raw_buffer_store_b32(vb + ent, opos, (off + c) * 4u, 0, 0);
+                SK ? p.out.sk + run0_u : p.out.pos + run0_u, 0, (int)room_bytes, 0x00020000);
+            constexpr int kBatch = 8;
+            const uint32_t store_mask =
+                __builtin_amdgcn_readfirstlane((p.debug & 8u) ? 0u : 0xffffffffu);  // timing experiment: no store
+#pragma unroll
+            for (int L0 = 0; L0 < kWave; L0 += kBatch) {
+                uint32_t ent[kBatch], ent2[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    ent[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u));
+                    if (SK) ent2[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u) + list_bytes);
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const uint32_t n = __builtin_amdgcn_readlane(my_count, L0 + u);
+                    const uint32_t off = __builtin_amdgcn_readlane(excl, L0 + u);
+                    const uint32_t vb = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
+                    uint32_t voff = (uint32_t)lane < n ? (off + (uint32_t)lane) * 4u : 0xffffffffu;
+                    voff |= ~store_mask;
+                    __builtin_amdgcn_raw_buffer_store_b32(vb + ent[u], opos, voff, 0, MM_STORE_AUX);
                     if (SK)
-                        __builtin_amdgcn_raw_buffer_store_b32(
-                            vb + (MODE == 0 ? 1u : 0u) + *reinterpret_cast<const uint16_t *>(q + list_bytes),
-                            osk, (off + c) * 4u, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(vb + (MODE == 0 ? 1u : 0u) + ent2[u], osk, voff, 0,
+                                                              MM_STORE_AUX);
+                }
+            }
+            // lists longer than one wave (dense output): the remaining entries, list by list
+            if (__ballot(my_count > (uint32_t)kWave)) {
+                for (uint32_t L = 0; L < kWave; ++L) {
+                    const uint32_t n = __builtin_amdgcn_readlane(my_count, L);
+                    const uint32_t off = __builtin_amdgcn_readlane(excl, L);
+                    const uint32_t vb = READS ? vb0 : vb0 + L * S;
+                    for (uint32_t c = kWave + lane; c < n; c += kWave) {
+                        const uint8_t *q = rd + 2u * L + (c - lane) * kListStride;
+                        const uint32_t e1 = *reinterpret_cast<const uint16_t *>(q);
+                        __builtin_amdgcn_raw_buffer_store_b32(vb + e1, opos, (off + c) * 4u, 0, 0);
+                        if (SK)
+                            __builtin_amdgcn_raw_buffer_store_b32(
+                                vb + (MODE == 0 ? 1u : 0u) + *reinterpret_cast<const uint16_t *>(q + list_bytes),
+                                osk, (off + c) * 4u, 0, 0);
+                    }
                 }
             }
         }
@@ -595,6 +690,10 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         if (kAmbi && p.wamb) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true, kAmbi>(p, ctx, over);
         else if (READS || partial) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true>(p, ctx, over);
         else lane_walk<W, CANON, HASH_RC, MODE, SK, true, false>(p, ctx, over);
+    }
+    if (p.trace) {
+        __syncthreads();
+        if (tid == 0) p.trace[6 * (size_t)bid + 3] = wall_clock64();
     }
     if (tid == 0 && bid == gridDim.x - 1) {
         *p.out.total = s_excl + block_total;

@@ -97,8 +97,22 @@ bool compile(const std::string &name, std::vector<char> &code, std::string &lowe
     }
     hiprtcAddNameExpression(prog, name.c_str());
     const std::string threads = "-DMM_FUSED_THREADS=" + std::to_string(kFusedThreads);
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", threads.c_str()};
-    const hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+    std::vector<std::string> extra;  // MM_JIT_DEFS: extra -D options (tuning experiments)
+    if (const char *d = getenv("MM_JIT_DEFS")) {
+        std::string cur;
+        for (const char *c = d;; ++c) {
+            if (*c == ' ' || *c == '\0') {
+                if (!cur.empty()) extra.push_back(cur);
+                cur.clear();
+                if (!*c) break;
+            } else {
+                cur.push_back(*c);
+            }
+        }
+    }
+    std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", threads.c_str()};
+    for (const std::string &e : extra) opts.push_back(e.c_str());
+    const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0;
         hiprtcGetProgramLogSize(prog, &ls);
@@ -151,11 +165,12 @@ hipFunction_t jit_fused_kernel(uint32_t w, bool canon, bool hash_rc, int mode, b
         return nullptr;
     }
     const std::string name = fused_kernel_name(w, canon, hash_rc, mode, sk, reads);
-    const std::string key = std::to_string(device) + ":" + name;
+    const char *defs = getenv("MM_JIT_DEFS");
+    const std::string key = std::to_string(device) + ":" + name + "|" + (defs ? defs : "");
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_functions.find(key);
     if (it != g_functions.end()) return it->second;
-    auto bad = g_failed.find(name);
+    auto bad = g_failed.find(key);
     if (bad != g_failed.end()) {
         *err = bad->second;
         return nullptr;
@@ -164,7 +179,7 @@ hipFunction_t jit_fused_kernel(uint32_t w, bool canon, bool hash_rc, int mode, b
     // disk cache: <hash of source, name, compiler>.hsaco + .name (the lowered symbol)
     int rtc_major = 0, rtc_minor = 0;
     hiprtcVersion(&rtc_major, &rtc_minor);
-    const uint64_t h = fnv1a(name + "|gfx950|" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
+    const uint64_t h = fnv1a(name + "|" + (defs ? defs : "") + "|gfx950|" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
                              "|" + std::to_string(kFusedThreads), fnv1a(kernel_source()));
     char hex[32];
     snprintf(hex, sizeof hex, "%016llx", (unsigned long long)h);
@@ -179,7 +194,7 @@ hipFunction_t jit_fused_kernel(uint32_t w, bool canon, bool hash_rc, int mode, b
     }
     if (!from_disk) {
         if (!compile(name, code, lowered, err)) {
-            g_failed[name] = *err;
+            g_failed[key] = *err;
             return nullptr;
         }
         if (!path.empty()) {
@@ -203,7 +218,7 @@ hipFunction_t jit_fused_kernel(uint32_t w, bool canon, bool hash_rc, int mode, b
     }
     if (e != hipSuccess || !fn) {
         *err = std::string("loading the specialised kernel failed: ") + hipGetErrorString(e);
-        g_failed[name] = *err;
+        g_failed[key] = *err;
         return nullptr;
     }
     g_functions[key] = fn;

@@ -15,10 +15,10 @@ def t(b, ws, d, n, out, reps=5):
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 30
 d = sm.generate_device(n, 2); ws = sm.default_workspace(0)
 out = torch.zeros(int(n * 0.2) + 1024, dtype=torch.int32, device="cuda")
-for (k, w, canon, nblk) in [(21, 11, True, 16), (21, 11, False, 16)]:
+for (k, w, canon, nblk) in [(21, 11, True, 0), (21, 11, False, 0)]:
     ws.set_blocks_per_lane(nblk)
     b = sm.Builder(k, w, canon, 0)
-    for dbg in [0, 1, 2, 3, 4, 7]:
+    for dbg in [0, 8, 9, 1, 2, 3]:
         os.environ["MM_DEBUG"] = str(dbg)
         ms = t(b, ws, d, n, out)
         print(f"k={k} w={w} canon={canon} nblk={nblk} debug={dbg:2d}: {ms:.3f} ms {n/ms/1e6:.0f} Gbase/s", flush=True)

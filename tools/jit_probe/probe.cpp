@@ -35,5 +35,6 @@ int main(int argc, char **argv) {
     const char *lowered = nullptr; hiprtcGetLoweredName(prog, name, &lowered);
     size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
     printf("lowered: %s\ncode size: %zu\n", lowered, cs);
+    { std::vector<char> code(cs); hiprtcGetCode(prog, code.data()); FILE *f = fopen("/tmp/jit.co", "wb"); fwrite(code.data(), 1, cs, f); fclose(f); }
     return 0;
 }
