@@ -72,9 +72,12 @@ Geometry geometry(const RunArgs &a) {
         if (cap > g.S + a.w) cap = g.S + a.w;
         g.list_cap = cap;
         g.lds_bytes = cap * kListStride * lists;
-        // large w (run-time specialised kernels): shorten the lanes until the lists fit the LDS
-        if (g.lds_bytes <= kMaxLdsBytes || g.nblk == 1) break;
-        g.nblk = g.nblk > 2 ? g.nblk * 3 / 4 : 1;
+        // large w (run-time specialised kernels): shorten the lanes until the lists fit the LDS;
+        // with two lists per lane (super-k-mer indices) keep at least two workgroups per CU
+        // unless the caller fixed the lane length
+        const uint32_t budget = (lists == 2u && a.nblk == 0) ? 79u * 1024u : kMaxLdsBytes;
+        if (g.lds_bytes <= budget || g.nblk == 1) break;
+        g.nblk = g.nblk > 4 ? g.nblk * 7 / 8 : g.nblk - 1;
     }
     g.NB = kFusedThreads * g.S;
     const uint64_t nwin = a.win_end - a.win_begin;
