@@ -148,6 +148,8 @@ bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_c
 
 uint64_t fused_status_words(const RunArgs &a) { return geometry(a).nblocks + 1; }
 
+static uint32_t g_lds_pad = 0;
+
 int launch_fused(const RunArgs &a, hipStream_t stream) {
     const Geometry g = geometry(a);
     if (g.nblocks == 0) return 0;
@@ -179,6 +181,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * g.nblocks, stream) != hipSuccess)
         return -1;
     if (hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
+    if (const char *pad = getenv("MM_LDS_PAD")) g_lds_pad = (uint32_t)atoi(pad);  // occupancy experiments
     p.trace = nullptr;
     if (const char *tr = getenv("MM_TRACE")) {
         // timing experiment: per-tile timestamps dumped to the file MM_TRACE (synchronous)
@@ -198,7 +201,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         }
         return r;
     }
-    return launch_kernel(kr, (uint32_t)g.nblocks, g.lds_bytes, stream, p, a.timing_start, a.timing_stop);
+    return launch_kernel(kr, (uint32_t)g.nblocks, g.lds_bytes + g_lds_pad, stream, p, a.timing_start, a.timing_stop);
 }
 
 // ------------------------------------------------------------------ reads mode

@@ -644,34 +644,78 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
             constexpr int kBatch = 8;
             const uint32_t store_mask =
                 __builtin_amdgcn_readfirstlane((p.debug & 8u) ? 0u : 0xffffffffu);  // timing experiment: no store
+            // Fast path (the whole wave fits the caller's capacity, no SK): the lane mask "entry <
+            // length of the list" and the list's byte offset are made on the scalar unit (s_bfm ->
+            // exec, soffset), so a list costs 2 v_readlane + 1 v_add; lists of 64 and more entries
+            // are left to the loop below.
+            const bool fast = !SK && room32 >= wave_total;
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned long long obase = (unsigned long long)reinterpret_cast<uintptr_t>(p.out.pos + run0_u);
+            u32x4 odesc;
+            odesc.x = __builtin_amdgcn_readfirstlane((uint32_t)obase);
+            odesc.y = __builtin_amdgcn_readfirstlane((uint32_t)(obase >> 32) & 0xffffu);
+            odesc.z = 0x7fffffffu;  // the capacity was checked for the whole wave
+            odesc.w = 0x00020000u;
+            const uint32_t lane4 = (uint32_t)lane * 4u;
+            if (fast) {
 #pragma unroll
-            for (int L0 = 0; L0 < kWave; L0 += kBatch) {
-                uint32_t ent[kBatch], ent2[kBatch];
+                for (int L0 = 0; L0 < kWave; L0 += kBatch) {
+                    uint32_t ent[kBatch];
 #pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    ent[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u));
-                    if (SK) ent2[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u) + list_bytes);
+                    for (int u = 0; u < kBatch; ++u) ent[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u));
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) {
+                        const uint32_t n = __builtin_amdgcn_readlane(my_count, L0 + u);
+                        const uint32_t off = __builtin_amdgcn_readlane(excl, L0 + u);
+                        const uint32_t val = (READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S) + ent[u];
+                        uint32_t t0;
+                        unsigned long long sv;
+                        asm volatile(
+                            "s_cmp_lt_u32 %[n], 64\n\t"
+                            "s_cselect_b32 %[t0], %[n], 0\n\t"
+                            "s_and_b32 %[t0], %[t0], %[sm]\n\t"
+                            "s_mov_b64 %[sv], exec\n\t"
+                            "s_bfm_b64 exec, %[t0], 0\n\t"
+                            "s_lshl_b32 %[t0], %[off], 2\n\t"
+                            "buffer_store_dword %[val], %[lane4], %[desc], %[t0] offen nt\n\t"
+                            "s_mov_b64 exec, %[sv]"
+                            : [t0] "=&s"(t0), [sv] "=&s"(sv)
+                            : [n] "s"(n), [off] "s"(off), [val] "v"(val), [lane4] "v"(lane4), [desc] "s"(odesc),
+                              [sm] "s"(store_mask)
+                            : "scc", "memory");
+                    }
                 }
+            } else {
 #pragma unroll
-                for (int u = 0; u < kBatch; ++u) {
-                    const uint32_t n = __builtin_amdgcn_readlane(my_count, L0 + u);
-                    const uint32_t off = __builtin_amdgcn_readlane(excl, L0 + u);
-                    const uint32_t vb = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
-                    uint32_t voff = (uint32_t)lane < n ? (off + (uint32_t)lane) * 4u : 0xffffffffu;
-                    voff |= ~store_mask;
-                    __builtin_amdgcn_raw_buffer_store_b32(vb + ent[u], opos, voff, 0, MM_STORE_AUX);
-                    if (SK)
-                        __builtin_amdgcn_raw_buffer_store_b32(vb + (MODE == 0 ? 1u : 0u) + ent2[u], osk, voff, 0,
-                                                              MM_STORE_AUX);
+                for (int L0 = 0; L0 < kWave; L0 += kBatch) {
+                    uint32_t ent[kBatch], ent2[kBatch];
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) {
+                        ent[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u));
+                        if (SK) ent2[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u) + list_bytes);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) {
+                        const uint32_t n = __builtin_amdgcn_readlane(my_count, L0 + u);
+                        const uint32_t off = __builtin_amdgcn_readlane(excl, L0 + u);
+                        const uint32_t vb = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
+                        uint32_t voff = (uint32_t)lane < n ? (off + (uint32_t)lane) * 4u : 0xffffffffu;
+                        voff |= ~store_mask;
+                        __builtin_amdgcn_raw_buffer_store_b32(vb + ent[u], opos, voff, 0, MM_STORE_AUX);
+                        if (SK)
+                            __builtin_amdgcn_raw_buffer_store_b32(vb + (MODE == 0 ? 1u : 0u) + ent2[u], osk, voff, 0,
+                                                                  MM_STORE_AUX);
+                    }
                 }
             }
             // lists longer than one wave (dense output): the remaining entries, list by list
-            if (__ballot(my_count > (uint32_t)kWave)) {
+            if (__ballot(my_count >= (uint32_t)kWave)) {
                 for (uint32_t L = 0; L < kWave; ++L) {
                     const uint32_t n = __builtin_amdgcn_readlane(my_count, L);
                     const uint32_t off = __builtin_amdgcn_readlane(excl, L);
                     const uint32_t vb = READS ? vb0 : vb0 + L * S;
-                    for (uint32_t c = kWave + lane; c < n; c += kWave) {
+                    // (the fast path above skipped lists of 64 and more entries entirely)
+                    for (uint32_t c = (fast && n >= (uint32_t)kWave ? 0u : (uint32_t)kWave) + lane; c < n; c += kWave) {
                         const uint8_t *q = rd + 2u * L + (c - lane) * kListStride;
                         const uint32_t e1 = *reinterpret_cast<const uint16_t *>(q);
                         __builtin_amdgcn_raw_buffer_store_b32(vb + e1, opos, (off + c) * 4u, 0, 0);
