@@ -686,7 +686,9 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
                     }
                 }
             } else {
-#pragma unroll
+                // (capacity-checked offsets; also the super-k-mer flavour.  Kept rolled: eight lists
+                // per iteration are enough to cover the LDS latency and the code stays small)
+#pragma unroll 1
                 for (int L0 = 0; L0 < kWave; L0 += kBatch) {
                     uint32_t ent[kBatch], ent2[kBatch];
 #pragma unroll
