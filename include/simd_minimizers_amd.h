@@ -179,8 +179,9 @@ int mm_values_u128_host(mm_workspace_t *ws, const uint8_t *packed, uint64_t base
  * Builder::run once per sequence (bench/src/bin/paper.rs:410-431).  Sequence s lives at
  * d_packed[s] (device pointers, host array).  Positions are sequence-local and are written back
  * to back into d_out_pos; out_offsets[s] .. out_offsets[s+1] (host array of n_seqs+1 entries)
- * delimit sequence s.  One kernel launch per sequence on the workspace stream, no host
- * synchronisation in between. */
+ * delimit sequence s.  With a fused kernel for the plan the whole batch is ONE launch (every tile
+ * looks its sequence up in a device table), so thousands of contigs cost no more launches than one
+ * chromosome; other plans take one launch per sequence on the workspace stream. */
 int mm_run_batch_device(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_seqs,
                         const void *const *d_packed, const uint64_t *packed_bytes,
                         const uint64_t *base_offsets, const uint64_t *n_bases,

@@ -100,6 +100,13 @@ struct mm_workspace {
     // skip-ambiguous path: window ambiguity bits, staged ambiguity bits of the host entry points
     uint32_t *wamb = nullptr;
     uint64_t wamb_dwords = 0;
+    // batch mode tables (sequence descriptors, tile -> sequence, per-sequence offsets)
+    mm::BatchSeq *batch_seqs = nullptr;
+    uint64_t batch_seqs_n = 0;
+    uint32_t *batch_tiles = nullptr;
+    uint64_t batch_tiles_n = 0;
+    unsigned long long *batch_offsets = nullptr;
+    uint64_t batch_offsets_n = 0;
     void *d_amb = nullptr;
     uint64_t d_amb_bytes = 0;
     unsigned long long *d_vals = nullptr;
@@ -297,6 +304,9 @@ void mm_workspace_destroy(mm_workspace_t *ws) {
     if (ws->d_out) hipFree(ws->d_out);
     if (ws->d_sk) hipFree(ws->d_sk);
     if (ws->wamb) hipFree(ws->wamb);
+    if (ws->batch_seqs) hipFree(ws->batch_seqs);
+    if (ws->batch_tiles) hipFree(ws->batch_tiles);
+    if (ws->batch_offsets) hipFree(ws->batch_offsets);
     if (ws->d_amb) hipFree(ws->d_amb);
     if (ws->d_vals) hipFree(ws->d_vals);
     if (ws->own_stream && ws->stream) hipStreamDestroy(ws->stream);
@@ -421,6 +431,11 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
         a.timing_start = a.timing_stop = nullptr;
         a.wamb = nullptr;
         a.wamb_dwords = 0;
+        a.batch_seqs = nullptr;
+        a.batch_tile_seq = nullptr;
+        a.batch_offsets = nullptr;
+        a.batch_n = 0;
+        a.batch_tiles = 0;
         if (amb) {
             r = prepare_window_ambiguity(ws, *amb, n_bases, (uint32_t)l, win_begin, win_end, &a.wamb_dwords);
             if (r) return r;
@@ -485,6 +500,136 @@ int mm_run_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d
                                  win_end, d_out_pos, d_out_sk, capacity, d_count, false);
 }
 
+// Batch mode of the fused kernel: every sequence is cut into tiles, one launch covers all tiles of
+// all sequences (a tile reads its sequence from a device table), so a batch of thousands of contigs
+// costs one launch instead of one per sequence.  Returns MM_BATCH_FALLBACK when the plan has no
+// fused kernel (then the caller loops over the sequences).
+static const int MM_BATCH_FALLBACK = 1;
+
+static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_seqs,
+                                const void *const *d_packed, const uint64_t *packed_bytes,
+                                const uint64_t *base_offsets, const uint64_t *n_bases,
+                                uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
+                                uint64_t *out_offsets) {
+    if (ws->force_generic || n_seqs == 0 || n_seqs >= (1ull << 32) ||
+        !mm::fused_supported(plan->k, plan->w, plan->canonical_windows, (int)plan->ht.canonical))
+        return MM_BATCH_FALLBACK;
+    if (d_out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;
+    if (!d_out_pos) capacity = 0;
+    mm::RunArgs a;
+    a.ht = plan->ht;
+    a.k = plan->k;
+    a.w = plan->w;
+    a.canonical_windows = plan->canonical_windows;
+    a.mode = plan->mode;
+    a.win_begin = a.win_end = 0;
+    a.out.pos = d_out_pos;
+    a.out.sk = d_out_sk;
+    a.out.cap = capacity;
+    a.out.total = ws->total;
+    a.out.ticket = ws->ticket;
+    a.out.error = reinterpret_cast<uint32_t *>(ws->total + 1);
+    a.nblk = ws->nblk;
+    a.scratch = nullptr;
+    a.generic_round_windows = 0;
+    a.wamb = nullptr;
+    a.wamb_dwords = 0;
+    a.seq = mm::SeqView{nullptr, 0, 0, 0};
+    a.batch_seqs = nullptr;
+    a.batch_tile_seq = nullptr;
+    a.batch_offsets = nullptr;
+    a.batch_n = (uint32_t)n_seqs;
+    a.batch_tiles = 0;
+    const uint64_t NB = mm::fused_tile_windows(a);
+    const uint64_t l = (uint64_t)plan->k + plan->w - 1;
+
+    std::vector<mm::BatchSeq> seqs(n_seqs);
+    std::vector<uint32_t> tile_seq;
+    for (uint64_t s = 0; s < n_seqs; ++s) {
+        if (n_bases[s] >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+        const uint64_t nw = n_bases[s] >= l ? n_bases[s] - l + 1 : 0;
+        mm::BatchSeq &b = seqs[s];
+        b = mm::BatchSeq{nullptr, 0, 0, 0, (uint32_t)tile_seq.size(), {0, 0}};
+        if (nw == 0) continue;
+        if (!d_packed[s]) return MM_ERR_NULL;
+        mm::SeqView v;
+        int r = make_view(d_packed[s], packed_bytes[s], base_offsets ? base_offsets[s] : 0, n_bases[s], &v);
+        if (r) return r;
+        b.d = v.d;
+        b.n_dwords = v.n_dwords;
+        b.base0 = v.base0;
+        b.n_windows = (uint32_t)nw;
+        const uint64_t tiles = (nw + NB - 1) / NB;
+        if (tile_seq.size() + tiles >= (1ull << 31)) return MM_BATCH_FALLBACK;
+        tile_seq.insert(tile_seq.end(), (size_t)tiles, (uint32_t)s);
+    }
+    const uint64_t n_tiles = tile_seq.size();
+    if (n_tiles == 0) {
+        for (uint64_t s = 0; s <= n_seqs; ++s) out_offsets[s] = 0;
+        return MM_OK;
+    }
+    int r = grow(ws->batch_seqs, ws->batch_seqs_n, n_seqs, sizeof(mm::BatchSeq));
+    if (r) return r;
+    r = grow(ws->batch_tiles, ws->batch_tiles_n, n_tiles, sizeof(uint32_t));
+    if (r) return r;
+    r = grow(ws->batch_offsets, ws->batch_offsets_n, n_seqs + 1, sizeof(unsigned long long));
+    if (r) return r;
+    MM_HIP(hipMemcpyAsync(ws->batch_seqs, seqs.data(), n_seqs * sizeof(mm::BatchSeq), hipMemcpyHostToDevice,
+                          ws->stream));
+    MM_HIP(hipMemcpyAsync(ws->batch_tiles, tile_seq.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice,
+                          ws->stream));
+    a.batch_seqs = ws->batch_seqs;
+    a.batch_tile_seq = ws->batch_tiles;
+    a.batch_offsets = ws->batch_offsets;
+    a.batch_tiles = n_tiles;
+    r = grow(ws->status, ws->status_words, n_tiles + 1, sizeof(unsigned long long));
+    if (r) return r;
+    a.out.status = ws->status;
+
+    std::vector<unsigned long long> offs(n_seqs + 1);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        a.use_ticket = (ws->force_ticket || getenv("MM_FORCE_TICKET")) ? 1 : 0;
+        a.timing_start = a.timing_stop = nullptr;
+        MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
+        MM_HIP(hipMemsetAsync(ws->batch_offsets, 0xFF, (n_seqs + 1) * sizeof(unsigned long long), ws->stream));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ws->timing) {
+            MM_HIP(hipEventCreate(&e0));
+            MM_HIP(hipEventCreate(&e1));
+            a.timing_start = e0;
+            a.timing_stop = e1;
+        }
+        const int lr = mm::launch_fused(a, ws->stream);
+        if (lr != 0) {
+            if (e0) hipEventDestroy(e0);
+            if (e1) hipEventDestroy(e1);
+            if (lr == -2) return MM_BATCH_FALLBACK;
+            g_last_error = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
+            return MM_ERR_HIP;
+        }
+        if (ws->timing) ws->events.emplace_back(e0, e1);
+        ws->last_path = MM_PATH_FUSED;
+        MM_HIP(hipMemcpyAsync(offs.data(), ws->batch_offsets, (n_seqs + 1) * sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, ws->stream));
+        MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                              ws->stream));
+        MM_HIP(hipStreamSynchronize(ws->stream));
+        if (ws->h_total[1] == 0) break;
+        if (ws->force_ticket) {
+            g_last_error = "look-back scan timed out in ticket mode";
+            return MM_ERR_HIP;
+        }
+        ws->force_ticket = true;  // redo the batch in ticket mode
+    }
+    // sequences without a window own no tile: their slice is empty and starts where the next one does
+    offs[n_seqs] = ws->h_total[0];
+    for (uint64_t s = n_seqs; s-- > 0;)
+        if (offs[s] == ~0ull) offs[s] = offs[s + 1];
+    for (uint64_t s = 0; s <= n_seqs; ++s) out_offsets[s] = offs[s];
+    if (d_out_pos && out_offsets[n_seqs] > capacity) return MM_ERR_CAPACITY;
+    return MM_OK;
+}
+
 int mm_run_batch_device(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_seqs,
                         const void *const *d_packed, const uint64_t *packed_bytes,
                         const uint64_t *base_offsets, const uint64_t *n_bases,
@@ -493,6 +638,11 @@ int mm_run_batch_device(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_se
     if (!plan || !ws || !out_offsets) return MM_ERR_NULL;
     if (n_seqs && (!d_packed || !packed_bytes || !n_bases)) return MM_ERR_NULL;
     MM_HIP(hipSetDevice(ws->device));
+    {
+        int r = run_batch_one_launch(plan, ws, n_seqs, d_packed, packed_bytes, base_offsets, n_bases,
+                                     d_out_pos, d_out_sk, capacity, out_offsets);
+        if (r != MM_BATCH_FALLBACK) return r;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         // running totals after each sequence, read back once at the end
         unsigned long long *h = nullptr;

@@ -47,6 +47,16 @@ struct SeqView {
     uint32_t n_bases;
 };
 
+// One sequence of a batch launch (device table, 32 bytes).
+struct BatchSeq {
+    const uint32_t *d;    // dword-aligned base of the packed bytes
+    uint32_t n_dwords;    // readable dwords
+    uint32_t base0;       // first base inside d
+    uint32_t n_windows;   // windows of this sequence (> 0: empty sequences get no tile)
+    uint32_t first_tile;  // id of the sequence's first tile
+    uint32_t pad[2];
+};
+
 struct OutParams {
     uint32_t *pos;
     uint32_t *sk;  // may be null

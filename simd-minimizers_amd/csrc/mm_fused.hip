@@ -80,8 +80,12 @@ Geometry geometry(const RunArgs &a) {
         g.nblk = g.nblk > 4 ? g.nblk * 7 / 8 : g.nblk - 1;
     }
     g.NB = kFusedThreads * g.S;
-    const uint64_t nwin = a.win_end - a.win_begin;
-    g.nblocks = (nwin + g.NB - 1) / g.NB;
+    if (a.batch_tile_seq) {
+        g.nblocks = a.batch_tiles;
+    } else {
+        const uint64_t nwin = a.win_end - a.win_begin;
+        g.nblocks = (nwin + g.NB - 1) / g.NB;
+    }
     return g;
 }
 
@@ -147,6 +151,7 @@ bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_c
 }
 
 uint64_t fused_status_words(const RunArgs &a) { return geometry(a).nblocks + 1; }
+uint32_t fused_tile_windows(const RunArgs &a) { return geometry(a).NB; }
 
 static uint32_t g_lds_pad = 0;
 
@@ -172,6 +177,10 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.read_offsets = nullptr;
     p.wamb = a.wamb;
     p.wamb_dwords = a.wamb_dwords;
+    p.batch_seqs = a.batch_seqs;
+    p.batch_tile_seq = a.batch_tile_seq;
+    p.batch_offsets = a.batch_offsets;
+    p.batch_n = a.batch_n;
     p.out = a.out;
     p.use_ticket = a.use_ticket ? 1u : 0u;
     {
@@ -186,13 +195,13 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     if (const char *tr = getenv("MM_TRACE")) {
         // timing experiment: per-tile timestamps dumped to the file MM_TRACE (synchronous)
         unsigned long long *d_tr = nullptr;
-        const size_t bytes = sizeof(unsigned long long) * 6 * g.nblocks;
+        const size_t bytes = sizeof(unsigned long long) * 10 * g.nblocks;
         if (hipMalloc(reinterpret_cast<void **>(&d_tr), bytes) != hipSuccess) return -1;
         hipMemsetAsync(d_tr, 0, bytes, stream);
         p.trace = d_tr;
         int r = launch_kernel(kr, (uint32_t)g.nblocks, g.lds_bytes, stream, p, a.timing_start, a.timing_stop);
         hipStreamSynchronize(stream);
-        std::vector<unsigned long long> h(6 * g.nblocks);
+        std::vector<unsigned long long> h(10 * g.nblocks);
         hipMemcpy(h.data(), d_tr, bytes, hipMemcpyDeviceToHost);
         hipFree(d_tr);
         if (FILE *f = fopen(tr, "wb")) {
@@ -267,6 +276,10 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.read_offsets = a.read_offsets;
     p.wamb = a.wamb;
     p.wamb_dwords = a.wamb_dwords;
+    p.batch_seqs = nullptr;
+    p.batch_tile_seq = nullptr;
+    p.batch_offsets = nullptr;
+    p.batch_n = 0;
     p.trace = nullptr;
     p.out = a.out;
     if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * nblocks, stream) != hipSuccess) return -1;

@@ -62,6 +62,14 @@ struct FusedParams {
     // starts at base g (relative to the first base of the sequence / buffer span) is skipped
     const uint32_t *wamb;               // null for a plain PackedSeq
     uint32_t wamb_dwords;
+    // Batch mode (sequence-mode kernels): many independent sequences in one launch.  Tile b belongs
+    // to sequence batch_tile_seq[b]; the sequence's view, window count and first tile come from
+    // batch_seqs[]; positions are sequence-local; batch_offsets[s] receives the first output slot
+    // of sequence s (written by its first tile), batch_offsets[n] the total.  Null = one sequence.
+    const BatchSeq *batch_seqs;
+    const uint32_t *batch_tile_seq;
+    unsigned long long *batch_offsets;
+    uint32_t batch_n;
     // timing experiments (MM_TRACE): 4 timestamps per tile (start, phase 1 done, look-back done, end)
     unsigned long long *trace;
     OutParams out;
@@ -115,7 +123,9 @@ struct LaneCtx {
     uint32_t list_bytes;     // list_cap * kListStride (the super-k-mer list follows at +list_bytes)
     unsigned long long dst;  // first output slot of this lane (DIRECT mode)
     uint32_t abase;          // bit of the lane's window 0 in FusedParams::wamb (AMBI walks)
-    uint32_t nblk;           // W-blocks this lane walks (tile-specific in the staggered prologue)
+    uint32_t nblk;           // W-blocks this lane walks
+    const uint32_t *seq_d;   // the sequence the tile reads (p.seq, or the batch entry)
+    uint32_t seq_dwords;
 };
 
 // One lane walks its S windows.  List mode: appends emitted 16-bit values to the lane's LDS
@@ -134,13 +144,14 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // (tile-uniform; pinned to SGPRs so that the buffer descriptor below is scalar and the loads
     // need no per-lane descriptor loop)
     const long long Q0v = Q0 < 0 ? 0 : Q0;
-    const long long Q0c = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)Q0v >> 32)) << 32) |
-                                      __builtin_amdgcn_readfirstlane((uint32_t)Q0v));
+    const long long Q0c =
+        (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)Q0v >> 32)) << 32) |
+                    (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)Q0v));
     const int32_t prel0 = (int32_t)(P0 - (Q0c << 4));  // -1 .. 15
     // Bounds-checked view of the packed sequence from dword Q0c on: dwords past the end read as 0,
     // so the halo after the last base needs no clamping.
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t *>(p.seq.d + Q0c), 0, (int)(((long long)p.seq.n_dwords - Q0c) * 4), 0x00020000);
+        const_cast<uint32_t *>(ctx.seq_d + Q0c), 0, (int)(((long long)ctx.seq_dwords - Q0c) * 4), 0x00020000);
     const int32_t pb = prel0 + (int32_t)ctx.lane_bases;  // first base of this lane's element 0
     // 16-base view starting at tile-relative base position pos >= 0
     auto view = [&](int32_t pos) -> uint32_t {
@@ -283,7 +294,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     static_assert(!AMBI || PARTIAL, "AMBI walks use the flag path");
     constexpr int NSUBA = AMBI ? (W + 31) / 32 : 1;
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t *>(AMBI ? p.wamb : p.seq.d), 0, AMBI ? (int)(p.wamb_dwords * 4u) : 0, 0x00020000);
+        const_cast<uint32_t *>(AMBI ? p.wamb : ctx.seq_d), 0, AMBI ? (int)(p.wamb_dwords * 4u) : 0, 0x00020000);
     auto aview = [&](uint32_t bit) -> uint32_t {
         const auto d = __builtin_amdgcn_raw_buffer_load_b64(arsrc, (bit >> 5) << 2, 0, 0);
         return __builtin_amdgcn_alignbit(d[1], d[0], bit & 31u);
@@ -530,8 +541,8 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         uint32_t hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        p.trace[6 * (size_t)bid + 0] = wall_clock64();
-        p.trace[6 * (size_t)bid + 4] = ((unsigned long long)xcc << 32) | hw;
+        p.trace[10 * (size_t)bid + 0] = wall_clock64();
+        p.trace[10 * (size_t)bid + 4] = ((unsigned long long)xcc << 32) | hw;
     }
 
     const uint32_t nblk_t = p.nblk;
@@ -539,9 +550,45 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     const uint32_t NB = kFusedThreads * S;
     // (one 32 x 32 -> 64-bit product: stays on the scalar unit, so everything derived from the tile
     // origin - the buffer descriptors of the sequence loads above all - lives in SGPRs)
-    const uint64_t bw0 = READS ? 0ull : (uint64_t)p.win_begin + (uint64_t)bid * NB;  // first window of the tile
+    // the sequence this tile belongs to (tile-uniform scalars)
+    const uint32_t *seq_d = p.seq.d;
+    uint32_t seq_dwords = p.seq.n_dwords, seq_base0 = p.seq.base0;
+    uint32_t win_begin = p.win_begin, win_end = p.win_end, local_tile = bid, batch_s = 0;
+    const bool batch = !READS && p.batch_tile_seq != nullptr;
+    if (batch) {
+        batch_s = __builtin_amdgcn_readfirstlane(p.batch_tile_seq[bid]);
+        const BatchSeq bs = p.batch_seqs[batch_s];
+        {
+            const unsigned long long a = (unsigned long long)reinterpret_cast<uintptr_t>(bs.d);
+            // (readfirstlane returns int: without the casts a low half with bit 31 set sign-extends)
+            const unsigned long long pa =
+                ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) |
+                (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
+            seq_d = reinterpret_cast<const uint32_t *>(static_cast<uintptr_t>(pa));
+        }
+        seq_dwords = __builtin_amdgcn_readfirstlane(bs.n_dwords);
+        seq_base0 = __builtin_amdgcn_readfirstlane(bs.base0);
+        win_begin = 0;
+        win_end = __builtin_amdgcn_readfirstlane(bs.n_windows);
+        local_tile = bid - __builtin_amdgcn_readfirstlane(bs.first_tile);
+        // a table entry that does not describe this tile must never be dereferenced
+        if (batch_s >= p.batch_n || win_end == 0u || (uint64_t)local_tile * NB >= win_end || seq_d == nullptr) {
+            if (tid == 0) {
+                p.out.error[0] = 0xbad00000u | (bid & 0xfffffu);
+                p.out.error[1] = batch_s;
+            }
+            return;
+        }
+    }
+    if (p.trace && tid == 0) {
+        p.trace[10 * (size_t)bid + 6] = (unsigned long long)reinterpret_cast<uintptr_t>(seq_d);
+        p.trace[10 * (size_t)bid + 7] = ((unsigned long long)seq_dwords << 32) | seq_base0;
+        p.trace[10 * (size_t)bid + 8] = ((unsigned long long)win_end << 32) | local_tile;
+        p.trace[10 * (size_t)bid + 9] = batch_s;
+    }
+    const uint64_t bw0 = READS ? 0ull : (uint64_t)win_begin + (uint64_t)local_tile * NB;  // first window of the tile
     const uint32_t nvalid = READS ? NB
-        : (uint32_t)(((uint64_t)p.win_end - bw0) < NB ? ((uint64_t)p.win_end - bw0) : NB);
+        : (uint32_t)(((uint64_t)win_end - bw0) < NB ? ((uint64_t)win_end - bw0) : NB);
     const bool partial = READS || nvalid < NB;
 
     LaneCtx ctx;
@@ -550,6 +597,8 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     ctx.list_bytes = p.list_cap * kListStride;
     ctx.dst = 0;
     ctx.nblk = nblk_t;
+    ctx.seq_d = seq_d;
+    ctx.seq_dwords = seq_dwords;
     bool lane_active, lane_in = false;  // lane_in: the lane owns a read (which may have no window)
     const uint32_t read0 = bid * kFusedThreads;  // READS: first read of the tile
     if (READS) {
@@ -559,7 +608,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         const uint32_t l = p.k + (uint32_t)W - 1u;
         const uint32_t nw = len >= l ? len - l + 1u : 0u;
         lane_active = nw != 0u;
-        ctx.p0 = (long long)p.seq.base0 + (long long)read0 * p.read_stride - 1;
+        ctx.p0 = (long long)seq_base0 + (long long)read0 * p.read_stride - 1;
         ctx.lane_bases = (uint32_t)tid * p.read_stride;
         ctx.wbase = 0;
         ctx.no_prev = true;
@@ -568,7 +617,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     } else {
         const uint32_t lw = (uint32_t)tid * S;  // first window of the lane, tile-relative
         lane_active = lw < nvalid;
-        ctx.p0 = (long long)p.seq.base0 + (long long)bw0 - 1;
+        ctx.p0 = (long long)seq_base0 + (long long)bw0 - 1;
         ctx.lane_bases = lw;
         ctx.wbase = (uint32_t)bw0 + lw;
         ctx.no_prev = (bw0 + lw == 0);
@@ -588,12 +637,12 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     }
 
     // ---------------------------------------------------------------- phase 2
-    if (p.trace && tid == 0) p.trace[6 * (size_t)bid + 1] = wall_clock64();
+    if (p.trace && tid == 0) p.trace[10 * (size_t)bid + 1] = wall_clock64();
     const uint32_t incl = wave_scan_dpp(my_count);
     const uint32_t wave_total = __builtin_amdgcn_readlane(incl, kWave - 1);
     if (lane == 0) s_wave_tot[wave] = wave_total;
     __syncthreads();
-    if (p.trace && tid == 0) p.trace[6 * (size_t)bid + 5] = wall_clock64();
+    if (p.trace && tid == 0) p.trace[10 * (size_t)bid + 5] = wall_clock64();
     uint32_t wave_base = 0, block_total = 0;
 #pragma unroll
     for (int v = 0; v < kFusedWaves; ++v) {
@@ -608,12 +657,13 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
             (p.debug & 1u) ? (unsigned long long)bid * (NB / 6u)
                            : lookback_exclusive(p.out.status, bid, block_total, carry, p.out.error);
         if (lane == 0) s_excl = ex;
-        if (p.trace && lane == 0) p.trace[6 * (size_t)bid + 2] = wall_clock64();
+        if (p.trace && lane == 0) p.trace[10 * (size_t)bid + 2] = wall_clock64();
     }
     __syncthreads();
     const unsigned long long run0 = s_excl + wave_base;  // first output slot of this wave
     const uint32_t excl = incl - my_count;
     if (READS && lane_in) p.read_offsets[read0 + (uint32_t)tid] = run0 + excl;
+    if (batch && tid == 0 && local_tile == 0) p.batch_offsets[batch_s] = s_excl;
 
     if (!overflow) {
         // Copy the 64 lists of this wave's lanes, in lane order (= window order).  Entry c of
@@ -648,7 +698,11 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
             // length of the list" and the list's byte offset are made on the scalar unit (s_bfm ->
             // exec, soffset), so a list costs 2 v_readlane + 1 v_add; lists of 64 and more entries
             // are left to the loop below.
+#ifdef MM_NO_FAST
+            const bool fast = false;
+#else
             const bool fast = !SK && room32 >= wave_total;
+#endif
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             const unsigned long long obase = (unsigned long long)reinterpret_cast<uintptr_t>(p.out.pos + run0_u);
             u32x4 odesc;
@@ -739,11 +793,12 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     }
     if (p.trace) {
         __syncthreads();
-        if (tid == 0) p.trace[6 * (size_t)bid + 3] = wall_clock64();
+        if (tid == 0) p.trace[10 * (size_t)bid + 3] = wall_clock64();
     }
     if (tid == 0 && bid == gridDim.x - 1) {
         *p.out.total = s_excl + block_total;
         if (READS) p.read_offsets[p.n_reads] = s_excl + block_total;
+        if (batch) p.batch_offsets[p.batch_n] = s_excl + block_total;
     }
 }
 

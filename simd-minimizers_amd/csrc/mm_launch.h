@@ -20,6 +20,12 @@ struct RunArgs {
     // skip-ambiguous windows: bit i set = window i holds an ambiguous base (null = plain PackedSeq)
     const uint32_t *wamb;
     uint32_t wamb_dwords;
+    // batch mode of the fused family: many sequences, one launch (device tables; null = one sequence)
+    const BatchSeq *batch_seqs;
+    const uint32_t *batch_tile_seq;
+    unsigned long long *batch_offsets;  // n + 1 entries
+    uint32_t batch_n;
+    uint64_t batch_tiles;
     // fused path
     uint32_t nblk;  // w-blocks per lane (0 = default)
     int use_ticket; // tile ids from an atomic ticket instead of blockIdx.x (safe mode)
@@ -33,6 +39,8 @@ struct RunArgs {
 // ---- fused family (mm_fused_*.hip): one kernel, specialised per w
 bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_canonical);
 uint64_t fused_status_words(const RunArgs &a);
+// windows per tile for this plan / output flavour (what a batch's tile table is built from)
+uint32_t fused_tile_windows(const RunArgs &a);
 // returns 0, -1 (HIP failure) or -2 (no kernel for this plan: take the generic family;
 // fused_unavailable_reason() says why)
 int launch_fused(const RunArgs &a, hipStream_t stream);

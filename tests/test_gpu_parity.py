@@ -504,6 +504,53 @@ def test_batch_of_contigs(sm, oracle, gpu):
             assert np.array_equal(host[offs[i]:offs[i + 1]], want), (i, n, k, w)
 
 
+def test_batch_many_small_contigs(sm, oracle, gpu):
+    """A few thousand contigs of 0 .. 6000 bases carved out of one buffer at odd byte and base
+    offsets: one launch (tile -> sequence table); every contig equals an independent run; the
+    generic family (one launch per sequence) gives the same."""
+    import torch
+    rng = np.random.default_rng(77)
+    n_seq = 1500
+    lens = rng.integers(0, 6001, size=n_seq)
+    lens[:8] = [0, 1, 30, 31, 32, 6000, 0, 5999]
+    total = int(lens.sum()) + 8 * n_seq + 64
+    data = oracle.gen_packed(9, total)
+    big = torch.from_numpy(data).cuda()
+    starts = np.concatenate([[0], np.cumsum(lens + rng.integers(0, 8, size=n_seq))])[:n_seq]  # base positions
+    d, offs_b = [], []
+    for s0 in starts:
+        byte0 = int(s0) // 4
+        d.append(big[byte0:])
+        offs_b.append(int(s0) % 4)
+    out = torch.zeros(int(lens.sum()) + 64, dtype=torch.int32, device="cuda")
+    sk = torch.zeros_like(out)
+    for k, w, canonical, mode, use_sk in [(21, 11, True, 0, False), (21, 11, False, 0, True), (15, 17, True, 1, False)]:
+        b = sm.Builder(k, w, canonical, mode)
+        results = []
+        for force_generic in (False, True):
+            gpu.force_generic(force_generic)
+            offs = sm.run_batch_device(b, d, [int(x) for x in lens], out, sk if use_sk else None, base_offsets=offs_b)
+            assert gpu.last_path() == (sm.PATH_GENERIC if force_generic else sm.PATH_FUSED)
+            results.append((offs, out[: offs[-1]].cpu().numpy().view(np.uint32).copy(),
+                            sk[: offs[-1]].cpu().numpy().view(np.uint32).copy()))
+        gpu.force_generic(False)
+        assert results[0][0] == results[1][0]
+        assert np.array_equal(results[0][1], results[1][1])
+        if use_sk:
+            assert np.array_equal(results[0][2], results[1][2])
+        offs, host, hsk = results[0]
+        assert offs[0] == 0 and len(offs) == n_seq + 1
+        for i in list(range(12)) + [int(x) for x in rng.integers(0, n_seq, size=150)]:
+            n = int(lens[i])
+            if use_sk:
+                want, wsk = oracle.run(data, n, k, w, canonical=canonical, mode=mode, super_kmers=True,
+                                       base_offset=int(starts[i]))
+                assert np.array_equal(hsk[offs[i]:offs[i + 1]], wsk), (i, n)
+            else:
+                want = oracle.run(data, n, k, w, canonical=canonical, mode=mode, base_offset=int(starts[i]))
+            assert np.array_equal(host[offs[i]:offs[i + 1]], want), (i, n, k, w)
+
+
 def test_pack_ascii_device(sm, oracle, gpu):
     """PackedSeqVec::from_ascii on the device (aligned 16-base fast path, tails, odd alignments)."""
     import ctypes as C

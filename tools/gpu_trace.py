@@ -17,7 +17,7 @@ for spec in sys.argv[1:] or ["0:0", "4:0"]:
     os.environ["MM_TRACE"] = "/tmp/mm_trace.bin"
     b.run_device(d, n, out)
     del os.environ["MM_TRACE"]
-    t = np.fromfile("/tmp/mm_trace.bin", dtype=np.uint64).reshape(-1, 6)
+    t = np.fromfile("/tmp/mm_trace.bin", dtype=np.uint64).reshape(-1, 10)
     t0 = t[:, 0].min()
     start, p1, lb, end = [(t[:, i] - t0).astype(np.float64) / 100.0 for i in range(4)]  # us (100 MHz)
     hw = t[:, 4]
