@@ -124,6 +124,9 @@ def lib():
         L.mm_run_reads_skip_ambiguous_device_async.argtypes = reads_skip_args + [vp]
         L.mm_run_reads_skip_ambiguous_device.argtypes = reads_skip_args + [u64p]
         L.mm_pack_ascii_n_device_async.argtypes = [vp, vp, C.c_uint64, vp, vp]
+        L.mm_host_alloc.argtypes = [C.POINTER(vp), C.c_uint64]
+        L.mm_host_free.argtypes = [vp]
+        L.mm_host_free.restype = None
         L.mm_pack_ascii_device_async.argtypes = [vp, vp, C.c_uint64, vp]
         L.mm_generate_device_async.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
         _lib = L
@@ -141,6 +144,7 @@ EXPORTED_SYMBOLS = [
     "mm_run_skip_ambiguous_device_async", "mm_run_skip_ambiguous_device", "mm_run_skip_ambiguous_host",
     "mm_run_skip_ambiguous_host_ascii", "mm_run_reads_skip_ambiguous_device_async",
     "mm_run_reads_skip_ambiguous_device", "mm_pack_ascii_n_device_async", "mm_pack_ascii_device_async",
+    "mm_host_alloc", "mm_host_free",
     "mm_generate_device_async",
 ]
 
@@ -577,6 +581,28 @@ def run_reads_device(builder: "Builder", d_packed, n_reads, read_stride, read_le
         return cnt.value
     _check(fasync(*args, C.c_void_p(d_count.data_ptr()) if d_count is not None else None))
     return None
+
+
+def pinned_array(shape, dtype):
+    """numpy array backed by page-locked host memory (mm_host_alloc); keep the returned owner alive."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    _check(lib().mm_host_alloc(C.byref(p), max(n, 1)))
+
+    class _Owner:
+        def __init__(self, ptr):
+            self.ptr = ptr
+
+        def __del__(self):
+            try:
+                lib().mm_host_free(self.ptr)
+            except Exception:
+                pass
+
+    owner = _Owner(p)
+    buf = (C.c_uint8 * max(n, 1)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    return arr, owner
 
 
 def minimizers(k, w):  # src/lib.rs:240

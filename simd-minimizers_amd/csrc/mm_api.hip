@@ -100,6 +100,10 @@ struct mm_workspace {
     // skip-ambiguous path: window ambiguity bits, staged ambiguity bits of the host entry points
     uint32_t *wamb = nullptr;
     uint64_t wamb_dwords = 0;
+    // pipelined host entry point: copy streams, per-chunk events and pinned running totals
+    hipStream_t copy_in = nullptr, copy_out = nullptr;
+    hipEvent_t ev_in[16] = {}, ev_k[16] = {};
+    unsigned long long *h_pipe = nullptr;  // [16][2]
     // batch mode tables (sequence descriptors, tile -> sequence, per-sequence offsets)
     mm::BatchSeq *batch_seqs = nullptr;
     uint64_t batch_seqs_n = 0;
@@ -304,6 +308,13 @@ void mm_workspace_destroy(mm_workspace_t *ws) {
     if (ws->d_out) hipFree(ws->d_out);
     if (ws->d_sk) hipFree(ws->d_sk);
     if (ws->wamb) hipFree(ws->wamb);
+    if (ws->copy_in) hipStreamDestroy(ws->copy_in);
+    if (ws->copy_out) hipStreamDestroy(ws->copy_out);
+    for (int i = 0; i < 16; ++i) {
+        if (ws->ev_in[i]) hipEventDestroy(ws->ev_in[i]);
+        if (ws->ev_k[i]) hipEventDestroy(ws->ev_k[i]);
+    }
+    if (ws->h_pipe) hipHostFree(ws->h_pipe);
     if (ws->batch_seqs) hipFree(ws->batch_seqs);
     if (ws->batch_tiles) hipFree(ws->batch_tiles);
     if (ws->batch_offsets) hipFree(ws->batch_offsets);
@@ -941,6 +952,126 @@ static int run_host_common(const mm_plan_t *plan, mm_workspace_t *ws, const void
     return MM_OK;
 }
 
+// Host entry point for long sequences, pipelined: the window range is cut into chunks; while chunk
+// c is computed, chunk c+1's bytes travel host -> device and chunk c-1's positions device -> host
+// on two copy streams (the link is full duplex; the kernel itself is ~2 % of the call).
+// Returns MM_PIPE_FALLBACK if the caller should take the one-shot path instead.
+static const int MM_PIPE_FALLBACK = 1;
+static const uint64_t kPipeMinWindows = 48ull << 20;
+
+static int run_host_pipelined(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed,
+                              uint64_t base_offset, uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk,
+                              uint64_t capacity, uint64_t *out_count) {
+    const uint64_t l = (uint64_t)plan->k + plan->w - 1;
+    const uint64_t n_w = n_bases >= l ? n_bases - l + 1 : 0;
+    if (!out_pos || n_w < kPipeMinWindows || getenv("MM_NO_PIPELINE")) return MM_PIPE_FALLBACK;
+    const uint64_t cap = capacity < n_w ? capacity : n_w;
+    if (cap == 0) return MM_PIPE_FALLBACK;
+    const uint64_t bytes = (base_offset + n_bases + 3) / 4;
+    int r = grow(ws->d_out, ws->d_out_elems, cap, sizeof(uint32_t));
+    if (r) return r;
+    if (out_sk) {
+        r = grow(ws->d_sk, ws->d_sk_elems, cap, sizeof(uint32_t));
+        if (r) return r;
+    }
+    if (!ws->copy_in) {
+        MM_HIP(hipStreamCreateWithFlags(&ws->copy_in, hipStreamNonBlocking));
+        MM_HIP(hipStreamCreateWithFlags(&ws->copy_out, hipStreamNonBlocking));
+        for (int i = 0; i < 16; ++i) {
+            MM_HIP(hipEventCreateWithFlags(&ws->ev_in[i], hipEventDisableTiming));
+            MM_HIP(hipEventCreateWithFlags(&ws->ev_k[i], hipEventDisableTiming));
+        }
+        MM_HIP(hipHostMalloc(reinterpret_cast<void **>(&ws->h_pipe), 16 * 2 * sizeof(unsigned long long),
+                             hipHostMallocDefault));
+    }
+    uint64_t n_chunks = n_w / (24ull << 20);
+    if (n_chunks < 2) n_chunks = 2;
+    if (n_chunks > 16) n_chunks = 16;
+    const uint64_t chunk = (n_w + n_chunks - 1) / n_chunks;
+    uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
+
+    uint64_t sent = 0;        // bytes already on their way to the device
+    uint64_t done_total = 0;  // running total after the last drained chunk
+    bool failed = false, over = false;
+    auto drain = [&](uint64_t c) -> int {
+        MM_HIP(hipEventSynchronize(ws->ev_k[c]));
+        const uint64_t tot = ws->h_pipe[2 * c], err = ws->h_pipe[2 * c + 1];
+        if (err) failed = true;
+        if (tot > cap) over = true;
+        if (!failed && !over && tot > done_total) {
+            MM_HIP(hipStreamWaitEvent(ws->copy_out, ws->ev_k[c], 0));
+            MM_HIP(hipMemcpyAsync(out_pos + done_total, ws->d_out + done_total,
+                                  (tot - done_total) * sizeof(uint32_t), hipMemcpyDeviceToHost, ws->copy_out));
+            if (out_sk)
+                MM_HIP(hipMemcpyAsync(out_sk + done_total, ws->d_sk + done_total,
+                                      (tot - done_total) * sizeof(uint32_t), hipMemcpyDeviceToHost, ws->copy_out));
+        }
+        done_total = tot;
+        return MM_OK;
+    };
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+        const uint64_t wb = c * chunk, we = (wb + chunk < n_w) ? wb + chunk : n_w;
+        if (wb >= we) {
+            n_chunks = c;
+            break;
+        }
+        // bytes that hold the bases of windows < we (the last one ends at base we + l - 2)
+        uint64_t need = (base_offset + we + l - 2) / 4 + 1;
+        if (need > bytes || we == n_w) need = bytes;
+        if (need > sent) {
+            MM_HIP(hipMemcpyAsync(din + sent, packed + sent, need - sent, hipMemcpyHostToDevice, ws->copy_in));
+            sent = need;
+        }
+        MM_HIP(hipEventRecord(ws->ev_in[c], ws->copy_in));
+        MM_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in[c], 0));
+        r = run_device_async_impl(plan, ws, ws->d_in, bytes + 16, base_offset, n_bases, wb, we, ws->d_out,
+                                  out_sk ? ws->d_sk : nullptr, cap, nullptr, c != 0);
+        if (r) return r;
+        MM_HIP(hipMemcpyAsync(&ws->h_pipe[2 * c], ws->total, 2 * sizeof(unsigned long long),
+                              hipMemcpyDeviceToHost, ws->stream));
+        MM_HIP(hipEventRecord(ws->ev_k[c], ws->stream));
+        if (c > 0) {
+            r = drain(c - 1);
+            if (r) return r;
+        }
+    }
+    if (n_chunks > 0) {
+        r = drain(n_chunks - 1);
+        if (r) return r;
+    }
+    MM_HIP(hipStreamSynchronize(ws->copy_out));
+    MM_HIP(hipStreamSynchronize(ws->stream));
+    if (failed) {
+        // a look-back spin ran out in some chunk: redo the whole call in ticket mode, one shot
+        if (ws->force_ticket) {
+            g_last_error = "look-back scan timed out in ticket mode";
+            return MM_ERR_HIP;
+        }
+        ws->force_ticket = true;
+        return MM_PIPE_FALLBACK;
+    }
+    if (out_count) *out_count = done_total;
+    return over || done_total > capacity ? MM_ERR_CAPACITY : MM_OK;
+}
+
+int mm_host_alloc(void **out, uint64_t bytes) {
+    if (!out) return MM_ERR_NULL;
+    *out = nullptr;
+    if (bytes == 0) return MM_OK;
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+        return MM_ERR_ALLOC;
+    }
+    *out = p;
+    return MM_OK;
+}
+
+void mm_host_free(void *p) {
+    if (p) hipHostFree(p);
+}
+
 int mm_run_host(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed,
                 uint64_t base_offset, uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk,
                 uint64_t capacity, uint64_t *out_count) {
@@ -955,6 +1086,8 @@ int mm_run_host(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed
     if (r) return r;
     if (bytes) {
         if (!packed) return MM_ERR_NULL;
+        r = run_host_pipelined(plan, ws, packed, base_offset, n_bases, out_pos, out_sk, capacity, out_count);
+        if (r != MM_PIPE_FALLBACK) return r;
         MM_HIP(hipMemcpyAsync(ws->d_in, packed, bytes, hipMemcpyHostToDevice, ws->stream));
     }
     return run_host_common(plan, ws, ws->d_in, bytes + 16, base_offset, n_bases, out_pos, out_sk,

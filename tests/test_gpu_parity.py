@@ -864,3 +864,47 @@ def test_runtime_specialised_window_sizes(sm, oracle, gpu, k, w, canonical):
     # reads mode
     _check_reads(sm, oracle, k, w, canonical, 0, 300, 400, 397, None, 1, 60 + w)
     assert gpu.last_path() == sm.PATH_FUSED
+
+
+def test_host_entry_point_pipelined(sm, oracle, gpu):
+    """Long sequences take the pipelined host path (chunks: H2D, kernel and D2H overlapped on
+    three streams): identical to the device-resident run, with super-k-mer indices, with a non-zero
+    base offset, and with a capacity that is too small."""
+    import ctypes as C
+    import torch
+    n = 70_000_000
+    data = oracle.gen_packed(21, n + 8)
+    d = torch.from_numpy(data).cuda()
+    L = sm.lib()
+    u8p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+    for k, w, canonical, mode, use_sk, off in [(21, 11, True, 0, False, 0), (21, 11, False, 0, True, 3),
+                                                (15, 17, True, 1, False, 1)]:
+        b = sm.Builder(k, w, canonical, mode)
+        cap = int(n * 0.2)
+        dev_out = torch.zeros(cap, dtype=torch.int32, device="cuda")
+        dev_sk = torch.zeros(cap, dtype=torch.int32, device="cuda") if use_sk else None
+        c_dev = b.run_device(d, n, dev_out, out_sk=dev_sk, base_offset=off)
+        want = dev_out[:c_dev].cpu().numpy().view(np.uint32)
+        pos = np.zeros(cap, dtype=np.uint32)
+        sk = np.zeros(cap, dtype=np.uint32) if use_sk else None
+        cnt = C.c_uint64()
+        sm._check(L.mm_run_host(b.plan().h, gpu.h, data.ctypes.data_as(u8p), off, n, pos.ctypes.data_as(u32p),
+                                sk.ctypes.data_as(u32p) if use_sk else None, cap, C.byref(cnt)))
+        assert cnt.value == c_dev
+        assert np.array_equal(pos[:c_dev], want), (k, w, mode)
+        if use_sk:
+            assert np.array_equal(sk[:c_dev], dev_sk[:c_dev].cpu().numpy().view(np.uint32))
+        # the one-shot path gives the same
+        os.environ["MM_NO_PIPELINE"] = "1"
+        try:
+            pos2 = np.zeros(cap, dtype=np.uint32)
+            sm._check(L.mm_run_host(b.plan().h, gpu.h, data.ctypes.data_as(u8p), off, n, pos2.ctypes.data_as(u32p),
+                                    None, cap, C.byref(cnt)))
+            assert cnt.value == c_dev and np.array_equal(pos2[:c_dev], want)
+        finally:
+            del os.environ["MM_NO_PIPELINE"]
+    # capacity too small: the needed count comes back with the error
+    small = np.zeros(1000, dtype=np.uint32)
+    code = L.mm_run_host(b.plan().h, gpu.h, data.ctypes.data_as(u8p), 0, n, small.ctypes.data_as(u32p), None, 1000,
+                         C.byref(cnt))
+    assert code == sm.ERR["CAPACITY"] and cnt.value > 1000

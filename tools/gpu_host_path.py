@@ -8,11 +8,15 @@ import mm_oracle as oracle
 import simd_minimizers_amd as sm
 L = sm.lib()
 ws = sm.default_workspace(0)
-for n in (16 << 20, 256 << 20, 1 << 30):
+for n, pinned in [(16 << 20, False), (256 << 20, False), (256 << 20, True), (1 << 30, False), (1 << 30, True)]:
     data = oracle.gen_packed(2, n)
+    if pinned:
+        pd, own1 = sm.pinned_array(data.shape, np.uint8); pd[:] = data; data = pd
     plan = sm.Plan(21, 11, True, 0, None)
     cap = int(n * 0.2)
     pos = np.ones(cap, dtype=np.uint32)
+    if pinned:
+        pos, own2 = sm.pinned_array((cap,), np.uint32); pos[:] = 1
     cnt = C.c_uint64()
     u8p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
     def run():
@@ -22,5 +26,5 @@ for n in (16 << 20, 256 << 20, 1 << 30):
     reps = 5
     for _ in range(reps): run()
     dt = (time.perf_counter() - t0) / reps
-    print(f"n={n}: {dt*1e3:.2f} ms per call, {n/dt/1e9:.1f} Gbases/s, {cnt.value} positions "
+    print(f"n={n} pinned={pinned}: {dt*1e3:.2f} ms per call, {n/dt/1e9:.1f} Gbases/s, {cnt.value} positions "
           f"({(n/4 + 4*cnt.value)/dt/1e9:.1f} GB/s over PCIe)", flush=True)

@@ -31,6 +31,27 @@ int main() {
         rate("D2H registered", pageable, d, hipMemcpyDeviceToHost);
         t0 = now(); hipHostUnregister(pageable); printf("hipHostUnregister: %.1f ms\n", (now() - t0) * 1e3);
     }
+    // both directions at once on two streams
+    {
+        void *d2; hipMalloc(&d2, n);
+        char *pinned2; hipHostMalloc((void **)&pinned2, n, hipHostMallocDefault); memset(pinned2, 2, n);
+        char *pageable2 = (char *)aligned_alloc(4096, n); memset(pageable2, 3, n);
+        hipStream_t s2; hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+        hipStream_t s1; hipStreamCreateWithFlags(&s1, hipStreamNonBlocking);
+        auto both = [&](const char *what, void *hsrc, void *hdst) {
+            hipMemcpyAsync(d, hsrc, n, hipMemcpyHostToDevice, s1); hipMemcpyAsync(hdst, d2, n, hipMemcpyDeviceToHost, s2);
+            hipStreamSynchronize(s1); hipStreamSynchronize(s2);
+            double t0 = now();
+            for (int i = 0; i < 3; ++i) {
+                hipMemcpyAsync(d, hsrc, n, hipMemcpyHostToDevice, s1);
+                hipMemcpyAsync(hdst, d2, n, hipMemcpyDeviceToHost, s2);
+            }
+            hipStreamSynchronize(s1); hipStreamSynchronize(s2);
+            printf("%-28s %6.1f GB/s aggregate\n", what, 6.0 * n / (now() - t0) / 1e9);
+        };
+        both("H2D + D2H pinned", pinned, pinned2);
+        both("H2D + D2H pageable", pageable, pageable2);
+    }
     t0 = now(); memcpy(pinned, pageable, n); printf("host memcpy 1 thread: %.1f GB/s\n", n / (now() - t0) / 1e9);
     return 0;
 }
