@@ -11,7 +11,8 @@
 #include <stdint.h>
 
 #ifndef MM_LB_SLEEP
-#define MM_LB_SLEEP 2  // s_sleep argument (x 64 clocks) between two polls of a pending predecessor
+#define MM_LB_SLEEP 120  // fused kernel: s_sleep argument (x 64 clocks, the maximum) between two polls of
+                         // the nearest missing predecessor; shorter intervals measure slower
 #endif
 #ifndef MM_LB_FIRST
 #define MM_LB_FIRST 1  // 64-status chunks of the first look-back hop (1 measured best; then 4, 16)
@@ -153,7 +154,7 @@ __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long l
                         s[c] = kFlagIncl;
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(MM_LB_SLEEP);
+                    __builtin_amdgcn_s_sleep(2);
                     s[c] = ld_status(&status[idx]);
                 }
                 const unsigned long long incl_mask = __ballot((s[c] >> 62) == 2);

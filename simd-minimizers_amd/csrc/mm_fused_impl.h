@@ -27,6 +27,9 @@
 #pragma once
 #include "mm_common.h"
 
+#ifndef MM_LB_SLEEP_SHORT
+#define MM_LB_SLEEP_SHORT 120
+#endif
 #ifndef MM_STORE_AUX
 #define MM_STORE_AUX 2  // cache policy bits of the copy-out stores: slc (streaming), measured +1 %
 #endif
@@ -508,6 +511,79 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     return (lp32 - list0) / kListStride + dropped;
 }
 
+__device__ __forceinline__ void publish_aggregate(unsigned long long *status, uint32_t bid, uint32_t total) {
+    st_status(&status[bid], kFlagAgg | ((unsigned long long)total & kValMask));
+}
+
+// Look-back of a tile run by wave 0 alone while the other waves of the workgroup may still be in
+// phase 1 (every wave bumps *done when it finishes, its total is then in wave_tot[]; the last one
+// publishes the tile's aggregate itself).  The wave scans the predecessors without blocking on the
+// nearest missing one, consumes what is there (nearest first), and publishes the inclusive prefix
+// when the prefix and the tile's own total are both known.
+// Status words and bounds as in lookback_exclusive (mm_common.h).  Returns the exclusive prefix.
+__device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long long *status, uint32_t bid,
+                                                                  unsigned long long carry_in, uint32_t *error,
+                                                                  uint32_t *done, const uint32_t *wave_tot) {
+    const int lane = threadIdx.x & (kWave - 1);
+    bool have_excl = (bid == 0);
+    unsigned long long excl = (bid == 0) ? carry_in : 0ull;
+    long long j = (long long)bid - 1;
+    unsigned long long block_total = 0;
+    uint32_t idle = 0;
+    while (true) {
+        bool progress = false;
+        if (!have_excl) {
+            const long long idx = j - lane;
+            const unsigned long long s = idx >= 0 ? ld_status(&status[idx]) : kFlagIncl;
+            const unsigned long long zmask = __ballot((s >> 62) == 0);
+            const unsigned long long pmask = __ballot((s >> 62) == 2);
+            const int first_zero = zmask ? __builtin_ctzll(zmask) : kWave;
+            const int first_p = pmask ? __builtin_ctzll(pmask) : kWave;
+            const int take = first_p < first_zero ? first_p + 1 : first_zero;  // lanes [0, take) count
+            unsigned long long v = lane < take ? (s & kValMask) : 0ull;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+            excl += v;
+            if (first_p < first_zero) have_excl = true;
+            else j -= take;
+            progress = take > 0;
+        } else {
+            // the prefix is known: wait for the other waves of this workgroup
+            const uint32_t dn = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t *>(done));
+            if (dn == (uint32_t)kFusedWaves) {
+#pragma unroll
+                for (int v = 0; v < kFusedWaves; ++v) block_total += reinterpret_cast<const volatile uint32_t *>(wave_tot)[v];
+                break;
+            }
+        }
+        if (!progress) {
+            // Nothing new.  Waiting for a wave of this workgroup costs nothing (LDS); waiting for a
+            // predecessor polls ONE status word (the nearest missing one, status[j]) with one lane:
+            // a 64-wide poll through the device-coherent path every few hundred clocks by a thousand
+            // waiting tiles slows the whole chip down.
+            if (++idle > kMaxLookbackSpins) {
+                *error = 1u;  // dispatch-order violation: the host redoes the launch in ticket mode
+                if (have_excl) break;
+                have_excl = true;
+            }
+            if (!have_excl) {
+                unsigned long long s0 = 0;
+                for (uint32_t spins = 0; spins < 64u; ++spins) {
+                    __builtin_amdgcn_s_sleep(MM_LB_SLEEP);
+                    if (lane == 0) s0 = ld_status(&status[j]);
+                    s0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(s0 >> 32)) << 32) |
+                         (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)s0);
+                    if ((s0 >> 62) != 0) break;
+                }
+            } else {
+                __builtin_amdgcn_s_sleep(MM_LB_SLEEP_SHORT);
+            }
+        }
+    }
+    if (lane == 0) st_status(&status[bid], kFlagIncl | ((excl + block_total) & kValMask));
+    return excl;
+}
+
 // READS = false: one sequence (range of windows), lane t walks windows [t*S, (t+1)*S) of the tile.
 // READS = true : a batch of short reads at a fixed stride, lane t walks read (tile*256 + t) alone;
 //                positions are read-local and read_offsets[] delimits the reads in the output.
@@ -518,6 +594,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     __shared__ uint2 s_tab[20];  // [0..15] (out<<2)|in, [16..19] in only (warm-up)
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_overflow;
+    __shared__ uint32_t s_done;  // waves 1.. that have finished phase 1
     __shared__ uint32_t s_wave_tot[kFusedWaves];
     __shared__ unsigned long long s_excl;
 
@@ -532,6 +609,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     if (tid == 0) {
         s_bid = p.use_ticket ? atomicAdd(p.out.ticket, 1u) : blockIdx.x;
         s_overflow = 0;
+        s_done = 0;
     }
     if (tid < 16) s_tab[tid] = p.ht.t_in_out[tid];
     else if (tid < 20) s_tab[tid] = p.ht.t_in[tid - 16];
@@ -545,8 +623,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         p.trace[10 * (size_t)bid + 4] = ((unsigned long long)xcc << 32) | hw;
     }
 
-    const uint32_t nblk_t = p.nblk;
-    const uint32_t S = (uint32_t)W * nblk_t;
+    const uint32_t S = (uint32_t)W * p.nblk;
     const uint32_t NB = kFusedThreads * S;
     // (one 32 x 32 -> 64-bit product: stays on the scalar unit, so everything derived from the tile
     // origin - the buffer descriptors of the sequence loads above all - lives in SGPRs)
@@ -596,7 +673,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     ctx.list = smem + 2u * (uint32_t)tid;
     ctx.list_bytes = p.list_cap * kListStride;
     ctx.dst = 0;
-    ctx.nblk = nblk_t;
+    ctx.nblk = p.nblk;
     ctx.seq_d = seq_d;
     ctx.seq_dwords = seq_dwords;
     bool lane_active, lane_in = false;  // lane_in: the lane owns a read (which may have no window)
@@ -640,9 +717,29 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     if (p.trace && tid == 0) p.trace[10 * (size_t)bid + 1] = wall_clock64();
     const uint32_t incl = wave_scan_dpp(my_count);
     const uint32_t wave_total = __builtin_amdgcn_readlane(incl, kWave - 1);
-    if (lane == 0) s_wave_tot[wave] = wave_total;
+    if (lane == 0) {
+        s_wave_tot[wave] = wave_total;
+        // LDS, in order behind the store above.  The wave that finishes phase 1 last publishes the
+        // tile's aggregate at once (successors wait for that, never for this tile's look-back).
+        if (atomicAdd(&s_done, 1u) == (uint32_t)(kFusedWaves - 1) && bid != 0 && !(p.debug & 1u)) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int v = 0; v < kFusedWaves; ++v) tot += reinterpret_cast<volatile uint32_t *>(s_wave_tot)[v];
+            publish_aggregate(p.out.status, bid, tot);
+        }
+    }
+    if (wave == 0) {
+        // Wave 0 runs the look-back (non-blocking, see lookback_overlapped) as soon as its own lanes
+        // are done; the wave that finishes last has published the tile's aggregate.
+        const unsigned long long carry = (bid == 0) ? *p.out.total : 0ull;
+        const unsigned long long ex =
+            (p.debug & 1u) ? (unsigned long long)bid * (NB / 6u)
+                           : lookback_overlapped(p.out.status, bid, carry, p.out.error, &s_done, s_wave_tot);
+        if (lane == 0) s_excl = ex;
+        if (p.trace && lane == 0) p.trace[10 * (size_t)bid + 2] = wall_clock64();
+    }
     __syncthreads();
-    if (p.trace && tid == 0) p.trace[10 * (size_t)bid + 5] = wall_clock64();
+    if (p.trace && tid == 0) p.trace[10 * (size_t)bid + 5] = p.trace[10 * (size_t)bid + 1];
     uint32_t wave_base = 0, block_total = 0;
 #pragma unroll
     for (int v = 0; v < kFusedWaves; ++v) {
@@ -651,15 +748,6 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         block_total += t;
     }
     const bool overflow = s_overflow != 0;
-    if (wave == 0) {
-        const unsigned long long carry = (bid == 0) ? *p.out.total : 0ull;
-        const unsigned long long ex =
-            (p.debug & 1u) ? (unsigned long long)bid * (NB / 6u)
-                           : lookback_exclusive(p.out.status, bid, block_total, carry, p.out.error);
-        if (lane == 0) s_excl = ex;
-        if (p.trace && lane == 0) p.trace[10 * (size_t)bid + 2] = wall_clock64();
-    }
-    __syncthreads();
     const unsigned long long run0 = s_excl + wave_base;  // first output slot of this wave
     const uint32_t excl = incl - my_count;
     if (READS && lane_in) p.read_offsets[read0 + (uint32_t)tid] = run0 + excl;
