@@ -30,6 +30,9 @@
 #ifndef MM_LB_SLEEP_SHORT
 #define MM_LB_SLEEP_SHORT 120
 #endif
+#ifndef MM_STORE_MOD
+#define MM_STORE_MOD "nt"  // cache policy of the copy-out stores (fast path); see MM_STORE_AUX
+#endif
 #ifndef MM_STORE_AUX
 #define MM_STORE_AUX 2  // cache policy bits of the copy-out stores: slc (streaming), measured +1 %
 #endif
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
                             "s_mov_b64 %[sv], exec\n\t"
                             "s_bfm_b64 exec, %[t0], 0\n\t"
                             "s_lshl_b32 %[t0], %[off], 2\n\t"
-                            "buffer_store_dword %[val], %[lane4], %[desc], %[t0] offen nt\n\t"
+                            "buffer_store_dword %[val], %[lane4], %[desc], %[t0] offen " MM_STORE_MOD "\n\t"
                             "s_mov_b64 exec, %[sv]"
                             : [t0] "=&s"(t0), [sv] "=&s"(sv)
                             : [n] "s"(n), [off] "s"(off), [val] "v"(val), [lane4] "v"(lane4), [desc] "s"(odesc),
