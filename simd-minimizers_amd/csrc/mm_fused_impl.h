@@ -514,6 +514,9 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     return (lp32 - list0) / kListStride + dropped;
 }
 
+// a no-progress round of lookback_overlapped sleeps up to 64 x 3.5 us: give up after about a second
+constexpr uint32_t kMaxIdleRounds = 1u << 12;
+
 __device__ __forceinline__ void publish_aggregate(unsigned long long *status, uint32_t bid, uint32_t total) {
     st_status(&status[bid], kFlagAgg | ((unsigned long long)total & kValMask));
 }
@@ -564,7 +567,7 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
             // predecessor polls ONE status word (the nearest missing one, status[j]) with one lane:
             // a 64-wide poll through the device-coherent path every few hundred clocks by a thousand
             // waiting tiles slows the whole chip down.
-            if (++idle > kMaxLookbackSpins) {
+            if (++idle > kMaxIdleRounds) {
                 *error = 1u;  // dispatch-order violation: the host redoes the launch in ticket mode
                 if (have_excl) break;
                 have_excl = true;
