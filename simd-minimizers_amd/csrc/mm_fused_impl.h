@@ -117,6 +117,17 @@ __device__ __forceinline__ uint32_t select3(uint32_t m, uint32_t a, uint32_t b) 
     return r;
 }
 
+// The skip-ambiguous walk of full tiles carries two bodies per block (fast emit for blocks without a
+// skipped window, flag path otherwise); for larger W that costs registers and with them occupancy of
+// the whole kernel, so only small window sizes get it (the others walk with the flag path throughout).
+template <int W>
+constexpr bool kAmbiFastBlocks = W <= 12;
+
+template <bool B>
+struct BoolTag {
+    static constexpr bool value = B;
+};
+
 // What one lane needs to walk its windows.
 struct LaneCtx {
     const uint2 *tab;        // LDS hash tables
@@ -297,7 +308,6 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // skip-ambiguous windows: one bit per window, 32-window views prefetched one block ahead.
     // A skipped window emits nothing and (like the SIMD collector, src/intrinsics/dedup.rs:147-155)
     // never equals its successor, so the first clean window after it always emits.
-    static_assert(!AMBI || PARTIAL, "AMBI walks use the flag path");
     constexpr int NSUBA = AMBI ? (W + 31) / 32 : 1;
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(AMBI ? p.wamb : ctx.seq_d), 0, AMBI ? (int)(p.wamb_dwords * 4u) : 0, 0x00020000);
@@ -390,6 +400,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         };
 #pragma unroll
         for (int j = 0; j < PF; ++j) tq[j] = lookup(j);
+        // The W steps of the block.  FE (fast emit): the exec-masked append in inline assembly, legal
+        // when every window of the block is inside the range and none is skipped.
+        auto steps = [&](auto fe_tag) {
+        constexpr bool FE = decltype(fe_tag)::value;
 #pragma unroll
         for (int j = 0; j < W; ++j) {
             const uint32_t e = e0 + (uint32_t)j;  // uniform
@@ -426,7 +440,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             }
             // window i = e - W starts at element i + 1
             const uint32_t i = e - (uint32_t)W;  // uniform
-            if (!DIRECT && !PARTIAL && !SK) {
+            if (FE) {
                 // Common path: compare, and under the resulting exec mask append the 16-bit value
                 // to the lane's list and advance its slot pointer (2 VALU + 2 SALU + 1 LDS).
                 unsigned long long sv;
@@ -502,6 +516,22 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t.x;
             if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t.y;
             if (CANON) dn += __builtin_amdgcn_sbfe((int)tgw[j >> 4], 2 * (j & 15), 2);
+        }
+        };  // steps
+        constexpr bool kFastEmit = !DIRECT && !PARTIAL && !SK;
+        if (AMBI && kFastEmit && kAmbiFastBlocks<W>) {
+            // skip-ambiguous walk of a full tile: blocks in which no lane of the wave has a skipped
+            // window (all of a genome but its gaps) take the fast path
+            uint32_t any = 0;
+#pragma unroll
+            for (int g = 0; g < NSUBA; ++g) {
+                const int bits = W - 32 * g;
+                any |= bits >= 32 ? aw[g] : (aw[g] & ((1u << (bits > 0 ? bits : 0)) - 1u));
+            }
+            if (__ballot(any != 0) == 0) steps(BoolTag<kFastEmit>{});
+            else steps(BoolTag<false>{});
+        } else {
+            steps(BoolTag<kFastEmit>{});
         }
 #pragma unroll
         for (int j = W - 2; j >= 0; --j) {
@@ -712,7 +742,10 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     uint32_t my_count = 0;
     if (lane_active && !(p.debug & 4u)) {
         bool over = false;
-        if (kAmbi && p.wamb) my_count = lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi>(p, ctx, over);
+        if (kAmbi && p.wamb)
+            my_count = (READS || partial || !kAmbiFastBlocks<W>)
+                           ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi>(p, ctx, over)
+                           : lane_walk<W, CANON, HASH_RC, MODE, SK, false, kAmbi && !kAmbiFastBlocks<W>, kAmbi>(p, ctx, over);
         else if (READS) my_count = lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over);
         else my_count = partial ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over)
                                 : lane_walk<W, CANON, HASH_RC, MODE, SK, false, false>(p, ctx, over);
