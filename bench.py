@@ -82,6 +82,12 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # Libraries print banners to stdout (RCCL does when its communicator comes up); the contract is ONE
+    # JSON line on stdout, so everything before it goes to stderr.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -185,7 +191,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if distributed:
         dist.destroy_process_group()
 
