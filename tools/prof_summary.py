@@ -11,6 +11,15 @@ def summarize(path, out):
     except Exception as e:
         out.write(f"(no top_kernels: {e})\n")
     try:
+        # the stats average includes the untimed warm-up launches (clock ramp after idle): list them
+        d = [r[0] / 1e3 for r in cur.execute("select (end - start) from kernels where name like '%fused_kernel%' order by start")]
+        if len(d) >= 4:
+            half = d[len(d) // 2:]
+            out.write("-- fused_kernel launches in order, us: " + " ".join(f"{x:.0f}" for x in d) + "\n")
+            out.write(f"-- average of the second half ({len(half)} launches, the timed steps): {sum(half) / len(half):.1f} us\n")
+    except Exception as e:
+        out.write(f"(no per-launch durations: {e})\n")
+    try:
         rows = list(cur.execute("select kernel_name,counter_name,value,duration,grid_size,workgroup_size,lds_block_size,vgpr_count,sgpr_count from counters_collection"))
         if rows:
             out.write("-- counters (kernel, counter, value, duration_ns, grid, wg, lds, vgpr, sgpr)\n")
