@@ -117,11 +117,12 @@ __device__ __forceinline__ uint32_t select3(uint32_t m, uint32_t a, uint32_t b) 
     return r;
 }
 
-// The skip-ambiguous walk of full tiles carries two bodies per block (fast emit for blocks without a
-// skipped window, flag path otherwise); for larger W that costs registers and with them occupancy of
-// the whole kernel, so only small window sizes get it (the others walk with the flag path throughout).
+// Walks whose blocks are not all inside the range or may hold skipped windows (reads, the last tile of
+// a range, skip-ambiguous runs) carry two bodies per block: the fast exec-masked emit for blocks that
+// qualify, the flag path otherwise.  For larger W that costs registers and with them occupancy of the
+// whole kernel, so only small window sizes get it (the others take the flag path throughout).
 template <int W>
-constexpr bool kAmbiFastBlocks = W <= 12;
+constexpr bool kTwoBodies = W <= 12;
 
 template <bool B>
 struct BoolTag {
@@ -136,6 +137,7 @@ struct LaneCtx {
     uint32_t wbase;          // value of the lane's window 0 (absolute window index, or 0 for reads)
     bool no_prev;            // the lane's first window has no predecessor (always emits)
     int rem_valid;           // windows of this lane inside the range (PARTIAL walks only)
+    int min_rem;             // the smallest rem_valid among the walking lanes of the wave (wave-uniform)
     uint8_t *list;           // LDS: this lane's list slot 0 (list mode)
     uint32_t list_bytes;     // list_cap * kListStride (the super-k-mer list follows at +list_bytes)
     unsigned long long dst;  // first output slot of this lane (DIRECT mode)
@@ -518,20 +520,29 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             if (CANON) dn += __builtin_amdgcn_sbfe((int)tgw[j >> 4], 2 * (j & 15), 2);
         }
         };  // steps
-        constexpr bool kFastEmit = !DIRECT && !PARTIAL && !SK;
-        if (AMBI && kFastEmit && kAmbiFastBlocks<W>) {
-            // skip-ambiguous walk of a full tile: blocks in which no lane of the wave has a skipped
-            // window (all of a genome but its gaps) take the fast path
-            uint32_t any = 0;
+        // The inline-assembly emit needs every window of the block inside the range and none skipped.
+        // Full tiles of a plain sequence always qualify; walks that may not (range ends inside the
+        // tile, reads, skipped windows) carry both bodies and choose per block with a wave-uniform
+        // test - for small W only, see kTwoBodies.
+        constexpr bool kCanFast = !DIRECT && !SK;
+        if (kCanFast && !PARTIAL && !AMBI) {
+            steps(BoolTag<true>{});
+        } else if (kCanFast && kTwoBodies<W>) {
+            bool ok = true;
+            if (AMBI) {
+                uint32_t any = 0;
 #pragma unroll
-            for (int g = 0; g < NSUBA; ++g) {
-                const int bits = W - 32 * g;
-                any |= bits >= 32 ? aw[g] : (aw[g] & ((1u << (bits > 0 ? bits : 0)) - 1u));
+                for (int g = 0; g < NSUBA; ++g) {
+                    const int bits = W - 32 * g;
+                    any |= bits >= 32 ? aw[g] : (aw[g] & ((1u << (bits > 0 ? bits : 0)) - 1u));
+                }
+                ok = __ballot(any != 0) == 0;
             }
-            if (__ballot(any != 0) == 0) steps(BoolTag<kFastEmit>{});
+            if (PARTIAL) ok = ok && (int)(b * (uint32_t)W) <= ctx.min_rem;  // windows < b * W all valid
+            if (ok) steps(BoolTag<kCanFast && kTwoBodies<W>>{});
             else steps(BoolTag<false>{});
         } else {
-            steps(BoolTag<kFastEmit>{});
+            steps(BoolTag<false>{});
         }
 #pragma unroll
         for (int j = W - 2; j >= 0; --j) {
@@ -738,14 +749,22 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         ctx.abase = (uint32_t)bw0 + lw;
     }
 
+    {
+        // wave-uniform minimum of rem_valid over the lanes that walk (all lanes take part here)
+        int m = lane_active ? ctx.rem_valid : 0x7fffffff;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = min(m, __shfl_xor(m, d, kWave));
+        ctx.min_rem = __builtin_amdgcn_readfirstlane(m);
+    }
+
     // ---------------------------------------------------------------- phase 1
     uint32_t my_count = 0;
     if (lane_active && !(p.debug & 4u)) {
         bool over = false;
         if (kAmbi && p.wamb)
-            my_count = (READS || partial || !kAmbiFastBlocks<W>)
+            my_count = (READS || partial || !kTwoBodies<W>)
                            ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi>(p, ctx, over)
-                           : lane_walk<W, CANON, HASH_RC, MODE, SK, false, kAmbi && !kAmbiFastBlocks<W>, kAmbi>(p, ctx, over);
+                           : lane_walk<W, CANON, HASH_RC, MODE, SK, false, kAmbi && !kTwoBodies<W>, kAmbi>(p, ctx, over);
         else if (READS) my_count = lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over);
         else my_count = partial ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over)
                                 : lane_walk<W, CANON, HASH_RC, MODE, SK, false, false>(p, ctx, over);
