@@ -172,6 +172,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.win_end = (uint32_t)a.win_end;
     p.list_cap = g.list_cap;
     p.n_reads = 0;
+    p.reads_per_lane = 1;
     p.read_stride = p.read_len = 0;
     p.read_lens = nullptr;
     p.read_offsets = nullptr;
@@ -247,11 +248,25 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     const uint32_t nblk = (max_nw + a.w - 1) / a.w;  // every lane must be able to walk its whole read
     const uint32_t S = nblk * a.w;
     if (S + a.w > 60000u) return -3;
-    uint32_t cap = (uint32_t)(1.3 * emit_density(a.w, 0) * S) + 8u + a.w;
-    if (cap > S + a.w) cap = S + a.w;
+    // A lane walks R consecutive reads, so that a tile holds about as many windows as a tile of the
+    // sequence mode (fewer tiles: less look-back and copy-out overhead per window).  MM_READS_PER_LANE
+    // overrides (experiments).
+    auto cap_for = [&](uint32_t r) {
+        uint32_t c = (uint32_t)(1.3 * emit_density(a.w, 0) * S * r) + 8u + a.w;
+        return c > (S + a.w) * r ? (S + a.w) * r : c;
+    };
+    // as many reads per lane (up to 4) as keep the lists near 40 KB, i.e. 4 workgroups per CU
+    uint32_t R = 1;
+    while (R < 4u && cap_for(R + 1) * kListStride <= 40u * 1024u) ++R;
+    if (const char *e = getenv("MM_READS_PER_LANE")) R = (uint32_t)atoi(e);
+    if (R < 1u) R = 1u;
+    if (R > 4u) R = 4u;
+    const uint32_t cap = cap_for(R);
+    if (cap > 65535u) return -3;  // 16-bit per-read counts
     const uint32_t lds_bytes = cap * kListStride;
     if (lds_bytes > 159u * 1024u) return -3;
-    const uint64_t nblocks = (a.n_reads + kFusedThreads - 1) / kFusedThreads;
+    const uint64_t per_tile = (uint64_t)kFusedThreads * R;
+    const uint64_t nblocks = (a.n_reads + per_tile - 1) / per_tile;
     KernelRef kr;
     if (const FusedReadsInstance *inst = find_reads_instance(a.w, a.canonical_windows, (int)a.ht.canonical))
         kr.host = inst->fn;
@@ -270,6 +285,7 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.use_ticket = a.use_ticket ? 1u : 0u;
     p.debug = 0;
     p.n_reads = (uint32_t)a.n_reads;
+    p.reads_per_lane = R;
     p.read_stride = a.read_stride;
     p.read_len = a.read_len;
     p.read_lens = a.read_lens;

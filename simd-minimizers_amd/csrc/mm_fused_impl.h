@@ -60,6 +60,7 @@ struct FusedParams {
                          // 4 no phase 1
     // reads mode (READS kernels): one lane per read, reads at a fixed stride in the buffer
     uint32_t n_reads;
+    uint32_t reads_per_lane;            // READS: consecutive reads one lane walks one after the other (1..4)
     uint32_t read_stride;               // bases between the starts of consecutive reads
     uint32_t read_len;                  // length of every read, or the maximum when read_lens != null
     const uint32_t *read_lens;          // optional per-read lengths (device)
@@ -140,6 +141,7 @@ struct LaneCtx {
     int min_rem;             // the smallest rem_valid among the walking lanes of the wave (wave-uniform)
     uint8_t *list;           // LDS: this lane's list slot 0 (list mode)
     uint32_t list_bytes;     // list_cap * kListStride (the super-k-mer list follows at +list_bytes)
+    uint32_t list_used;      // entries already in the list (reads mode: earlier reads of the lane)
     unsigned long long dst;  // first output slot of this lane (DIRECT mode)
     uint32_t abase;          // bit of the lane's window 0 in FusedParams::wamb (AMBI walks)
     uint32_t nblk;           // W-blocks this lane walks
@@ -327,7 +329,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // ---- blocks 1..nblk: one window per step
     // next free list slot as a 32-bit LDS address (the low half of the flat address of LDS memory)
     const uint32_t list0 = (uint32_t)reinterpret_cast<uintptr_t>(ctx.list);
-    uint32_t lp32 = list0;
+    uint32_t lp32 = list0 + ctx.list_used * kListStride;
     const uint32_t lp_end = list0 + ctx.list_bytes;
     uint32_t dropped = 0;              // entries that did not fit the list
     uint32_t valreg = 0;
@@ -635,7 +637,9 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
 // READS = true : a batch of short reads at a fixed stride, lane t walks read (tile*256 + t) alone;
 //                positions are read-local and read_offsets[] delimits the reads in the output.
 template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool READS>
-__global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams p) {
+// (small W: at least 4 waves per SIMD, i.e. at most 128 VGPRs - the two-body walks sit right at that
+// limit; larger W need more registers and get no such bound)
+__global__ __launch_bounds__(kFusedThreads, (W <= 12 ? 4 : 1)) void fused_kernel(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // lane lists
     // static LDS: distinct objects, so table look-ups can be scheduled across the list stores
     __shared__ uint2 s_tab[20];  // [0..15] (out<<2)|in, [16..19] in only (warm-up)
@@ -723,21 +727,57 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     ctx.nblk = p.nblk;
     ctx.seq_d = seq_d;
     ctx.seq_dwords = seq_dwords;
-    bool lane_active, lane_in = false;  // lane_in: the lane owns a read (which may have no window)
-    const uint32_t read0 = bid * kFusedThreads;  // READS: first read of the tile
-    if (READS) {
-        const uint32_t r = read0 + (uint32_t)tid;
-        lane_in = r < p.n_reads;
-        const uint32_t len = lane_in ? (p.read_lens ? p.read_lens[r] : p.read_len) : 0u;
+    bool lane_active = false;
+    // READS: a lane walks reads_per_lane consecutive reads; read j of lane t is read
+    // (bid * 256 + t) * R + j of the batch
+    const uint32_t R = READS ? p.reads_per_lane : 1u;
+    const uint32_t tile_read0 = bid * kFusedThreads * R;          // first read of the tile
+    const uint32_t lane_read0 = tile_read0 + (uint32_t)tid * R;   // first read of the lane
+    ctx.list_used = 0;
+    // sets ctx up for read j of the lane (READS); returns whether the lane has windows to walk
+    auto setup_read = [&](uint32_t j) -> bool {
+        const uint32_t r = lane_read0 + j;
+        const bool in = r < p.n_reads;
+        const uint32_t len = in ? (p.read_lens ? p.read_lens[r] : p.read_len) : 0u;
         const uint32_t l = p.k + (uint32_t)W - 1u;
         const uint32_t nw = len >= l ? len - l + 1u : 0u;
-        lane_active = nw != 0u;
-        ctx.p0 = (long long)seq_base0 + (long long)read0 * p.read_stride - 1;
-        ctx.lane_bases = (uint32_t)tid * p.read_stride;
+        ctx.p0 = (long long)seq_base0 + (long long)tile_read0 * p.read_stride - 1;
+        ctx.lane_bases = ((uint32_t)tid * R + j) * p.read_stride;
         ctx.wbase = 0;
         ctx.no_prev = true;
         ctx.rem_valid = (int)(nw < S ? nw : S);
         ctx.abase = r * p.read_stride;
+        return nw != 0u;
+    };
+    // wave-uniform minimum of rem_valid over the lanes that walk (all lanes take part)
+    auto set_min_rem = [&](bool active) {
+        int m = active ? ctx.rem_valid : 0x7fffffff;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = min(m, __shfl_xor(m, d, kWave));
+        ctx.min_rem = __builtin_amdgcn_readfirstlane(m);
+    };
+
+    // ---------------------------------------------------------------- phase 1
+    uint32_t my_count = 0;
+    unsigned long long read_counts = 0;  // READS: 16 bits per read of the lane
+    if (READS) {
+        for (uint32_t j = 0; j < R; ++j) {
+            const bool act = setup_read(j);
+            set_min_rem(act);
+            ctx.list_used = my_count;
+            uint32_t c = 0;
+            if (act && !(p.debug & 4u)) {
+                bool over = false;
+                const uint32_t tot = (kAmbi && p.wamb)
+                                         ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi>(p, ctx, over)
+                                         : lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over);
+                c = tot - my_count;
+                if (over) s_overflow = 1;  // benign race: every writer stores 1
+            }
+            read_counts |= (unsigned long long)(c & 0xffffu) << (16u * j);
+            my_count += c;
+            lane_active = lane_active || act;
+        }
     } else {
         const uint32_t lw = (uint32_t)tid * S;  // first window of the lane, tile-relative
         lane_active = lw < nvalid;
@@ -747,28 +787,17 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
         ctx.no_prev = (bw0 + lw == 0);
         ctx.rem_valid = (int)nvalid - (int)lw;
         ctx.abase = (uint32_t)bw0 + lw;
-    }
-
-    {
-        // wave-uniform minimum of rem_valid over the lanes that walk (all lanes take part here)
-        int m = lane_active ? ctx.rem_valid : 0x7fffffff;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) m = min(m, __shfl_xor(m, d, kWave));
-        ctx.min_rem = __builtin_amdgcn_readfirstlane(m);
-    }
-
-    // ---------------------------------------------------------------- phase 1
-    uint32_t my_count = 0;
-    if (lane_active && !(p.debug & 4u)) {
-        bool over = false;
-        if (kAmbi && p.wamb)
-            my_count = (READS || partial || !kTwoBodies<W>)
-                           ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi>(p, ctx, over)
-                           : lane_walk<W, CANON, HASH_RC, MODE, SK, false, kAmbi && !kTwoBodies<W>, kAmbi>(p, ctx, over);
-        else if (READS) my_count = lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over);
-        else my_count = partial ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over)
-                                : lane_walk<W, CANON, HASH_RC, MODE, SK, false, false>(p, ctx, over);
-        if (over) s_overflow = 1;  // benign race: every writer stores 1
+        set_min_rem(lane_active);
+        if (lane_active && !(p.debug & 4u)) {
+            bool over = false;
+            if (kAmbi && p.wamb)
+                my_count = (partial || !kTwoBodies<W>)
+                               ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi>(p, ctx, over)
+                               : lane_walk<W, CANON, HASH_RC, MODE, SK, false, kAmbi && !kTwoBodies<W>, kAmbi>(p, ctx, over);
+            else my_count = partial ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over)
+                                    : lane_walk<W, CANON, HASH_RC, MODE, SK, false, false>(p, ctx, over);
+            if (over) s_overflow = 1;  // benign race: every writer stores 1
+        }
     }
 
     // ---------------------------------------------------------------- phase 2
@@ -808,7 +837,13 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
     const bool overflow = s_overflow != 0;
     const unsigned long long run0 = s_excl + wave_base;  // first output slot of this wave
     const uint32_t excl = incl - my_count;
-    if (READS && lane_in) p.read_offsets[read0 + (uint32_t)tid] = run0 + excl;
+    if (READS) {
+        unsigned long long o = run0 + excl;
+        for (uint32_t j = 0; j < R; ++j) {
+            if (lane_read0 + j < p.n_reads) p.read_offsets[lane_read0 + j] = o;
+            o += (read_counts >> (16u * j)) & 0xffffu;
+        }
+    }
     if (batch && tid == 0 && local_tile == 0) p.batch_offsets[batch_s] = s_excl;
 
     if (!overflow) {
@@ -929,12 +964,25 @@ __global__ __launch_bounds__(kFusedThreads) void fused_kernel(const FusedParams 
                 }
             }
         }
+    } else if (READS) {
+        // some list overflowed: walk the lane's reads again, now storing straight to the output
+        unsigned long long o = run0 + excl;
+        for (uint32_t j = 0; j < R; ++j) {
+            const bool act = setup_read(j);
+            ctx.dst = o;
+            bool over;
+            if (act) {
+                if (kAmbi && p.wamb) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true, kAmbi>(p, ctx, over);
+                else lane_walk<W, CANON, HASH_RC, MODE, SK, true, true>(p, ctx, over);
+            }
+            o += (read_counts >> (16u * j)) & 0xffffu;
+        }
     } else if (lane_active) {
         // some list overflowed: walk the tile again, now storing straight to the output
         ctx.dst = run0 + excl;
         bool over;
         if (kAmbi && p.wamb) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true, kAmbi>(p, ctx, over);
-        else if (READS || partial) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true>(p, ctx, over);
+        else if (partial) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true>(p, ctx, over);
         else lane_walk<W, CANON, HASH_RC, MODE, SK, true, false>(p, ctx, over);
     }
     if (p.trace) {
