@@ -9,6 +9,7 @@
  * that are NOT in the reference tree: their published behaviour is restated
  * here and anchored on the reference's doctest / unit-test vectors.
  */
+#define _POSIX_C_SOURCE 200809L /* pthread barriers under -std=c11 */
 #include "mm_oracle.h"
 
 #include <stdlib.h>
@@ -609,10 +610,51 @@ static void fast_range(fast_job *jb) {
     jb->count = m;
 }
 
+/* Worker of mmo_run_fast: walk the range into the thread's slot, wait for everybody, let worker 0
+ * turn the counts into offsets, then copy the slot to its place in the caller's array (the merge runs
+ * in parallel too: a serial merge of 180 MB per 256 Mbp would dominate with many threads). */
+typedef struct fast_shared {
+    pthread_barrier_t bar;
+    fast_job *jobs;
+    int threads;
+    uint32_t *out_pos;
+    uint64_t cap;
+    uint64_t *dst;   /* [threads] first output slot of every worker */
+    int64_t total;
+} fast_shared;
+
+typedef struct fast_arg {
+    fast_shared *sh;
+    int t;
+} fast_arg;
+
 static void *fast_thread(void *p) {
-    fast_range((fast_job *)p);
+    fast_arg *fa = (fast_arg *)p;
+    fast_shared *sh = fa->sh;
+    fast_job *jb = &sh->jobs[fa->t];
+    fast_range(jb);
+    pthread_barrier_wait(&sh->bar);
+    if (fa->t == 0) {
+        uint64_t m = 0;
+        int fits = 1;
+        for (int t = 0; t < sh->threads; ++t) {
+            if (sh->jobs[t].count > sh->jobs[t].cap) fits = 0;
+            sh->dst[t] = m;
+            m += sh->jobs[t].count;
+        }
+        sh->total = (fits && m <= sh->cap) ? (int64_t)m : MMO_ERR_CAPACITY;
+    }
+    pthread_barrier_wait(&sh->bar);
+    if (sh->total >= 0)
+        memcpy(sh->out_pos + sh->dst[fa->t], jb->out, sizeof(uint32_t) * (size_t)jb->count);
     return NULL;
 }
+
+/* Per-worker output slots are kept between calls (grow-only), like the reference's reusable
+ * thread-local buffers (src/lib.rs:80-81,217-219): a fresh 8 MB malloc per worker and call would put
+ * tens of thousands of page faults into every timed call. */
+static uint32_t *g_fast_slots = NULL;
+static uint64_t g_fast_slots_elems = 0;
 
 /* Minimizer positions (mode 0) with `threads` worker threads; returns the count or MMO_ERR_*. */
 int64_t mmo_run_fast(const uint8_t *packed, uint64_t off, uint64_t n, uint32_t k, uint32_t w,
@@ -625,41 +667,55 @@ int64_t mmo_run_fast(const uint8_t *packed, uint64_t off, uint64_t n, uint32_t k
     if (threads < 1) threads = 1;
     if ((uint64_t)threads > nw) threads = (int)nw;
     fast_job *jobs = (fast_job *)calloc((size_t)threads, sizeof(fast_job));
-    pthread_t *tids = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
     uint64_t per = (nw + threads - 1) / threads;
     uint64_t slot = (uint64_t)((double)per * 2.2 / (w + 1.0)) + 1024;
     if (slot > per) slot = per;
-    int ok = 1;
+    if (threads > 1 && g_fast_slots_elems < slot * (uint64_t)threads) {
+        free(g_fast_slots);
+        g_fast_slots_elems = slot * (uint64_t)threads;
+        g_fast_slots = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)g_fast_slots_elems);
+        if (!g_fast_slots) {
+            g_fast_slots_elems = 0;
+            free(jobs);
+            return MMO_ERR_CAPACITY;
+        }
+    }
     for (int t = 0; t < threads; ++t) {
         fast_job *jb = &jobs[t];
         jb->packed = packed; jb->off = off; jb->n = n; jb->k = k; jb->w = w; jb->h = h;
         jb->canonical = canonical;
         jb->win_begin = (uint64_t)t * per < nw ? (uint64_t)t * per : nw;
         jb->win_end = (uint64_t)(t + 1) * per < nw ? (uint64_t)(t + 1) * per : nw;
-        jb->cap = (t == 0 && threads == 1) ? cap : slot;
-        jb->out = (t == 0 && threads == 1) ? out_pos : (uint32_t *)malloc(sizeof(uint32_t) * (size_t)slot);
-        if (!jb->out) ok = 0;
+        jb->cap = threads == 1 ? cap : slot;
+        jb->out = threads == 1 ? out_pos : g_fast_slots + (uint64_t)t * slot;
     }
-    int64_t total = MMO_ERR_CAPACITY;
-    if (ok) {
-        if (threads == 1) fast_range(&jobs[0]);
-        else {
-            for (int t = 0; t < threads; ++t) pthread_create(&tids[t], NULL, fast_thread, &jobs[t]);
-            for (int t = 0; t < threads; ++t) pthread_join(tids[t], NULL);
-        }
-        uint64_t m = 0;
-        int fits = 1;
+    int64_t total;
+    if (threads == 1) {
+        fast_range(&jobs[0]);
+        total = jobs[0].count <= cap ? (int64_t)jobs[0].count : MMO_ERR_CAPACITY;
+    } else {
+        fast_shared sh;
+        pthread_barrier_init(&sh.bar, NULL, (unsigned)threads);
+        sh.jobs = jobs;
+        sh.threads = threads;
+        sh.out_pos = out_pos;
+        sh.cap = cap;
+        sh.dst = (uint64_t *)calloc((size_t)threads, sizeof(uint64_t));
+        sh.total = MMO_ERR_CAPACITY;
+        pthread_t *tids = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+        fast_arg *args = (fast_arg *)calloc((size_t)threads, sizeof(fast_arg));
         for (int t = 0; t < threads; ++t) {
-            if (jobs[t].count > jobs[t].cap) fits = 0;
-            if (threads > 1 && fits && m + jobs[t].count <= cap)
-                memcpy(out_pos + m, jobs[t].out, sizeof(uint32_t) * (size_t)jobs[t].count);
-            m += jobs[t].count;
+            args[t].sh = &sh;
+            args[t].t = t;
+            pthread_create(&tids[t], NULL, fast_thread, &args[t]);
         }
-        total = (fits && m <= cap) ? (int64_t)m : MMO_ERR_CAPACITY;
+        for (int t = 0; t < threads; ++t) pthread_join(tids[t], NULL);
+        total = sh.total;
+        pthread_barrier_destroy(&sh.bar);
+        free(sh.dst);
+        free(tids);
+        free(args);
     }
-    if (threads > 1)
-        for (int t = 0; t < threads; ++t) free(jobs[t].out);
     free(jobs);
-    free(tids);
     return total;
 }
