@@ -71,11 +71,25 @@ def cpu_baseline():
         assert r > 0
         total_n += CPU_SAMPLE_CHUNK
         chunks += 1
+    # the same code on one thread (32 Mbp), and the CPU model, for the record
+    one_n = 32 * 1024 * 1024
+    t0 = time.perf_counter()
+    lib.mmo_run_fast(g0.ctypes.data_as(C.POINTER(C.c_uint8)), 0, one_n, K, W, C.byref(h), 1, 1,
+                     pos.ctypes.data_as(C.POINTER(C.c_uint32)), cap)
+    one_thread = one_n / (time.perf_counter() - t0) / 1e9
+    model = "unknown CPU"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
     return {
         "value": round(total_n / total_t / 1e9, 5), "unit": "Gbases/s", "cores": threads, "kind": "port",
         "sample": f"{chunks} x {CPU_SAMPLE_CHUNK} bases of the same generator (seed {SEED}), canonical "
                   f"k={K} w={W}; scalar two-stacks + ntHash port of the reference (oracle/mm_oracle.c "
-                  f"mmo_run_fast, gcc -O3 -march=native), window ranges over {threads} threads{quota}; the "
+                  f"mmo_run_fast, gcc -O3 -march=native), window ranges over {threads} threads on {model}{quota}; one thread: {one_thread:.3f} Gbases/s; the "
                   f"reference's own published figure (unstated x86 AVX2, 1 thread, not measured here) "
                   f"is 0.455 Gbases/s",
     }
