@@ -30,8 +30,9 @@ CPU_SAMPLE_MAX_CHUNKS = 12
 
 def cpu_baseline():
     """The oracle's one-pass port of the reference algorithm (oracle/mm_oracle.c: mmo_run_fast,
-    scalar two-stacks + ntHash, window ranges spread over all host cores like the reference's
-    rayon-over-contigs benchmark) timed on this box's host cores on a bounded sample of the same
+    two-stacks + ntHash, eight AVX2 lanes per thread when the host has them like the reference's
+    SIMD path, window ranges spread over all host cores like the reference's rayon-over-contigs
+    benchmark) timed on this box's host cores on a bounded sample of the same
     workload.  Checker/baseline use only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ctypes as C
@@ -77,6 +78,7 @@ def cpu_baseline():
     lib.mmo_run_fast(g0.ctypes.data_as(C.POINTER(C.c_uint8)), 0, one_n, K, W, C.byref(h), 1, 1,
                      pos.ctypes.data_as(C.POINTER(C.c_uint32)), cap)
     one_thread = one_n / (time.perf_counter() - t0) / 1e9
+    flavour = "eight-lane AVX2" if lib.mmo_fast_lanes() == 8 else "scalar"
     model = "unknown CPU"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -88,7 +90,7 @@ def cpu_baseline():
     return {
         "value": round(total_n / total_t / 1e9, 5), "unit": "Gbases/s", "cores": threads, "kind": "port",
         "sample": f"{chunks} x {CPU_SAMPLE_CHUNK} bases of the same generator (seed {SEED}), canonical "
-                  f"k={K} w={W}; scalar two-stacks + ntHash port of the reference (oracle/mm_oracle.c "
+                  f"k={K} w={W}; {flavour} two-stacks + ntHash port of the reference (oracle/mm_oracle.c "
                   f"mmo_run_fast, gcc -O3 -march=native), window ranges over {threads} threads on {model}{quota}; one thread: {one_thread:.3f} Gbases/s; the "
                   f"reference's own published figure (unstated x86 AVX2, 1 thread, not measured here) "
                   f"is 0.455 Gbases/s",

@@ -545,6 +545,14 @@ void mmo_checksum(const uint32_t *v, uint64_t n, uint64_t *weighted, uint64_t *p
  * cpu_baseline of bench.py and checked against mmo_run by the tests. */
 #include <pthread.h>
 
+/* One output segment of a job: the job's output is the concatenation of its segments. */
+typedef struct {
+    uint32_t *p;
+    uint64_t count, cap;
+} fast_seg;
+
+#define FAST_MAX_SEGS 10
+
 typedef struct {
     const uint8_t *packed;
     uint64_t off, n;
@@ -552,24 +560,31 @@ typedef struct {
     const mmo_hasher *h;
     int canonical;
     uint64_t win_begin, win_end;
-    uint32_t *out;
-    uint64_t cap, count;
+    uint32_t *out;          /* the job's slot: the segments live inside it */
+    uint64_t cap, count;    /* slot size; total entries of all segments */
+    fast_seg segs[FAST_MAX_SEGS];
+    int n_segs, failed;
 } fast_job;
 
-static void fast_range(fast_job *jb) {
+/* scalar walk of windows [wb, we) into seg (dedup against window wb - 1 when it exists) */
+static void scalar_range(const fast_job *jb, uint64_t wb, uint64_t we, fast_seg *seg) {
     const uint8_t *packed = jb->packed;
     const uint64_t off = jb->off;
     const uint32_t k = jb->k, w = jb->w;
     const uint64_t l = (uint64_t)k + w - 1;
     const int canonical = jb->canonical;
-    /* element 0 = k-mer (win_begin - 1) when it exists, so that the seam dedup is exact */
-    const uint64_t first_km = jb->win_begin > 0 ? jb->win_begin - 1 : 0;
-    const int have_prev = jb->win_begin > 0;
+    seg->count = 0;
+    if (wb >= we) return;
+    /* element 0 = k-mer (wb - 1) when it exists, so that the seam dedup is exact */
+    const uint64_t first_km = wb > 0 ? wb - 1 : 0;
+    const int have_prev = wb > 0;
     roll_state st;
     roll_init(&st, jb->h, k);
     lrmin_state lr;
-    jb->count = 0;
-    if (lrmin_init(&lr, w)) return;
+    if (lrmin_init(&lr, w)) {
+        seg->count = seg->cap + 1; /* reported as a capacity failure */
+        return;
+    }
     uint64_t a = first_km; /* next base to consume */
     for (uint32_t j = 0; j + 1 < k; ++j, ++a) roll_push(&st, mmo_base(packed, off + a));
     int64_t cnt = 0;
@@ -581,8 +596,8 @@ static void fast_range(fast_job *jb) {
     uint32_t left, right, prev = 0;
     int first = 1;
     uint64_t m = 0;
-    /* k-mers first_km .. win_end + w - 2; window i completes with k-mer i + w - 1 */
-    const uint64_t last_km = jb->win_end + w - 1; /* exclusive */
+    /* k-mers first_km .. we + w - 2; window i completes with k-mer i + w - 1 */
+    const uint64_t last_km = we + w - 1; /* exclusive */
     for (uint64_t km = first_km; km < last_km; ++km, ++a) {
         uint32_t c = mmo_base(packed, off + a);
         if (km == first_km) roll_push(&st, c);
@@ -597,9 +612,9 @@ static void fast_range(fast_job *jb) {
             cnt -= mmo_base(packed, off + i) & 2u;
         }
         pos += (uint32_t)first_km;
-        if (i >= jb->win_begin) {
+        if (i >= wb) {
             if ((first && !have_prev) || pos != prev) {
-                if (m < jb->cap) jb->out[m] = pos;
+                if (m < seg->cap) seg->p[m] = pos;
                 ++m;
             }
         }
@@ -607,7 +622,235 @@ static void fast_range(fast_job *jb) {
         first = 0;
     }
     lrmin_free(&lr);
-    jb->count = m;
+    seg->count = m;
+}
+
+#if defined(__AVX2__)
+#include <immintrin.h>
+/* Eight-lane flavour of the same walk for host-tuned builds (the reference's SIMD path also runs
+ * eight chunks of the sequence side by side in the lanes of a 256-bit vector,
+ * src/minimizers.rs:133-166, src/sliding_min.rs:302-355, src/collect.rs:128-285).  Written from
+ * the scalar code above, not from the reference: lane L walks windows [vb + L * per8, + per8) with
+ * its own predecessor window, so every lane is the scalar walk of a sub-range and the concatenation
+ * of the eight outputs is exact.  per8 is a multiple of 16, which makes all lanes' base positions
+ * congruent mod 16: one scalar shift count and one refill schedule serve all lanes of a stream. */
+typedef struct {
+    __m256i byteoff; /* byte offset of the current dword, per lane */
+    __m256i cur;     /* current dword (16 bases), per lane */
+    int sh;          /* bit position of the next base inside cur (same for all lanes) */
+} vstream;
+
+static inline void vstream_init(vstream *s, const uint8_t *packed, const uint64_t *pos /* [8] absolute bases */) {
+    int32_t bo[8];
+    for (int i = 0; i < 8; ++i) bo[i] = (int32_t)((pos[i] >> 4) << 2);
+    s->byteoff = _mm256_loadu_si256((const __m256i *)bo);
+    s->cur = _mm256_i32gather_epi32((const int *)packed, s->byteoff, 1);
+    s->sh = (int)((pos[0] & 15u) * 2u);
+}
+static inline __m256i vstream_next(vstream *s, const uint8_t *packed) {
+    const __m256i code = _mm256_and_si256(_mm256_srl_epi32(s->cur, _mm_cvtsi32_si128(s->sh)), _mm256_set1_epi32(3));
+    s->sh += 2;
+    if (s->sh == 32) {
+        s->byteoff = _mm256_add_epi32(s->byteoff, _mm256_set1_epi32(4));
+        s->cur = _mm256_i32gather_epi32((const int *)packed, s->byteoff, 1);
+        s->sh = 0;
+    }
+    return code;
+}
+static inline __m256i vrotl(__m256i x, uint32_t r) {
+    r &= 31u;
+    if (r == 0) return x;
+    return _mm256_or_si256(_mm256_sll_epi32(x, _mm_cvtsi32_si128((int)r)),
+                           _mm256_srl_epi32(x, _mm_cvtsi32_si128((int)(32u - r))));
+}
+static inline __m256i vtable(const uint32_t t[4]) {
+    return _mm256_setr_epi32((int)t[0], (int)t[1], (int)t[2], (int)t[3], (int)t[0], (int)t[1], (int)t[2], (int)t[3]);
+}
+
+/* windows [vb, vb + 8 * per8) of the job, vb > 0, per8 % 16 == 0; segs[0..7] receive the lanes */
+static int avx2_range(const fast_job *jb, uint64_t vb, uint64_t per8, fast_seg *segs) {
+    const uint8_t *packed = jb->packed;
+    const uint32_t k = jb->k, w = jb->w;
+    const uint64_t l = (uint64_t)k + w - 1;
+    const mmo_hasher *h = jb->h;
+    const int canonical = jb->canonical, hash_rc = h->canonical != 0;
+    const uint32_t rot = h->rot;
+    uint32_t fw_out[4], rc_in[4];
+    for (int c = 0; c < 4; ++c) {
+        fw_out[c] = rotl32(h->fw[c], rot * k);
+        rc_in[c] = rotl32(h->rc[c], rot * (k - 1));
+    }
+    const __m256i T_fw = vtable(h->fw), T_fwout = vtable(fw_out), T_rc = vtable(h->rc), T_rcin = vtable(rc_in);
+    __m256i *rl = (__m256i *)aligned_alloc(32, sizeof(__m256i) * w);
+    __m256i *rr = (__m256i *)aligned_alloc(32, sizeof(__m256i) * w);
+    if (!rl || !rr) {
+        free(rl);
+        free(rr);
+        return -1;
+    }
+    const __m256i ones = _mm256_set1_epi32(-1), himask = _mm256_set1_epi32((int)0xffff0000u);
+    for (uint32_t i = 0; i < w; ++i) rl[i] = rr[i] = ones;
+    uint64_t first_km[8], posA[8];
+    int32_t base_pos[8], cnt0[8];
+    for (int L = 0; L < 8; ++L) {
+        first_km[L] = vb + (uint64_t)L * per8 - 1;
+        posA[L] = jb->off + first_km[L];
+        base_pos[L] = (int32_t)first_km[L];
+        int64_t c = -(int64_t)l;
+        if (canonical)
+            for (uint64_t j = first_km[L]; j + 1 < first_km[L] + l; ++j) c += mmo_base(packed, jb->off + j) & 2u;
+        cnt0[L] = (int32_t)c;
+    }
+    vstream sa, sb, sc; /* entering base, base leaving the hash, base leaving the window */
+    vstream_init(&sa, packed, posA);
+    vstream_init(&sb, packed, posA);
+    vstream_init(&sc, packed, posA);
+    __m256i fw = _mm256_setzero_si256(), rc = _mm256_setzero_si256();
+    for (uint32_t j = 0; j + 1 < k; ++j) { /* the first k - 1 bases: add only */
+        const __m256i in = vstream_next(&sa, packed);
+        fw = _mm256_xor_si256(vrotl(fw, rot), _mm256_permutevar8x32_epi32(T_fw, in));
+        rc = _mm256_xor_si256(vrotl(rc, 32u - (rot & 31u)), _mm256_permutevar8x32_epi32(T_rcin, in));
+    }
+    __m256i cnt = _mm256_loadu_si256((const __m256i *)cnt0);
+    const __m256i vbase = _mm256_loadu_si256((const __m256i *)base_pos);
+    __m256i pl = ones, pr = ones, prev = _mm256_setzero_si256();
+    uint32_t idx = 0, pos = 0, pos_offset = 0;
+    uint64_t m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t steps = per8 + w; /* k-mers first_km .. first_km + per8 + w - 1 */
+    for (uint64_t t = 0; t < steps; ++t) {
+        const __m256i in = vstream_next(&sa, packed);
+        if (t == 0) {
+            fw = _mm256_xor_si256(vrotl(fw, rot), _mm256_permutevar8x32_epi32(T_fw, in));
+            rc = _mm256_xor_si256(vrotl(rc, 32u - (rot & 31u)), _mm256_permutevar8x32_epi32(T_rcin, in));
+        } else {
+            const __m256i out = vstream_next(&sb, packed);
+            fw = _mm256_xor_si256(_mm256_xor_si256(vrotl(fw, rot), _mm256_permutevar8x32_epi32(T_fwout, out)),
+                                  _mm256_permutevar8x32_epi32(T_fw, in));
+            rc = _mm256_xor_si256(vrotl(_mm256_xor_si256(rc, _mm256_permutevar8x32_epi32(T_rc, out)), 32u - (rot & 31u)),
+                                  _mm256_permutevar8x32_epi32(T_rcin, in));
+        }
+        const __m256i val = hash_rc ? _mm256_add_epi32(fw, rc) : fw;
+        /* two-stacks minimum, same steps as lrmin_push */
+        if (pos == 0xffffu) {
+            const uint32_t delta = (1u << 16) - 2u - w;
+            const __m256i d = _mm256_set1_epi32((int)delta);
+            pos -= delta;
+            pl = _mm256_sub_epi32(pl, d);
+            pr = _mm256_sub_epi32(pr, d);
+            pos_offset += delta;
+            for (uint32_t i = 0; i < w; ++i) {
+                rl[i] = _mm256_sub_epi32(rl[i], d);
+                rr[i] = _mm256_sub_epi32(rr[i], d);
+            }
+        }
+        const __m256i vpos = _mm256_set1_epi32((int)pos);
+        const __m256i le = _mm256_or_si256(_mm256_and_si256(val, himask), vpos);
+        const __m256i re = _mm256_or_si256(_mm256_andnot_si256(val, himask), vpos);
+        pos += 1;
+        rl[idx] = le;
+        if (canonical) rr[idx] = re;
+        if (++idx == w) idx = 0;
+        pl = _mm256_min_epu32(pl, le);
+        pr = _mm256_max_epu32(pr, re);
+        if (idx == 0) {
+            __m256i sl = rl[w - 1];
+            for (uint32_t i = w - 1; i-- > 0;) {
+                sl = _mm256_min_epu32(sl, rl[i]);
+                rl[i] = sl;
+            }
+            if (canonical) { /* the rightmost minimum is only needed for the strand choice */
+                __m256i sr = rr[w - 1];
+                for (uint32_t i = w - 1; i-- > 0;) {
+                    sr = _mm256_max_epu32(sr, rr[i]);
+                    rr[i] = sr;
+                }
+            }
+            pl = le;
+            pr = re;
+        }
+        if (t + 1 < w) continue; /* window not complete yet */
+        const __m256i ml = _mm256_min_epu32(pl, rl[idx]), mr = _mm256_max_epu32(pr, rr[idx]);
+        const __m256i lo16 = _mm256_set1_epi32(0xffff), voff = _mm256_set1_epi32((int)pos_offset);
+        __m256i p = _mm256_add_epi32(_mm256_and_si256(ml, lo16), voff);
+        if (canonical) {
+            const __m256i two = _mm256_set1_epi32(2);
+            cnt = _mm256_add_epi32(cnt, _mm256_and_si256(in, two));
+            const __m256i right = _mm256_add_epi32(_mm256_and_si256(mr, lo16), voff);
+            p = _mm256_blendv_epi8(right, p, _mm256_cmpgt_epi32(cnt, _mm256_setzero_si256()));
+            cnt = _mm256_sub_epi32(cnt, _mm256_and_si256(vstream_next(&sc, packed), two));
+        }
+        p = _mm256_add_epi32(p, vbase);
+        if (t + 1 > w) { /* t + 1 == w is the predecessor window of every lane */
+            unsigned flags = (unsigned)_mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpeq_epi32(p, prev))) ^ 0xffu;
+            if (flags) {
+                uint32_t pv[8];
+                _mm256_storeu_si256((__m256i *)pv, p);
+                while (flags) {
+                    const int L = __builtin_ctz(flags);
+                    flags &= flags - 1;
+                    if (m[L] < segs[L].cap) segs[L].p[m[L]] = pv[L];
+                    ++m[L];
+                }
+            }
+        }
+        prev = p;
+    }
+    for (int L = 0; L < 8; ++L) segs[L].count = m[L];
+    free(rl);
+    free(rr);
+    return 0;
+}
+#endif
+
+/* A job's range as up to ten pieces: [scalar head] + eight vector lanes + [scalar tail] in
+ * host-tuned builds, one scalar piece otherwise (MMO_NO_AVX2 forces the scalar walk). */
+static int fast_range(fast_job *jb, fast_seg *segs, int *n_segs) {
+    uint64_t wb = jb->win_begin, we = jb->win_end;
+    uint32_t *p = jb->out;
+    uint64_t room = jb->cap;
+    *n_segs = 0;
+#if defined(__AVX2__)
+    if (!getenv("MMO_NO_AVX2") && we - wb >= 4096 && jb->n < (1ull << 31)) {
+        const uint64_t vb = wb == 0 ? 16 : wb;          /* the vector lanes need a predecessor window */
+        const uint64_t per8 = ((we - 64 - vb) / 8) & ~15ull; /* the last 64 windows stay scalar: no over-read */
+        const uint64_t ve = vb + 8 * per8;
+        if (per8 >= 16) {
+            const double dens = (double)jb->cap / (double)(we - wb + 1);
+            if (vb > wb) { /* scalar head [0, 16) */
+                fast_seg *sg = &segs[(*n_segs)++];
+                sg->p = p; sg->cap = room < 32 ? room : 32;
+                scalar_range(jb, wb, vb, sg);
+                p += sg->cap; room -= sg->cap;
+            }
+            uint64_t lane_cap = (uint64_t)(dens * (double)per8) + 64;
+            /* the scalar tail holds fewer than 64 + 8 * 16 windows */
+            if (lane_cap * 8 + 256 > room) lane_cap = room > 256 ? (room - 256) / 8 : 0;
+            fast_seg *lanes = &segs[*n_segs];
+            for (int L = 0; L < 8; ++L) {
+                lanes[L].p = p + (uint64_t)L * lane_cap;
+                lanes[L].cap = lane_cap;
+                lanes[L].count = 0;
+            }
+            if (avx2_range(jb, vb, per8, lanes)) return -1;
+            *n_segs += 8;
+            p += 8 * lane_cap; room -= 8 * lane_cap;
+            wb = ve;
+        }
+    }
+#endif
+    fast_seg *sg = &segs[(*n_segs)++];
+    sg->p = p; sg->cap = room;
+    scalar_range(jb, wb, we, sg);
+    return 0;
+}
+
+static void fast_job_run(fast_job *jb) {
+    jb->failed = fast_range(jb, jb->segs, &jb->n_segs) != 0;
+    jb->count = 0;
+    for (int g = 0; g < jb->n_segs; ++g) {
+        if (jb->segs[g].count > jb->segs[g].cap) jb->failed = 1;
+        jb->count += jb->segs[g].count;
+    }
 }
 
 /* Worker of mmo_run_fast: walk the range into the thread's slot, wait for everybody, let worker 0
@@ -632,21 +875,26 @@ static void *fast_thread(void *p) {
     fast_arg *fa = (fast_arg *)p;
     fast_shared *sh = fa->sh;
     fast_job *jb = &sh->jobs[fa->t];
-    fast_range(jb);
+    fast_job_run(jb);
     pthread_barrier_wait(&sh->bar);
     if (fa->t == 0) {
         uint64_t m = 0;
         int fits = 1;
         for (int t = 0; t < sh->threads; ++t) {
-            if (sh->jobs[t].count > sh->jobs[t].cap) fits = 0;
+            if (sh->jobs[t].failed) fits = 0;
             sh->dst[t] = m;
             m += sh->jobs[t].count;
         }
         sh->total = (fits && m <= sh->cap) ? (int64_t)m : MMO_ERR_CAPACITY;
     }
     pthread_barrier_wait(&sh->bar);
-    if (sh->total >= 0)
-        memcpy(sh->out_pos + sh->dst[fa->t], jb->out, sizeof(uint32_t) * (size_t)jb->count);
+    if (sh->total >= 0) {
+        uint32_t *dst = sh->out_pos + sh->dst[fa->t];
+        for (int g = 0; g < jb->n_segs; ++g) {
+            memcpy(dst, jb->segs[g].p, sizeof(uint32_t) * (size_t)jb->segs[g].count);
+            dst += jb->segs[g].count;
+        }
+    }
     return NULL;
 }
 
@@ -655,6 +903,15 @@ static void *fast_thread(void *p) {
  * tens of thousands of page faults into every timed call. */
 static uint32_t *g_fast_slots = NULL;
 static uint64_t g_fast_slots_elems = 0;
+
+/* 1 when mmo_run_fast of this build walks eight lanes per thread with AVX2, 0 for the scalar walk */
+int mmo_fast_lanes(void) {
+#if defined(__AVX2__)
+    return getenv("MMO_NO_AVX2") ? 1 : 8;
+#else
+    return 1;
+#endif
+}
 
 /* Minimizer positions (mode 0) with `threads` worker threads; returns the count or MMO_ERR_*. */
 int64_t mmo_run_fast(const uint8_t *packed, uint64_t off, uint64_t n, uint32_t k, uint32_t w,
@@ -668,9 +925,10 @@ int64_t mmo_run_fast(const uint8_t *packed, uint64_t off, uint64_t n, uint32_t k
     if ((uint64_t)threads > nw) threads = (int)nw;
     fast_job *jobs = (fast_job *)calloc((size_t)threads, sizeof(fast_job));
     uint64_t per = (nw + threads - 1) / threads;
-    uint64_t slot = (uint64_t)((double)per * 2.2 / (w + 1.0)) + 1024;
-    if (slot > per) slot = per;
-    if (threads > 1 && g_fast_slots_elems < slot * (uint64_t)threads) {
+    uint64_t slot = (uint64_t)((double)per * 2.2 / (w + 1.0)) + 4096;
+    if (slot > per + 4096) slot = per + 4096; /* a window emits at most once; room for the piece layout */
+    if (slot < 4096) slot = 4096;
+    if (g_fast_slots_elems < slot * (uint64_t)threads) {
         free(g_fast_slots);
         g_fast_slots_elems = slot * (uint64_t)threads;
         g_fast_slots = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)g_fast_slots_elems);
@@ -686,13 +944,22 @@ int64_t mmo_run_fast(const uint8_t *packed, uint64_t off, uint64_t n, uint32_t k
         jb->canonical = canonical;
         jb->win_begin = (uint64_t)t * per < nw ? (uint64_t)t * per : nw;
         jb->win_end = (uint64_t)(t + 1) * per < nw ? (uint64_t)(t + 1) * per : nw;
-        jb->cap = threads == 1 ? cap : slot;
-        jb->out = threads == 1 ? out_pos : g_fast_slots + (uint64_t)t * slot;
+        jb->cap = slot;
+        jb->out = g_fast_slots + (uint64_t)t * slot;
     }
     int64_t total;
     if (threads == 1) {
-        fast_range(&jobs[0]);
-        total = jobs[0].count <= cap ? (int64_t)jobs[0].count : MMO_ERR_CAPACITY;
+        /* one worker: walk into a scratch slot as well (the pieces are then packed into out_pos) */
+        fast_job_run(&jobs[0]);
+        total = MMO_ERR_CAPACITY;
+        if (!jobs[0].failed && jobs[0].count <= cap) {
+            uint32_t *dst = out_pos;
+            for (int g = 0; g < jobs[0].n_segs; ++g) {
+                memcpy(dst, jobs[0].segs[g].p, sizeof(uint32_t) * (size_t)jobs[0].segs[g].count);
+                dst += jobs[0].segs[g].count;
+            }
+            total = (int64_t)jobs[0].count;
+        }
     } else {
         fast_shared sh;
         pthread_barrier_init(&sh.bar, NULL, (unsigned)threads);

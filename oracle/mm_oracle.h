@@ -101,6 +101,8 @@ int64_t mmo_run(const uint8_t *packed, uint64_t base_offset, uint64_t n, uint32_
 
 /* One-pass, optionally multi-threaded port of the minimizer path (mode 0), used as the timed
  * cpu_baseline of bench.py; same output as mmo_run(..., MMO_MINIMIZERS, ...). */
+/* lanes per thread of mmo_run_fast in this build: 8 (AVX2, -march=native builds) or 1 (scalar) */
+int mmo_fast_lanes(void);
 int64_t mmo_run_fast(const uint8_t *packed, uint64_t base_offset, uint64_t n, uint32_t k, uint32_t w,
                      const mmo_hasher *h, int canonical_windows, int threads, uint32_t *out_pos,
                      uint64_t cap);

@@ -63,6 +63,8 @@ def _bind(lib):
     lib.mmo_run_fast.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, hp, C.c_int, C.c_int,
                                  u32p, C.c_uint64]
     lib.mmo_run_fast.restype = C.c_int64
+    lib.mmo_fast_lanes.argtypes = []
+    lib.mmo_fast_lanes.restype = C.c_int
     lib.mmo_values_u64.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_int, u32p, C.c_uint64, u64p]
     lib.mmo_values_u64.restype = None
     lib.mmo_values_u128.argtypes = [u8p, C.c_uint64, C.c_uint32, C.c_int, u32p, C.c_uint64, u64p]

@@ -163,6 +163,21 @@ def test_fast_port_equals_run(oracle):
     assert len(oracle.run_fast(data, 20, 21, 11, canonical=True, threads=4)) == 0
 
 
+def test_fast_port_native_build_equals_run(oracle, tmp_path):
+    """The host-tuned build of the timed port (eight AVX2 lanes per thread where the CPU has them)
+    produces exactly the oracle's output, also at a base offset and across thread counts."""
+    nat = oracle.lib(oracle.build(native=True, out_dir=str(tmp_path)))
+    assert nat.mmo_fast_lanes() in (1, 8)
+    n = 1_500_017
+    data = oracle.gen_packed(13, n)
+    for k, w, canon in [(21, 11, True), (21, 11, False), (5, 7, False), (31, 51, True), (3, 1, True), (15, 17, True)]:
+        for off in (0, 3):
+            want = oracle.run(data, n - off, k, w, canonical=canon, base_offset=off)
+            for threads in (1, 3):
+                got = oracle.run_fast(data, n - off, k, w, canonical=canon, threads=threads, base_offset=off, lib_=nat)
+                assert np.array_equal(got, want), (k, w, canon, threads, off)
+
+
 # ------------------------------------------------- skip-ambiguous windows (PackedNSeq)
 def test_reference_skip_max_collector_vectors(oracle):
     """src/test.rs:358-399: collect_and_dedup_into::<SKIP_MAX> known answers (both dedup rules)."""
