@@ -51,7 +51,7 @@ def cpu_baseline():
     try:  # a container may be allowed fewer CPUs than it sees (cgroup v2 cpu.max: quota period)
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if q != "max":
-            quota = f"; the container's CPU quota is {int(q) / int(per):.0f} CPUs (cgroup cpu.max), which is what bounds this figure"
+            quota = f"; the container's cgroup cpu.max reads {int(q) / int(per):.0f} CPUs"
     except Exception:
         pass
     h = o.default_hasher(True)

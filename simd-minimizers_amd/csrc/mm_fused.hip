@@ -62,7 +62,13 @@ constexpr uint32_t kMaxLdsBytes = 159u * 1024u;  // 160 KB per CU minus the stat
 Geometry geometry(const RunArgs &a) {
     Geometry g;
     g.nblk = legal_nblk(a.w, a.mode, a.nblk);
-    const uint32_t lists = (a.out.sk && a.mode == 0) ? 2u : 1u;
+    // super-k-mer runs pack (window << shift) + offset-in-window into the 16-bit list entry
+    // (kSkShift in mm_fused_impl.h): the lane length is bounded by S << shift <= 65536
+    if (a.out.sk && a.mode == 0) {
+        uint32_t sh = 1;
+        while ((1u << sh) <= a.w) ++sh;
+        while (g.nblk > 1u && ((uint64_t)a.w * g.nblk << sh) > 65536u) --g.nblk;
+    }
     for (;;) {
         g.S = a.w * g.nblk;
         // Lane list capacity: 1.3 x the expected number of emitted windows + 8 (> 5 sigma on random
@@ -71,12 +77,9 @@ Geometry geometry(const RunArgs &a) {
         uint32_t cap = (uint32_t)(1.3 * emit_density(a.w, a.mode) * g.S) + 8u + a.w;
         if (cap > g.S + a.w) cap = g.S + a.w;
         g.list_cap = cap;
-        g.lds_bytes = cap * kListStride * lists;
-        // large w (run-time specialised kernels): shorten the lanes until the lists fit the LDS;
-        // with two lists per lane (super-k-mer indices) keep at least two workgroups per CU
-        // unless the caller fixed the lane length
-        const uint32_t budget = (lists == 2u && a.nblk == 0) ? 79u * 1024u : kMaxLdsBytes;
-        if (g.lds_bytes <= budget || g.nblk == 1) break;
+        g.lds_bytes = cap * kListStride;
+        // large w (run-time specialised kernels): shorten the lanes until the lists fit the LDS
+        if (g.lds_bytes <= kMaxLdsBytes || g.nblk == 1) break;
         g.nblk = g.nblk > 4 ? g.nblk * 7 / 8 : g.nblk - 1;
     }
     g.NB = kFusedThreads * g.S;

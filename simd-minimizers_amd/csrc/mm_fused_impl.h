@@ -125,6 +125,12 @@ __device__ __forceinline__ uint32_t select3(uint32_t m, uint32_t a, uint32_t b) 
 template <int W>
 constexpr bool kTwoBodies = W <= 12;
 
+// Super-k-mer runs keep ONE 16-bit list per lane as well: an entry packs the window index i (lane-
+// relative) and the minimizer's offset inside that window, rel = element - i in [1, W], as
+// (i << kSkShift<W>) + rel = element + i * (2^shift - 1); the launcher keeps S << shift <= 65536.
+template <int W>
+constexpr int kSkShift = W < 2 ? 1 : W < 4 ? 2 : W < 8 ? 3 : W < 16 ? 4 : W < 32 ? 5 : W < 64 ? 6 : W < 128 ? 7 : 8;
+
 template <bool B>
 struct BoolTag {
     static constexpr bool value = B;
@@ -140,7 +146,7 @@ struct LaneCtx {
     int rem_valid;           // windows of this lane inside the range (PARTIAL walks only)
     int min_rem;             // the smallest rem_valid among the walking lanes of the wave (wave-uniform)
     uint8_t *list;           // LDS: this lane's list slot 0 (list mode)
-    uint32_t list_bytes;     // list_cap * kListStride (the super-k-mer list follows at +list_bytes)
+    uint32_t list_bytes;     // list_cap * kListStride
     uint32_t list_used;      // entries already in the list (reads mode: earlier reads of the lane)
     unsigned long long dst;  // first output slot of this lane (DIRECT mode)
     uint32_t abase;          // bit of the lane's window 0 in FusedParams::wamb (AMBI walks)
@@ -448,7 +454,21 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 // Common path: compare, and under the resulting exec mask append the 16-bit value
                 // to the lane's list and advance its slot pointer (2 VALU + 2 SALU + 1 LDS).
                 unsigned long long sv;
-                if (MODE == 0) {
+                if (MODE == 0 && SK) {
+                    // one more VALU under the mask: the packed (window, offset) entry
+                    const uint32_t skc = i * ((1u << kSkShift<W>) - 1u);  // uniform
+                    asm volatile(
+                        "v_cmp_ne_u32_sdwa vcc, %[sel], %[prev] src0_sel:WORD_0 src1_sel:WORD_0\n\t"
+                        "s_and_saveexec_b64 %[sv], vcc\n\t"
+                        "v_add_u32 %[val], %[c], %[sel]\n\t"
+                        "ds_write_b16 %[lp], %[val]\n\t"
+                        "v_add_u32 %[lp], %[st], %[lp]\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [lp] "+v"(lp32), [sv] "=&s"(sv), [val] "=&v"(valreg)
+                        : [sel] "v"(sel), [prev] "v"(prev), [st] "v"(stride_v), [c] "s"(skc)
+                        : "vcc", "scc", "memory");  // s_and_saveexec writes SCC
+                    prev = sel;
+                } else if (MODE == 0) {
                     asm volatile(
                         "v_cmp_ne_u32_sdwa vcc, %[sel], %[prev] src0_sel:WORD_0 src1_sel:WORD_0\n\t"
                         "s_and_saveexec_b64 %[sv], vcc\n\t"
@@ -509,8 +529,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                         ++dst;
                     } else {
                         uint8_t *lp = ctx.list + (lp32 - list0);
-                        *reinterpret_cast<uint16_t *>(lp) = (uint16_t)(MODE == 0 ? sel : i);
-                        if (SK) *reinterpret_cast<uint16_t *>(lp + ctx.list_bytes) = (uint16_t)i;
+                        *reinterpret_cast<uint16_t *>(lp) =
+                            (uint16_t)(MODE == 0 ? (SK ? sel + i * ((1u << kSkShift<W>) - 1u) : sel) : i);
                         lp32 += kListStride;
                     }
                 }
@@ -526,7 +546,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         // Full tiles of a plain sequence always qualify; walks that may not (range ends inside the
         // tile, reads, skipped windows) carry both bodies and choose per block with a wave-uniform
         // test - for small W only, see kTwoBodies.
-        constexpr bool kCanFast = !DIRECT && !SK;
+        constexpr bool kCanFast = !DIRECT;
         if (kCanFast && !PARTIAL && !AMBI) {
             steps(BoolTag<true>{});
         } else if (kCanFast && kTwoBodies<W>) {
@@ -855,7 +875,6 @@ __global__ __launch_bounds__(kFusedThreads, (W <= 12 ? 4 : 1)) void fused_kernel
         if (!(p.debug & 2u)) {
             const uint32_t tid0 = (uint32_t)wave * kWave;
             const uint8_t *rd = smem + (uint32_t)lane * kListStride + 2u * tid0;
-            const uint32_t list_bytes = ctx.list_bytes;
             const uint32_t vb0 = (READS ? 0u : (uint32_t)bw0 + tid0 * S) - (MODE == 0 ? 1u : 0u);
             // Output window of this wave as a bounds-checked buffer (wave-uniform, so the
             // descriptor lives in SGPRs): stores past the caller's capacity are dropped by the
@@ -882,7 +901,7 @@ __global__ __launch_bounds__(kFusedThreads, (W <= 12 ? 4 : 1)) void fused_kernel
 #ifdef MM_NO_FAST
             const bool fast = false;
 #else
-            const bool fast = !SK && room32 >= wave_total;
+            const bool fast = room32 >= wave_total;
 #endif
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             const unsigned long long obase = (unsigned long long)reinterpret_cast<uintptr_t>(p.out.pos + run0_u);
@@ -891,6 +910,13 @@ __global__ __launch_bounds__(kFusedThreads, (W <= 12 ? 4 : 1)) void fused_kernel
             odesc.y = __builtin_amdgcn_readfirstlane((uint32_t)(obase >> 32) & 0xffffu);
             odesc.z = 0x7fffffffu;  // the capacity was checked for the whole wave
             odesc.w = 0x00020000u;
+            const unsigned long long sbase =
+                (unsigned long long)reinterpret_cast<uintptr_t>((SK ? p.out.sk : p.out.pos) + run0_u);
+            u32x4 sdesc = odesc;  // super-k-mer indices: same slots of the second output array
+            sdesc.x = __builtin_amdgcn_readfirstlane((uint32_t)sbase);
+            sdesc.y = __builtin_amdgcn_readfirstlane((uint32_t)(sbase >> 32) & 0xffffu);
+            // an SK entry packs (window << shift) + offset-in-window (see kSkShift)
+            constexpr uint32_t kSh = (uint32_t)kSkShift<W>, kRelMask = (1u << kSh) - 1u;
             const uint32_t lane4 = (uint32_t)lane * 4u;
             if (fast) {
 #pragma unroll
@@ -902,9 +928,28 @@ __global__ __launch_bounds__(kFusedThreads, (W <= 12 ? 4 : 1)) void fused_kernel
                     for (int u = 0; u < kBatch; ++u) {
                         const uint32_t n = __builtin_amdgcn_readlane(my_count, L0 + u);
                         const uint32_t off = __builtin_amdgcn_readlane(excl, L0 + u);
-                        const uint32_t val = (READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S) + ent[u];
+                        const uint32_t vbl = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
+                        const uint32_t iw = ent[u] >> kSh;
+                        const uint32_t val = SK ? vbl + iw + (ent[u] & kRelMask) : vbl + ent[u];
+                        const uint32_t val2 = vbl + 1u + iw;
                         uint32_t t0;
                         unsigned long long sv;
+                        if (SK)
+                            asm volatile(
+                                "s_cmp_lt_u32 %[n], 64\n\t"
+                                "s_cselect_b32 %[t0], %[n], 0\n\t"
+                                "s_and_b32 %[t0], %[t0], %[sm]\n\t"
+                                "s_mov_b64 %[sv], exec\n\t"
+                                "s_bfm_b64 exec, %[t0], 0\n\t"
+                                "s_lshl_b32 %[t0], %[off], 2\n\t"
+                                "buffer_store_dword %[val], %[lane4], %[desc], %[t0] offen " MM_STORE_MOD "\n\t"
+                                "buffer_store_dword %[val2], %[lane4], %[desc2], %[t0] offen " MM_STORE_MOD "\n\t"
+                                "s_mov_b64 exec, %[sv]"
+                                : [t0] "=&s"(t0), [sv] "=&s"(sv)
+                                : [n] "s"(n), [off] "s"(off), [val] "v"(val), [val2] "v"(val2), [lane4] "v"(lane4),
+                                  [desc] "s"(odesc), [desc2] "s"(sdesc), [sm] "s"(store_mask)
+                                : "scc", "memory");
+                        else
                         asm volatile(
                             "s_cmp_lt_u32 %[n], 64\n\t"
                             "s_cselect_b32 %[t0], %[n], 0\n\t"
@@ -925,12 +970,9 @@ __global__ __launch_bounds__(kFusedThreads, (W <= 12 ? 4 : 1)) void fused_kernel
                 // per iteration are enough to cover the LDS latency and the code stays small)
 #pragma unroll 1
                 for (int L0 = 0; L0 < kWave; L0 += kBatch) {
-                    uint32_t ent[kBatch], ent2[kBatch];
+                    uint32_t ent[kBatch];
 #pragma unroll
-                    for (int u = 0; u < kBatch; ++u) {
-                        ent[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u));
-                        if (SK) ent2[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u) + list_bytes);
-                    }
+                    for (int u = 0; u < kBatch; ++u) ent[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u));
 #pragma unroll
                     for (int u = 0; u < kBatch; ++u) {
                         const uint32_t n = __builtin_amdgcn_readlane(my_count, L0 + u);
@@ -938,10 +980,10 @@ __global__ __launch_bounds__(kFusedThreads, (W <= 12 ? 4 : 1)) void fused_kernel
                         const uint32_t vb = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
                         uint32_t voff = (uint32_t)lane < n ? (off + (uint32_t)lane) * 4u : 0xffffffffu;
                         voff |= ~store_mask;
-                        __builtin_amdgcn_raw_buffer_store_b32(vb + ent[u], opos, voff, 0, MM_STORE_AUX);
-                        if (SK)
-                            __builtin_amdgcn_raw_buffer_store_b32(vb + (MODE == 0 ? 1u : 0u) + ent2[u], osk, voff, 0,
-                                                                  MM_STORE_AUX);
+                        const uint32_t iw = ent[u] >> kSh;
+                        __builtin_amdgcn_raw_buffer_store_b32(SK ? vb + iw + (ent[u] & kRelMask) : vb + ent[u], opos,
+                                                              voff, 0, MM_STORE_AUX);
+                        if (SK) __builtin_amdgcn_raw_buffer_store_b32(vb + 1u + iw, osk, voff, 0, MM_STORE_AUX);
                     }
                 }
             }
@@ -955,11 +997,10 @@ __global__ __launch_bounds__(kFusedThreads, (W <= 12 ? 4 : 1)) void fused_kernel
                     for (uint32_t c = (fast && n >= (uint32_t)kWave ? 0u : (uint32_t)kWave) + lane; c < n; c += kWave) {
                         const uint8_t *q = rd + 2u * L + (c - lane) * kListStride;
                         const uint32_t e1 = *reinterpret_cast<const uint16_t *>(q);
-                        __builtin_amdgcn_raw_buffer_store_b32(vb + e1, opos, (off + c) * 4u, 0, 0);
-                        if (SK)
-                            __builtin_amdgcn_raw_buffer_store_b32(
-                                vb + (MODE == 0 ? 1u : 0u) + *reinterpret_cast<const uint16_t *>(q + list_bytes),
-                                osk, (off + c) * 4u, 0, 0);
+                        const uint32_t iw = e1 >> kSh;
+                        __builtin_amdgcn_raw_buffer_store_b32(SK ? vb + iw + (e1 & kRelMask) : vb + e1, opos,
+                                                              (off + c) * 4u, 0, 0);
+                        if (SK) __builtin_amdgcn_raw_buffer_store_b32(vb + 1u + iw, osk, (off + c) * 4u, 0, 0);
                     }
                 }
             }

@@ -354,6 +354,16 @@ def test_blocks_per_lane_knob(sm, oracle, gpu):
             want2 = oracle.run(data, n, k2, w2, canonical=True)
             c = sm.canonical_minimizers(k2, w2).run_device(d, n, out)
             assert c == len(want2) and np.array_equal(out[:c].cpu().numpy().view(np.uint32), want2), (nblk, k2, w2)
+        # super-k-mer runs pack (window, offset) into one 16-bit list entry, which bounds the lane
+        # length: over-long requests are shortened by the launcher, results stay the same
+        sk = torch.zeros(n, dtype=torch.int32, device="cuda")
+        for nblk, (k2, w2) in ((500, (21, 11)), (372, (21, 11)), (30, (31, 51)), (1, (21, 11)), (700, (9, 7))):
+            gpu.set_blocks_per_lane(nblk)
+            want2, wsk2 = oracle.run(data, n, k2, w2, canonical=True, super_kmers=True)
+            c = sm.canonical_minimizers(k2, w2).run_device(d, n, out, out_sk=sk)
+            assert gpu.last_path() == sm.PATH_FUSED
+            assert c == len(want2) and np.array_equal(out[:c].cpu().numpy().view(np.uint32), want2), (nblk, k2, w2)
+            assert np.array_equal(sk[:c].cpu().numpy().view(np.uint32), wsk2), (nblk, k2, w2)
     finally:
         gpu.set_blocks_per_lane(0)
 
