@@ -692,9 +692,9 @@ int mm_run_batch_device(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_se
 }
 
 // Batched short reads: read r = bases [base_offset + r * read_stride, + len_r) of one packed buffer.
-// Fast path: the reads-mode fused kernel (one lane per read, one launch).  Anything it has no
-// instance for (syncmer modes, other w, reads too long for the LDS lists) runs one launch per read
-// on the same stream: slower, same results.
+// Fast path: the reads-mode fused kernel (one lane per read, one launch; prebuilt for minimizers,
+// specialised at first use for the syncmer modes and other w).  Anything it cannot take (w > 128,
+// reads too long for the LDS lists) runs one launch per read on the same stream: slower, same results.
 static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
                                 uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
                                 uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
@@ -718,14 +718,15 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
     int r = make_view(d_packed, packed_bytes, base_offset, span, &view);
     if (r) return r;
 
-    bool fast = plan->mode == MM_MINIMIZERS && !ws->force_generic &&
-                mm::fused_reads_supported(plan->w, plan->canonical_windows, (int)plan->ht.canonical);
+    bool fast = !ws->force_generic &&
+                mm::fused_reads_supported(plan->w, plan->canonical_windows, (int)plan->ht.canonical, plan->mode);
     if (fast) {
         mm::ReadsArgs a;
         a.seq = view;
         a.ht = plan->ht;
         a.k = plan->k;
         a.w = plan->w;
+        a.mode = plan->mode;
         a.canonical_windows = plan->canonical_windows;
         a.n_reads = n_reads;
         a.read_stride = read_stride;

@@ -235,8 +235,10 @@ const FusedReadsInstance *find_reads_instance(uint32_t w, int canonical_windows,
 }
 }  // namespace
 
-bool fused_reads_supported(uint32_t w, int canonical_windows, int hasher_canonical) {
-    if (find_reads_instance(w, canonical_windows, hasher_canonical)) return true;
+bool fused_reads_supported(uint32_t w, int canonical_windows, int hasher_canonical, uint32_t mode) {
+    if (mode > 2) return false;
+    // (syncmer modes have no prebuilt reads-mode kernels: compiled at first use, cached on disk)
+    if (mode == 0 && find_reads_instance(w, canonical_windows, hasher_canonical)) return true;
     return jit_enabled() && w >= 1 && w <= kJitMaxW;
 }
 
@@ -255,7 +257,7 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     // sequence mode (fewer tiles: less look-back and copy-out overhead per window).  MM_READS_PER_LANE
     // overrides (experiments).
     auto cap_for = [&](uint32_t r) {
-        uint32_t c = (uint32_t)(1.3 * emit_density(a.w, 0) * S * r) + 8u + a.w;
+        uint32_t c = (uint32_t)(1.3 * emit_density(a.w, a.mode) * S * r) + 8u + a.w;
         return c > (S + a.w) * r ? (S + a.w) * r : c;
     };
     // as many reads per lane (up to 4) as keep the lists near 40 KB, i.e. 4 workgroups per CU
@@ -271,10 +273,12 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     const uint64_t per_tile = (uint64_t)kFusedThreads * R;
     const uint64_t nblocks = (a.n_reads + per_tile - 1) / per_tile;
     KernelRef kr;
-    if (const FusedReadsInstance *inst = find_reads_instance(a.w, a.canonical_windows, (int)a.ht.canonical))
+    const FusedReadsInstance *inst =
+        a.mode == 0 ? find_reads_instance(a.w, a.canonical_windows, (int)a.ht.canonical) : nullptr;
+    if (inst)
         kr.host = inst->fn;
     else
-        kr.mod = jit_fused_kernel(a.w, a.canonical_windows != 0, a.ht.canonical != 0, 0, false, true,
+        kr.mod = jit_fused_kernel(a.w, a.canonical_windows != 0, a.ht.canonical != 0, (int)a.mode, false, true,
                                   &t_jit_error);
     if (!kr) return -2;
 

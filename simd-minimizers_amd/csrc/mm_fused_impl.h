@@ -659,7 +659,10 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
 template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool READS>
 // (small W: at least 4 waves per SIMD, i.e. at most 128 VGPRs - the two-body walks sit right at that
 // limit; larger W need more registers and get no such bound)
-__global__ __launch_bounds__(kFusedThreads, (W <= 12 ? 4 : 1)) void fused_kernel(const FusedParams p) {
+#ifndef MM_MIN_BLOCKS
+#define MM_MIN_BLOCKS (W <= 12 ? 4 : 1)
+#endif
+__global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // lane lists
     // static LDS: distinct objects, so table look-ups can be scheduled across the list stores
     __shared__ uint2 s_tab[20];  // [0..15] (out<<2)|in, [16..19] in only (warm-up)
@@ -821,6 +824,9 @@ __global__ __launch_bounds__(kFusedThreads, (W <= 12 ? 4 : 1)) void fused_kernel
     }
 
     // ---------------------------------------------------------------- phase 2
+#ifdef MM_PRIO_P2
+    __builtin_amdgcn_s_setprio(MM_PRIO_P2);  // experiment: phase 2 ahead of the other tiles' walks
+#endif
     if (p.trace && tid == 0) p.trace[10 * (size_t)bid + 1] = wall_clock64();
     const uint32_t incl = wave_scan_dpp(my_count);
     const uint32_t wave_total = __builtin_amdgcn_readlane(incl, kWave - 1);

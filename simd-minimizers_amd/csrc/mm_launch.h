@@ -51,6 +51,7 @@ struct ReadsArgs {
     SeqView seq;
     HashTables ht;
     uint32_t k, w;
+    uint32_t mode;  // 0 minimizers (prebuilt instances), 1 / 2 closed / open syncmers (run-time specialised)
     int canonical_windows;
     uint64_t n_reads;
     uint32_t read_stride, read_len;
@@ -62,7 +63,7 @@ struct ReadsArgs {
     int use_ticket;
     hipEvent_t timing_start, timing_stop;
 };
-bool fused_reads_supported(uint32_t w, int canonical_windows, int hasher_canonical);
+bool fused_reads_supported(uint32_t w, int canonical_windows, int hasher_canonical, uint32_t mode = 0);
 uint64_t fused_reads_status_words(const ReadsArgs &a);
 // returns 0, -1 (HIP failure), -2 (no instance), -3 (reads too long for the LDS lists)
 int launch_fused_reads(const ReadsArgs &a, hipStream_t stream);

@@ -660,8 +660,20 @@ def test_reads_mode(sm, oracle, gpu):
         lens = rng.integers(0, 301, size=n_reads)
         lens[:6] = [0, l - 1, l, l + 1, 300, 1]
         _check_reads(sm, oracle, k, w, canonical, 0, n_reads, 304, 300, lens, 5, 6)
-    # plans without a reads-mode instance take one launch per read: same results
-    _check_reads(sm, oracle, 15, 17, True, 1, 40, 150, 150, None, 2, 7)   # closed syncmers
+    # syncmer plans have no prebuilt reads-mode kernel: specialised at first use, still ONE launch;
+    # with MM_JIT=0 one launch per read - same results
+    for (k, w, canonical, mode) in [(15, 17, True, 1), (15, 17, True, 2), (9, 11, False, 1), (8, 5, False, 2),
+                                    (10, 12, True, 1)]:
+        lens = rng.integers(0, 301, size=700)
+        _check_reads(sm, oracle, k, w, canonical, mode, 700, 303, 300, lens, 3, 70 + w + mode)
+        assert gpu.last_path() == 1, sm.lib().mm_last_error()
+    _check_reads(sm, oracle, 15, 17, True, 1, 600, 151, 150, None, 2, 7)
+    assert gpu.last_path() == 1
+    os.environ["MM_JIT"] = "0"
+    try:
+        _check_reads(sm, oracle, 15, 17, True, 1, 40, 150, 150, None, 2, 7)
+    finally:
+        del os.environ["MM_JIT"]
     # a w without a prebuilt instance: specialised at run time (one launch) or, with MM_JIT=0, one
     # launch per read through the generic family
     _check_reads(sm, oracle, 12, 18, True, 0, 40, 150, 149, None, 0, 8)
@@ -804,8 +816,9 @@ def test_skip_ambiguous_reads(sm, oracle, gpu):
     """Reads with Ns in one launch: each read equals run_skip_ambiguous_windows on that read."""
     import torch
     rng = np.random.default_rng(31)
-    for k, w, n_reads, stride, read_len, off in [(21, 11, 900, 151, 150, 0), (15, 5, 300, 160, 101, 3),
-                                                 (31, 19, 300, 250, 250, 1), (12, 18, 40, 150, 150, 2)]:
+    for k, w, n_reads, stride, read_len, off, mode in [(21, 11, 900, 151, 150, 0, 0), (15, 5, 300, 160, 101, 3, 0),
+                                                       (31, 19, 300, 250, 250, 1, 0), (12, 18, 40, 150, 150, 2, 0),
+                                                       (15, 17, 500, 151, 150, 1, 1), (15, 9, 300, 151, 150, 0, 2)]:
         span = n_reads * stride + 64 + off
         a = _ascii_with_n(rng, span, 0.004, False)
         for s in rng.integers(0, span - 100, size=20):
@@ -817,14 +830,15 @@ def test_skip_ambiguous_reads(sm, oracle, gpu):
             d_lens = torch.from_numpy(lens.astype(np.int32)).cuda() if use_lens else None
             out = torch.zeros(n_reads * read_len, dtype=torch.int32, device="cuda")
             offs = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
-            total = sm.run_reads_device(sm.canonical_minimizers(k, w), d_p, n_reads, stride, read_len, out, offs,
+            total = sm.run_reads_device(sm.Builder(k, w, True, mode), d_p, n_reads, stride, read_len, out, offs,
                                         read_lens=d_lens, base_offset=off, d_amb=d_m, amb_offset=off)
+            assert gpu.last_path() == sm.PATH_FUSED
             ho = offs.cpu().numpy()
             hp = out[:total].cpu().numpy().view(np.uint32)
             assert ho[-1] == total
             for r in range(n_reads):
                 m = int(lens[r]) if use_lens else read_len
-                want = oracle.run_skip_ambiguous(packed, amb, m, k, w, base_offset=off + r * stride,
+                want = oracle.run_skip_ambiguous(packed, amb, m, k, w, mode=mode, base_offset=off + r * stride,
                                                  amb_offset=off + r * stride)
                 assert np.array_equal(hp[ho[r]:ho[r + 1]], want), (k, w, r, m)
 
