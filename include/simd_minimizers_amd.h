@@ -199,9 +199,10 @@ int mm_run_batch_device(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_se
  * an independent Builder::run, src/lib.rs:378): read r is the bases
  * [base_offset + r * read_stride, + len_r) of one packed device buffer, len_r = d_read_lens[r]
  * (<= read_len) or read_len when d_read_lens is NULL.  Positions are read-local and written back
- * to back; d_out_offsets (device, n_reads + 1 entries) delimits the reads.  Minimizer plans with a
- * reads-mode kernel instance run as ONE launch with one lane per read; other plans (syncmers,
- * other w, reads too long for a lane's LDS list) take one launch per read - same results. */
+ * to back; d_out_offsets (device, n_reads + 1 entries) delimits the reads.  Plans run as ONE launch
+ * with one lane per read (prebuilt kernels for minimizers at the common window sizes, kernels
+ * specialised at first use for syncmers, super-k-mer indices and other w <= 128); only reads too
+ * long for a lane's LDS list or w > 128 take one launch per read - same results. */
 int mm_run_reads_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
                               uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
                               uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
@@ -243,6 +244,21 @@ int mm_run_skip_ambiguous_host(const mm_plan_t *plan, mm_workspace_t *ws, const 
 int mm_run_skip_ambiguous_host_ascii(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *ascii,
                                      uint64_t n_bases, uint32_t *out_pos, uint64_t capacity,
                                      uint64_t *out_count);
+/* The same with super-k-mer indices (Builder::super_kmers + run per read, src/lib.rs:341,545-576):
+ * d_out_sk[j] = read-local index of the first window that selected d_out_pos[j].  Minimizer plans
+ * only (MM_ERR_BAD_MODE otherwise, like src/lib.rs:339). */
+int mm_run_reads_superkmers_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                                         uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
+                                         uint32_t read_stride, uint32_t read_len,
+                                         const uint32_t *d_read_lens, uint32_t *d_out_pos,
+                                         uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_out_offsets,
+                                         uint64_t *d_count);
+int mm_run_reads_superkmers_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                                   uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
+                                   uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
+                                   uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
+                                   uint64_t *d_out_offsets, uint64_t *out_count);
+
 /* Batched short reads with ambiguity bits (same layout rules as mm_run_reads_device; read r's
  * ambiguity bits start at bit amb_offset + r * read_stride). */
 int mm_run_reads_skip_ambiguous_device_async(const mm_plan_t *plan, mm_workspace_t *ws,

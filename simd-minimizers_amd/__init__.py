@@ -112,6 +112,10 @@ def lib():
                       C.c_uint64, vp]
         L.mm_run_reads_device_async.argtypes = reads_args + [vp]
         L.mm_run_reads_device.argtypes = reads_args + [u64p]
+        reads_sk_args = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, vp,
+                         C.c_uint64, vp]
+        L.mm_run_reads_superkmers_device_async.argtypes = reads_sk_args + [vp]
+        L.mm_run_reads_superkmers_device.argtypes = reads_sk_args + [u64p]
         skip_args = [vp, vp, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, C.c_uint64, C.c_uint64,
                      C.c_uint64, C.c_uint64, vp, C.c_uint64]
         L.mm_run_skip_ambiguous_device_async.argtypes = skip_args + [vp]
@@ -141,6 +145,7 @@ EXPORTED_SYMBOLS = [
     "mm_run_device_async", "mm_run_device", "mm_run_host", "mm_run_host_ascii",
     "mm_values_u64_device_async", "mm_values_u64_host", "mm_values_u128_device_async",
     "mm_values_u128_host", "mm_run_batch_device", "mm_run_reads_device_async", "mm_run_reads_device",
+    "mm_run_reads_superkmers_device_async", "mm_run_reads_superkmers_device",
     "mm_run_skip_ambiguous_device_async", "mm_run_skip_ambiguous_device", "mm_run_skip_ambiguous_host",
     "mm_run_skip_ambiguous_host_ascii", "mm_run_reads_skip_ambiguous_device_async",
     "mm_run_reads_skip_ambiguous_device", "mm_pack_ascii_n_device_async", "mm_pack_ascii_device_async",
@@ -556,10 +561,12 @@ def run_batch_device(builder: "Builder", d_seqs, n_bases, out_pos, out_sk=None, 
 
 
 def run_reads_device(builder: "Builder", d_packed, n_reads, read_stride, read_len, out_pos, out_offsets,
-                     read_lens=None, base_offset=0, d_count=None, sync=True, d_amb=None, amb_offset=0):
+                     read_lens=None, base_offset=0, d_count=None, sync=True, d_amb=None, amb_offset=0,
+                     out_sk=None):
     """Batched short reads in one packed device buffer (read r at base ``base_offset + r*read_stride``);
     read-local positions go back to back into ``out_pos`` and ``out_offsets`` (int64/uint64 CUDA
-    tensor, n_reads+1) delimits the reads. Returns the total count when ``sync``."""
+    tensor, n_reads+1) delimits the reads; ``out_sk`` also receives the super-k-mer indices
+    (read-local window of the first selection). Returns the total count when ``sync``."""
     L = lib()
     ws = builder._ws()
     plan = builder.plan()
@@ -568,10 +575,17 @@ def run_reads_device(builder: "Builder", d_packed, n_reads, read_stride, read_le
     if d_amb is not None:  # PackedNSeq reads: skip windows with ambiguous bases
         args += [C.c_void_p(d_amb.data_ptr()), d_amb.numel(), amb_offset]
     args += [n_reads, read_stride, read_len, C.c_void_p(read_lens.data_ptr()) if read_lens is not None else None,
-             C.c_void_p(out_pos.data_ptr()) if out_pos is not None else None, cap,
-             C.c_void_p(out_offsets.data_ptr())]
-    fsync, fasync = ((L.mm_run_reads_skip_ambiguous_device, L.mm_run_reads_skip_ambiguous_device_async)
-                     if d_amb is not None else (L.mm_run_reads_device, L.mm_run_reads_device_async))
+             C.c_void_p(out_pos.data_ptr()) if out_pos is not None else None]
+    if out_sk is not None:
+        if d_amb is not None:
+            raise MinimizerError(ERR["BAD_MODE"], "no super-k-mer flavour of the skip-ambiguous run")
+        args += [C.c_void_p(out_sk.data_ptr())]
+    args += [cap, C.c_void_p(out_offsets.data_ptr())]
+    if out_sk is not None:
+        fsync, fasync = L.mm_run_reads_superkmers_device, L.mm_run_reads_superkmers_device_async
+    else:
+        fsync, fasync = ((L.mm_run_reads_skip_ambiguous_device, L.mm_run_reads_skip_ambiguous_device_async)
+                         if d_amb is not None else (L.mm_run_reads_device, L.mm_run_reads_device_async))
     if sync:
         cnt = C.c_uint64(0)
         code = fsync(*args, C.byref(cnt))

@@ -699,11 +699,16 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
                                 uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
                                 uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
                                 uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
-                                uint64_t *d_count, const AmbArgs *amb = nullptr) {
+                                uint64_t *d_count, const AmbArgs *amb = nullptr, uint32_t *d_out_sk = nullptr) {
     if (!plan || !ws || !d_out_offsets) return MM_ERR_NULL;
     if (n_reads >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     if (amb && !plan->canonical_windows) return MM_ERR_HASHER_NOT_CANONICAL;
-    if (!d_out_pos) capacity = 0;
+    if (d_out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;  // src/lib.rs:339
+    if (d_out_sk && amb) return MM_ERR_BAD_MODE;  // the reference has no skip-ambiguous super-k-mer run
+    if (!d_out_pos) {
+        capacity = 0;
+        d_out_sk = nullptr;
+    }
     MM_HIP(hipSetDevice(ws->device));
     MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
     if (n_reads == 0 || read_len == 0) {
@@ -718,8 +723,11 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
     int r = make_view(d_packed, packed_bytes, base_offset, span, &view);
     if (r) return r;
 
+    // (super-k-mer indices: run-time specialised kernel, like the syncmer modes)
     bool fast = !ws->force_generic &&
-                mm::fused_reads_supported(plan->w, plan->canonical_windows, (int)plan->ht.canonical, plan->mode);
+                (d_out_sk ? mm::fused_reads_supported(plan->w, plan->canonical_windows, (int)plan->ht.canonical, 1)
+                          : mm::fused_reads_supported(plan->w, plan->canonical_windows, (int)plan->ht.canonical,
+                                                      plan->mode));
     if (fast) {
         mm::ReadsArgs a;
         a.seq = view;
@@ -734,7 +742,7 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
         a.read_lens = d_read_lens;
         a.read_offsets = reinterpret_cast<unsigned long long *>(d_out_offsets);
         a.out.pos = d_out_pos;
-        a.out.sk = nullptr;
+        a.out.sk = d_out_sk;
         a.out.cap = capacity;
         a.out.total = ws->total;
         a.out.ticket = ws->ticket;
@@ -789,7 +797,7 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
             AmbArgs ra;
             if (amb) ra = AmbArgs{amb->d_amb, amb->bytes, amb->bit_offset + i * (uint64_t)read_stride};
             r = run_device_async_impl(plan, ws, bytes + first / 4, packed_bytes - first / 4, first % 4, len,
-                                      0, UINT64_MAX, d_out_pos, nullptr, capacity, nullptr, i != 0,
+                                      0, UINT64_MAX, d_out_pos, d_out_sk, capacity, nullptr, i != 0,
                                       amb ? &ra : nullptr);
             if (r) return r;
             MM_HIP(hipMemcpyAsync(d_out_offsets + i + 1, ws->total, sizeof(uint64_t),
@@ -815,11 +823,12 @@ static int run_reads_sync(const mm_plan_t *plan, mm_workspace_t *ws, const void 
                           uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
                           uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
                           uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
-                          uint64_t *out_count, const AmbArgs *amb) {
+                          uint64_t *out_count, const AmbArgs *amb, uint32_t *d_out_sk = nullptr) {
     if (!ws) return MM_ERR_NULL;
     for (int attempt = 0; attempt < 2; ++attempt) {
         int r = run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride,
-                                     read_len, d_read_lens, d_out_pos, capacity, d_out_offsets, nullptr, amb);
+                                     read_len, d_read_lens, d_out_pos, capacity, d_out_offsets, nullptr, amb,
+                                     d_out_sk);
         if (r) return r;
         MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long),
                               hipMemcpyDeviceToHost, ws->stream));
@@ -843,6 +852,27 @@ int mm_run_reads_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d
                         uint64_t *out_count) {
     return run_reads_sync(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride, read_len,
                           d_read_lens, d_out_pos, capacity, d_out_offsets, out_count, nullptr);
+}
+
+int mm_run_reads_superkmers_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                                         uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
+                                         uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
+                                         uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
+                                         uint64_t *d_out_offsets, uint64_t *d_count) {
+    if (!d_out_sk) return MM_ERR_NULL;
+    return run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride,
+                                read_len, d_read_lens, d_out_pos, capacity, d_out_offsets, d_count, nullptr,
+                                d_out_sk);
+}
+
+int mm_run_reads_superkmers_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                                   uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
+                                   uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
+                                   uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
+                                   uint64_t *d_out_offsets, uint64_t *out_count) {
+    if (!d_out_sk) return MM_ERR_NULL;
+    return run_reads_sync(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride, read_len,
+                          d_read_lens, d_out_pos, capacity, d_out_offsets, out_count, nullptr, d_out_sk);
 }
 
 int mm_run_reads_skip_ambiguous_device_async(const mm_plan_t *plan, mm_workspace_t *ws,

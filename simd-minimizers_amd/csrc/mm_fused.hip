@@ -273,12 +273,18 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     const uint64_t per_tile = (uint64_t)kFusedThreads * R;
     const uint64_t nblocks = (a.n_reads + per_tile - 1) / per_tile;
     KernelRef kr;
+    const bool sk = a.out.sk != nullptr && a.mode == 0;
+    if (sk) {  // packed (window, offset) list entries bound the read length (kSkShift, mm_fused_impl.h)
+        uint32_t sh = 1;
+        while ((1u << sh) <= a.w) ++sh;
+        if (((uint64_t)S << sh) > 65536u) return -3;
+    }
     const FusedReadsInstance *inst =
-        a.mode == 0 ? find_reads_instance(a.w, a.canonical_windows, (int)a.ht.canonical) : nullptr;
+        (a.mode == 0 && !sk) ? find_reads_instance(a.w, a.canonical_windows, (int)a.ht.canonical) : nullptr;
     if (inst)
         kr.host = inst->fn;
     else
-        kr.mod = jit_fused_kernel(a.w, a.canonical_windows != 0, a.ht.canonical != 0, (int)a.mode, false, true,
+        kr.mod = jit_fused_kernel(a.w, a.canonical_windows != 0, a.ht.canonical != 0, (int)a.mode, sk, true,
                                   &t_jit_error);
     if (!kr) return -2;
 

@@ -696,6 +696,41 @@ def test_reads_mode(sm, oracle, gpu):
     _check_reads(sm, oracle, 21, 11, True, 0, 0, 150, 150, None, 0, 1)
 
 
+def test_reads_mode_superkmers(sm, oracle, gpu):
+    """Super-k-mer indices per read in one launch (Builder::super_kmers + run per read,
+    src/lib.rs:341,545-576): positions and read-local window indices equal the oracle's per read;
+    reads too long for the packed list entry fall back to one launch per read."""
+    import torch
+    rng = np.random.default_rng(23)
+    for k, w, canonical, n_reads, stride, read_len, off in [(21, 11, True, 900, 151, 150, 0), (21, 11, False, 300, 303, 300, 3),
+                                                            (15, 5, True, 300, 160, 101, 1), (31, 19, True, 300, 250, 250, 2),
+                                                            (12, 18, True, 40, 400, 397, 0), (21, 11, True, 3, 9000, 8999, 1)]:
+        span = (n_reads - 1) * stride + read_len
+        data = oracle.gen_packed(90 + w, off + span + 64)
+        d = torch.from_numpy(data).cuda()
+        lens = rng.integers(0, read_len + 1, size=n_reads)
+        lens[:2] = [read_len, k + w - 1]
+        d_lens = torch.from_numpy(lens.astype(np.int32)).cuda()
+        out = torch.zeros(n_reads * read_len, dtype=torch.int32, device="cuda")
+        sk = torch.zeros_like(out)
+        offs = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
+        total = sm.run_reads_device(sm.Builder(k, w, canonical, 0), d, n_reads, stride, read_len, out, offs,
+                                    read_lens=d_lens, base_offset=off, out_sk=sk)
+        if read_len < 4000:
+            assert gpu.last_path() == sm.PATH_FUSED, sm.lib().mm_last_error()
+        ho = offs.cpu().numpy()
+        hp, hs = out[:total].cpu().numpy().view(np.uint32), sk[:total].cpu().numpy().view(np.uint32)
+        assert ho[0] == 0 and ho[-1] == total
+        for r in range(n_reads):
+            want, wsk = oracle.run(data, int(lens[r]), k, w, canonical=canonical, base_offset=off + r * stride,
+                                   super_kmers=True)
+            assert np.array_equal(hp[ho[r]:ho[r + 1]], want), (k, w, r)
+            assert np.array_equal(hs[ho[r]:ho[r + 1]], wsk), (k, w, r)
+    # syncmer plans have no super-k-mers (src/lib.rs:339)
+    with pytest.raises(sm.MinimizerError):
+        sm.run_reads_device(sm.Builder(15, 17, True, 1), d, 2, 100, 100, out, offs, out_sk=sk)
+
+
 def test_reads_mode_dense_and_long(sm, oracle, gpu):
     """Low-complexity reads (every window emits -> list overflow -> direct redo) and reads too
     long for the LDS lists (fallback to one launch per read)."""
