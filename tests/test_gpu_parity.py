@@ -295,6 +295,44 @@ def test_low_complexity_dense_output(sm, oracle, gpu):
             assert c == len(want) and np.array_equal(out[:c].cpu().numpy().view(np.uint32), want), (unit, k, w)
 
 
+def test_mixed_density_lists_with_superkmers(sm, oracle, gpu):
+    """Sequences whose lanes emit between a few and all of their windows: lane lists shorter than a
+    wave, longer than a wave (second copy-out loop) and overflowing (direct redo) in the same run —
+    positions and super-k-mer indices (packed list entries) against the oracle."""
+    import torch
+    rng = np.random.default_rng(5)
+    n = 1_200_000
+    codes = rng.integers(0, 4, size=n).astype(np.uint8)
+    pos = 0
+    while pos < n:  # homopolymer stretches of growing length between random stretches
+        run = int(rng.integers(20, 400))
+        codes[pos:pos + run] = codes[pos]
+        pos += run + int(rng.integers(100, 900))
+    seq = np.frombuffer(b"ACTG", dtype=np.uint8)[codes].tobytes()
+    data = oracle.pack_ascii(seq)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    sk = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for k, w, canonical in [(21, 11, True), (21, 11, False), (9, 5, True), (31, 51, True), (12, 18, True)]:
+        want, wsk = oracle.run(data, n, k, w, canonical=canonical, super_kmers=True)
+        b = sm.Builder(k, w, canonical, 0)
+        c = b.run_device(d, n, out)
+        assert c == len(want) and np.array_equal(out[:c].cpu().numpy().view(np.uint32), want), (k, w, "pos")
+        c = b.run_device(d, n, out, out_sk=sk)
+        assert gpu.last_path() == sm.PATH_FUSED
+        assert c == len(want) and np.array_equal(out[:c].cpu().numpy().view(np.uint32), want), (k, w, "pos+sk")
+        assert np.array_equal(sk[:c].cpu().numpy().view(np.uint32), wsk), (k, w, "sk")
+    # the same through reads mode (reads of 400 bases cut from the sequence)
+    n_reads, stride, read_len = 2500, 400, 400
+    offs = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
+    total = sm.run_reads_device(sm.Builder(21, 11, True, 0), d, n_reads, stride, read_len, out, offs, out_sk=sk)
+    ho = offs.cpu().numpy()
+    hp, hs = out[:total].cpu().numpy().view(np.uint32), sk[:total].cpu().numpy().view(np.uint32)
+    for r in range(0, n_reads, 7):
+        want, wsk = oracle.run(data, read_len, 21, 11, canonical=True, base_offset=r * stride, super_kmers=True)
+        assert np.array_equal(hp[ho[r]:ho[r + 1]], want) and np.array_equal(hs[ho[r]:ho[r + 1]], wsk), r
+
+
 def test_custom_hasher_tables(sm, oracle, gpu):
     """.hasher(&h) (src/lib.rs:327): tables cross the ABI as data (seeded hashers)."""
     rng = np.random.default_rng(77)
