@@ -400,7 +400,11 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         // Table look-ups do not depend on the hash state: issue them PF steps ahead so that the
         // LDS latency is off the serial fw/rc chain (the emit below ends a scheduling region at
         // every step, so the compiler cannot hoist them by itself).
+#ifdef MM_PF
+        constexpr int PF = W < MM_PF ? W : MM_PF;
+#else
         constexpr int PF = W < 12 ? W : 12;
+#endif
         uint2 tq[W];
         auto lookup = [&](int j) -> uint2 {
             const int jj = j & 15, g = j >> 4, m = jj >> 1;

@@ -7,7 +7,8 @@ import simd_minimizers_amd as sm
 n = 3_100_000_000
 d = sm.generate_device(n, 3); ws = sm.default_workspace(0)
 out = torch.zeros(int(n * 0.2) + 1024, dtype=torch.int32, device="cuda")
-b = sm.Builder(21, 11, True, 0)
+CANON = os.environ.get("MM_NBLK_CANON", "1") == "1"
+b = sm.Builder(21, 11, CANON, 0)
 def t(warm=15, reps=15):
     for _ in range(warm): b.run_device(d, n, out, sync=False)
     ws.sync(); ws.enable_timing(True); ws.kernel_time(True)
