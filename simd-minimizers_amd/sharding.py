@@ -10,7 +10,9 @@ The path partitions into independent units, so there is no data-path collective:
     (src/collect.rs:265-271): concatenating the rank outputs in rank order IS the result.
 The only exchange is optional and tiny: an all-gather of the per-rank counts (offsets of each
 shard in a notional concatenated buffer) and, if a caller wants everything on one rank, a
-gather of the position buffers (RCCL over xGMI when the backend is nccl).
+gather of the position buffers to that rank (RCCL over xGMI when the backend is nccl: N-1
+point-to-point transfers into the root, each on its own link; device-resident shards are sent
+from HBM to HBM without touching the host).
 """
 from __future__ import annotations
 
@@ -38,6 +40,37 @@ def assign_contigs(lengths: Sequence[int], world: int) -> list[list[int]]:
     return out
 
 
+def _as_tensor(x, dev):
+    """uint32 positions as an int32 tensor on ``dev`` (device tensors stay where they are)."""
+    import torch
+    if isinstance(x, torch.Tensor):
+        return x.to(dev).view(torch.int32).reshape(-1)
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint32).view(np.int32)).to(dev)
+
+
+def gather_positions(local, counts: Sequence[int], gather_to: int, group=None):
+    """Variable-size gather of position buffers to ONE rank: every rank sends its (padded) buffer to
+    the root only - over xGMI these are N-1 point-to-point transfers into the root on separate links,
+    not an all-gather that would move every shard to everybody.  Returns the list of per-rank int32
+    tensors (trimmed to their counts) on the root, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    m = max(1, max(int(c) for c in counts))
+    t = _as_tensor(local, dev)
+    buf = torch.zeros(m, dtype=torch.int32, device=dev)
+    buf[: t.numel()] = t
+    parts = [torch.zeros_like(buf) for _ in range(world)] if rank == gather_to else None
+    dist.gather(buf, parts, dst=gather_to, group=group)
+    if rank != gather_to:
+        return None
+    return [p[: int(c)] for p, c in zip(parts, counts)]
+
+
 def run_sharded(compute: Callable[[int, int], np.ndarray], n_windows: int, group=None,
                 gather_to: int | None = None):
     """Run one window-range shard per rank.
@@ -53,25 +86,25 @@ def run_sharded(compute: Callable[[int, int], np.ndarray], n_windows: int, group
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     begin, end = shard_windows(n_windows, world)[rank]
-    local = np.ascontiguousarray(compute(begin, end), dtype=np.uint32)
+    local = compute(begin, end)
+    on_device = isinstance(local, torch.Tensor)  # device-resident shards stay on the device
+    if not on_device:
+        local = np.ascontiguousarray(local, dtype=np.uint32)
+    n_local = int(local.numel()) if on_device else len(local)
     if world == 1:
-        return local, [len(local)], (local if gather_to == 0 else None)
+        return local, [n_local], (local if gather_to == 0 else None)
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    cnt = torch.tensor([len(local)], dtype=torch.int64, device=dev)
+    cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
     counts_t = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts_t, cnt, group=group)
     counts = [int(c.item()) for c in counts_t]
     gathered = None
     if gather_to is not None:
-        # variable-size gather as a padded all-gather (payload is small: 4 B per ~(w+1)/2 bases)
-        m = max(counts) if counts else 0
-        buf = torch.zeros(max(m, 1), dtype=torch.int32, device=dev)
-        buf[: len(local)] = torch.from_numpy(local.view(np.int32)).to(dev)
-        parts = [torch.zeros_like(buf) for _ in range(world)]
-        dist.all_gather(parts, buf, group=group)
-        if rank == gather_to:
-            gathered = np.concatenate([p[:c].cpu().numpy().view(np.uint32) for p, c in zip(parts, counts)])
+        parts = gather_positions(local, counts, gather_to, group)
+        if parts is not None:
+            cat = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int32)
+            gathered = cat if on_device else cat.cpu().numpy().view(np.uint32)
     return local, counts, gathered
 
 
@@ -109,14 +142,9 @@ def run_contigs_sharded(compute_contig: Callable[[int], np.ndarray], lengths: Se
     gathered = None
     if gather_to is not None:
         per_rank = [int(sum(counts[i] for i in placement[r])) for r in range(world)]
-        m = max(per_rank) if per_rank else 0
-        buf = torch.zeros(max(m, 1), dtype=torch.int32, device=dev)
-        if local:
-            cat = np.concatenate(local) if sum(len(p) for p in local) else np.zeros(0, dtype=np.uint32)
-            buf[: len(cat)] = torch.from_numpy(cat.view(np.int32)).to(dev)
-        parts = [torch.zeros_like(buf) for _ in range(world)]
-        dist.all_gather(parts, buf, group=group)
-        if rank == gather_to:
+        cat = np.concatenate(local) if sum(len(p) for p in local) else np.zeros(0, dtype=np.uint32)
+        parts = gather_positions(cat, per_rank, gather_to, group)
+        if parts is not None:
             gathered = [None] * n
             for r in range(world):
                 flat = parts[r].cpu().numpy().view(np.uint32)

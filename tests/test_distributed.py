@@ -41,6 +41,19 @@ def _worker(rank, world, port, n, k, w, canonical, mode, q):
         return np.array(out, dtype=np.uint32)
 
     local, counts, gathered = sharding.run_sharded(compute, nw, gather_to=0)
+    # the same with shards handed over as tensors (what a device-resident caller does): they are
+    # sent as they are and the root receives one tensor
+    import torch
+
+    def compute_t(b, e):
+        return torch.from_numpy(compute(b, e).view(np.int32))
+
+    local_t, counts_t, gathered_t = sharding.run_sharded(compute_t, nw, gather_to=1)
+    assert counts_t == counts and isinstance(local_t, torch.Tensor)
+    assert (gathered_t is None) == (rank != 1)
+    if rank == 1:
+        want = o.run(data, n, k, w, canonical=canonical, mode=mode)
+        assert np.array_equal(gathered_t.numpy().view(np.uint32), want)
     if rank == 0:
         want = o.run(data, n, k, w, canonical=canonical, mode=mode)
         q.put((counts, bool(np.array_equal(gathered, want)), len(want)))
