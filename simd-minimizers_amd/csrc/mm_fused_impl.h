@@ -663,8 +663,15 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
 template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool READS>
 // (small W: at least 4 waves per SIMD, i.e. at most 128 VGPRs - the two-body walks sit right at that
 // limit; larger W need more registers and get no such bound)
+// Workgroups per CU the register allocation is bounded for.  Small W: 4 (128 VGPRs; the lists allow
+// 4 workgroups per CU).  Canonical walks keep two rings of W registers: unbounded they take 134-138
+// VGPRs for W = 19..31 (3 waves per SIMD) and 190-230 for W = 33..47 (2 waves per SIMD); bounding
+// them to 128 / 168 VGPRs costs a few spilled registers outside the main loop and wins a wave per
+// SIMD (measured on 1 Gbp, tools/gpu_w19.py: W = 19..29: -2..4 %, W = 33..47: -7..19 %; W >= 49
+// spill too much and stay unbounded, as do the forward walks, which gain nothing).
 #ifndef MM_MIN_BLOCKS
-#define MM_MIN_BLOCKS (W <= 12 ? 4 : 1)
+#define MM_MIN_BLOCKS \
+    (W <= 12 ? 4 : (CANON && !READS ? (W >= 19 && W <= 31 ? 4 : (W >= 32 && W <= 47 ? 3 : 1)) : 1))
 #endif
 __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // lane lists
