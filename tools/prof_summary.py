@@ -16,7 +16,10 @@ def summarize(path, out):
         if len(d) >= 4:
             half = d[len(d) // 2:]
             out.write("-- fused_kernel launches in order, us: " + " ".join(f"{x:.0f}" for x in d) + "\n")
-            out.write(f"-- average of the second half ({len(half)} launches, the timed steps): {sum(half) / len(half):.1f} us\n")
+            out.write(f"-- average of the second half ({len(half)} launches): {sum(half) / len(half):.1f} us\n")
+            if len(d) >= 60:  # the stats pass runs 40 warm-up + 20 timed steps
+                last = d[-20:]
+                out.write(f"-- average of the last 20 launches (the timed steps of the stats pass): {sum(last) / len(last):.1f} us\n")
     except Exception as e:
         out.write(f"(no per-launch durations: {e})\n")
     try:
