@@ -194,6 +194,11 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * g.nblocks, stream) != hipSuccess)
         return -1;
     if (hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
+    uint32_t lds_bytes = g.lds_bytes;
+    if (p.debug & 16u) {  // timing experiment (wrong results): lists of half the capacity, overflow ignored
+        p.list_cap = g.list_cap / 2 > a.w + 2 ? g.list_cap / 2 : a.w + 2;
+        lds_bytes = p.list_cap * kListStride;
+    }
     if (const char *pad = getenv("MM_LDS_PAD")) g_lds_pad = (uint32_t)atoi(pad);  // occupancy experiments
     p.trace = nullptr;
     if (const char *tr = getenv("MM_TRACE")) {
@@ -203,7 +208,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         if (hipMalloc(reinterpret_cast<void **>(&d_tr), bytes) != hipSuccess) return -1;
         hipMemsetAsync(d_tr, 0, bytes, stream);
         p.trace = d_tr;
-        int r = launch_kernel(kr, (uint32_t)g.nblocks, g.lds_bytes, stream, p, a.timing_start, a.timing_stop);
+        int r = launch_kernel(kr, (uint32_t)g.nblocks, lds_bytes, stream, p, a.timing_start, a.timing_stop);
         hipStreamSynchronize(stream);
         std::vector<unsigned long long> h(10 * g.nblocks);
         hipMemcpy(h.data(), d_tr, bytes, hipMemcpyDeviceToHost);
@@ -214,7 +219,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         }
         return r;
     }
-    return launch_kernel(kr, (uint32_t)g.nblocks, g.lds_bytes + g_lds_pad, stream, p, a.timing_start, a.timing_stop);
+    return launch_kernel(kr, (uint32_t)g.nblocks, lds_bytes + g_lds_pad, stream, p, a.timing_start, a.timing_stop);
 }
 
 // ------------------------------------------------------------------ reads mode

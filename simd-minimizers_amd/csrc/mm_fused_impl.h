@@ -871,7 +871,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         if (v < wave) wave_base += t;
         block_total += t;
     }
-    const bool overflow = s_overflow != 0;
+    const bool overflow = s_overflow != 0 && !(p.debug & 16u);  // 16: timing experiment with half-size lists
     const unsigned long long run0 = s_excl + wave_base;  // first output slot of this wave
     const uint32_t excl = incl - my_count;
     if (READS) {
