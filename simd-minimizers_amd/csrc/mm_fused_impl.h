@@ -403,7 +403,9 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
 #ifdef MM_PF
         constexpr int PF = W < MM_PF ? W : MM_PF;
 #else
-        constexpr int PF = W < 12 ? W : 12;
+        // (canonical w = 42..47 are bounded to 168 VGPRs: the shallower look-ahead keeps their
+        // rings out of scratch, w = 47: 0.753 -> 0.686 ms per Gbp)
+        constexpr int PF = W < 12 ? W : (CANON && W >= 42 && W <= 47 ? 4 : 12);
 #endif
         uint2 tq[W];
         auto lookup = [&](int j) -> uint2 {
