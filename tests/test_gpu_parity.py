@@ -333,6 +333,29 @@ def test_mixed_density_lists_with_superkmers(sm, oracle, gpu):
         assert np.array_equal(hp[ho[r]:ho[r + 1]], want) and np.array_equal(hs[ho[r]:ho[r + 1]], wsk), r
 
 
+def test_register_bounded_canonical_kernels(sm, oracle, gpu):
+    """Canonical kernels for w = 19..47 are compiled under a register bound (a few spilled registers,
+    one more wave per SIMD): positions, syncmers and super-k-mer indices against the oracle on a
+    multi-tile input, prebuilt (25, 31, 33, 41) and run-time specialised (45) window sizes."""
+    import torch
+    n = 1_500_003
+    data = oracle.gen_packed(78, n)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    sk = torch.zeros_like(out)
+    for w, modes in ((25, (0, 1, 2)), (31, (0,)), (33, (0, 2)), (41, (0, 1)), (45, (0,))):
+        k = 21
+        for mode in modes:
+            want = oracle.run(data, n, k, w, canonical=True, mode=mode)
+            c = sm.Builder(k, w, True, mode).run_device(d, n, out)
+            assert gpu.last_path() == sm.PATH_FUSED
+            assert c == len(want) and np.array_equal(out[:c].cpu().numpy().view(np.uint32), want), (w, mode)
+        want, wsk = oracle.run(data, n, k, w, canonical=True, super_kmers=True)
+        c = sm.Builder(k, w, True, 0).run_device(d, n, out, out_sk=sk)
+        assert c == len(want) and np.array_equal(out[:c].cpu().numpy().view(np.uint32), want), w
+        assert np.array_equal(sk[:c].cpu().numpy().view(np.uint32), wsk), w
+
+
 def test_custom_hasher_tables(sm, oracle, gpu):
     """.hasher(&h) (src/lib.rs:327): tables cross the ABI as data (seeded hashers)."""
     rng = np.random.default_rng(77)
