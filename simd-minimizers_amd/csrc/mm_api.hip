@@ -59,6 +59,12 @@ mm::HashTables make_tables(const mm_hasher_t &h, uint32_t k) {
         t.t_in[in].x = h.fw[in];
         t.t_in[in].y = rc_in[in];
     }
+    // two add-only steps folded into one look-up (warm-up of a lane's first k-mer)
+    for (int b = 0; b < 4; ++b)
+        for (int a = 0; a < 4; ++a) {
+            t.t_in2[(b << 2) | a].x = rotl32(t.t_in[a].x, R) ^ t.t_in[b].x;
+            t.t_in2[(b << 2) | a].y = rotr32(t.t_in[a].y, R) ^ t.t_in[b].y;
+        }
     t.rot = R;
     t.canonical = h.canonical ? 1u : 0u;
     return t;

@@ -35,6 +35,7 @@ constexpr int kFusedWaves = kFusedThreads / kWave;
 struct HashTables {
     uint2 t_in_out[16];  // index = (out << 2) | in
     uint2 t_in[4];
+    uint2 t_in2[16];     // two warm-up steps at once: index = (second << 2) | first
     uint32_t rot;
     uint32_t canonical;  // 1: h = fw + rc, 0: h = fw
 };

@@ -207,14 +207,21 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     uint32_t fw = 0, rc = 0;
     const uint8_t *tabb = reinterpret_cast<const uint8_t *>(ctx.tab);
 
-    // hash of element 0: k add-only steps, 16 bases per view word
+    // hash of element 0: k add-only steps, 16 bases per view word, two bases per look-up
+    // (s_tab[20 + ((second << 2) | first)]), a last odd base through the one-base table
+    const uint32_t rot2_l = (32u - 2u * p.ht.rot) & 31u, rot2_r = (2u * p.ht.rot) & 31u;
     for (uint32_t g = 0; g * 16u < k; ++g) {
         const uint32_t wa = g == 0 ? view_first(pb) : view(pb + 16 * (int32_t)g);
         const uint32_t rem = k - 16u * g;
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            if ((uint32_t)jj < rem) {
-                const uint32_t a8 = (jj == 0 ? (wa << 3) : (jj == 1 ? (wa << 1) : (wa >> (2 * jj - 3)))) & 0x18u;
+        for (int m = 0; m < 8; ++m) {
+            if ((uint32_t)(2 * m + 1) < rem) {
+                const uint32_t a8 = (m == 0 ? (wa << 3) : (wa >> (4 * m - 3))) & 0x78u;
+                const uint2 t = *reinterpret_cast<const uint2 *>(tabb + 160 + a8);
+                fw = __builtin_amdgcn_alignbit(fw, fw, rot2_l) ^ t.x;
+                if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot2_r) ^ t.y;
+            } else if ((uint32_t)(2 * m) < rem) {
+                const uint32_t a8 = (m == 0 ? (wa << 3) : (wa >> (4 * m - 3))) & 0x18u;
                 const uint2 t = *reinterpret_cast<const uint2 *>(tabb + 128 + a8);
                 fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t.x;
                 if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t.y;
@@ -678,7 +685,7 @@ template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool READS>
 __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // lane lists
     // static LDS: distinct objects, so table look-ups can be scheduled across the list stores
-    __shared__ uint2 s_tab[20];  // [0..15] (out<<2)|in, [16..19] in only (warm-up)
+    __shared__ uint2 s_tab[36];  // [0..15] (out<<2)|in, [16..19] in only, [20..35] two bases in (warm-up)
     __shared__ uint32_t s_bid;
     __shared__ uint32_t s_overflow;
     __shared__ uint32_t s_done;  // waves 1.. that have finished phase 1
@@ -700,6 +707,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     }
     if (tid < 16) s_tab[tid] = p.ht.t_in_out[tid];
     else if (tid < 20) s_tab[tid] = p.ht.t_in[tid - 16];
+    else if (tid < 36) s_tab[tid] = p.ht.t_in2[tid - 20];
     __syncthreads();
     const uint32_t bid = __builtin_amdgcn_readfirstlane(s_bid);  // keep tile scalars in SGPRs
     if (p.trace && tid == 0) {
