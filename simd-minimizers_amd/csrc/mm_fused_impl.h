@@ -237,6 +237,13 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     asm volatile("v_mov_b32 %0, 0xffff0000" : "=v"(kmask));
 
     uint32_t va[NSUB], vr[NSUB], v2[NSUB];  // views of the block being processed
+    // The base leaving the strand window lags the base leaving the hash by exactly one W-block minus
+    // one base, so its view of block b is the hash-out view of block b - 1 moved on by one base: no
+    // third load stream unless W is a multiple of 16 (then the last base of the block is missing).
+    constexpr bool kV2Load = CANON && (W % 16 == 0);
+    auto next_base_view = [&](const uint32_t (&v)[NSUB], int g) -> uint32_t {
+        return g + 1 < NSUB ? __builtin_amdgcn_alignbit(v[g + 1 < NSUB ? g + 1 : g], v[g], 2u) : (v[g] >> 2);
+    };
     constexpr int PFD = MM_PREFETCH_BLOCKS;  // global loads run PFD W-blocks ahead of their use
     RawView qa[PFD - 1][NSUB], qr[PFD - 1][NSUB], q2[PFD - 1][NSUB];  // raw dwords of blocks b+2 .. b+PFD
 #pragma unroll
@@ -256,12 +263,19 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         }
         pos_in += W;
         pos_out += W;
-        // prefetch block 1 (its strand stream starts at pb + 1)
+        // prefetch block 1 (its strand stream starts at pb + 1: block 0's hash-out view, one base on)
+        if (CANON && !kV2Load) {
+            uint32_t t2[NSUB];
+#pragma unroll
+            for (int g = 0; g < NSUB; ++g) t2[g] = next_base_view(vr, g);
+#pragma unroll
+            for (int g = 0; g < NSUB; ++g) v2[g] = t2[g];
+        }
 #pragma unroll
         for (int g = 0; g < NSUB; ++g) {
             va[g] = view(pos_in + 16 * g);
             vr[g] = view(pos_out + 16 * g);
-            if (CANON) v2[g] = view(pb + 1 + 16 * g);
+            if (kV2Load) v2[g] = view(pb + 1 + 16 * g);
         }
         // ... and the raw dwords of block 2: global loads run two W-blocks ahead of their use, so
         // that a burst of copy-out stores of a neighbouring workgroup in the CU's memory pipeline
@@ -272,7 +286,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             for (int g = 0; g < NSUB; ++g) {
                 qa[d][g] = raw(pos_in + (d + 1) * W + 16 * g);
                 qr[d][g] = raw(pos_out + (d + 1) * W + 16 * g);
-                if (CANON) q2[d][g] = raw(pb + 1 + (d + 1) * W + 16 * g);
+                if (kV2Load) q2[d][g] = raw(pb + 1 + (d + 1) * W + 16 * g);
             }
 #pragma unroll
         for (int j = 0; j < W; ++j) {
@@ -368,22 +382,29 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         pos_in += W;
         pos_out += W;
         pos_r2 += W;
+        if (CANON && !kV2Load) {  // the next block's strand view, before vr moves on
+            uint32_t t2[NSUB];
+#pragma unroll
+            for (int g = 0; g < NSUB; ++g) t2[g] = next_base_view(vr, g);
+#pragma unroll
+            for (int g = 0; g < NSUB; ++g) v2[g] = t2[g];
+        }
         // views of the next block from the dwords loaded one block ago; issue the loads of the
         // block after it (a harmless over-read after the last block)
 #pragma unroll
         for (int g = 0; g < NSUB; ++g) {
             va[g] = aligned(qa[0][g], pos_in + 16 * g);
             vr[g] = aligned(qr[0][g], pos_out + 16 * g);
-            if (CANON) v2[g] = aligned(q2[0][g], pos_r2 + 16 * g);
+            if (kV2Load) v2[g] = aligned(q2[0][g], pos_r2 + 16 * g);
 #pragma unroll
             for (int d = 0; d + 1 < PFD - 1; ++d) {
                 qa[d][g] = qa[d + 1][g];
                 qr[d][g] = qr[d + 1][g];
-                if (CANON) q2[d][g] = q2[d + 1][g];
+                if (kV2Load) q2[d][g] = q2[d + 1][g];
             }
             qa[PFD - 2][g] = raw(pos_in + (PFD - 1) * W + 16 * g);
             qr[PFD - 2][g] = raw(pos_out + (PFD - 1) * W + 16 * g);
-            if (CANON) q2[PFD - 2][g] = raw(pos_r2 + (PFD - 1) * W + 16 * g);
+            if (kV2Load) q2[PFD - 2][g] = raw(pos_r2 + (PFD - 1) * W + 16 * g);
         }
         if (AMBI) {
 #pragma unroll
