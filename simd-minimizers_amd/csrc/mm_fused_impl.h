@@ -375,8 +375,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             mo[g] = ((va[g] >> 2) & 0x33333333u) | (vr[g] & 0xccccccccu);
             // 2-bit two's-complement fields: tg(in) - tg(leaving) in {-1,0,1}
             if (CANON) {
-                const uint32_t ti = (va[g] >> 1) & 0x55555555u, to = (v2[g] >> 1) & 0x55555555u;
-                tgw[g] = (ti ^ to) | ((to & ~ti) << 1);
+                // (bit 2j+1 of a view word = T|G of base j: low bit of the field = in ^ out, high bit =
+                // out & ~in; four instructions: xor, shift, and-not, bit-field insert)
+                const uint32_t x = va[g], y = v2[g];
+                tgw[g] = (((x ^ y) >> 1) & 0x55555555u) | ((y & ~x) & 0xAAAAAAAAu);
             }
         }
         pos_in += W;
