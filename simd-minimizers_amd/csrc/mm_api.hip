@@ -453,6 +453,7 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
         a.batch_offsets = nullptr;
         a.batch_n = 0;
         a.batch_tiles = 0;
+        a.work_windows = win_end - win_begin;
         if (amb) {
             r = prepare_window_ambiguity(ws, *amb, n_bases, (uint32_t)l, win_begin, win_end, &a.wamb_dwords);
             if (r) return r;
@@ -557,8 +558,10 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
     a.batch_offsets = nullptr;
     a.batch_n = (uint32_t)n_seqs;
     a.batch_tiles = 0;
-    const uint64_t NB = mm::fused_tile_windows(a);
     const uint64_t l = (uint64_t)plan->k + plan->w - 1;
+    a.work_windows = 0;
+    for (uint64_t s = 0; s < n_seqs; ++s) a.work_windows += n_bases[s] >= l ? n_bases[s] - l + 1 : 0;
+    const uint64_t NB = mm::fused_tile_windows(a);
 
     std::vector<mm::BatchSeq> seqs(n_seqs);
     std::vector<uint32_t> tile_seq;

@@ -37,14 +37,22 @@ double emit_density(uint32_t w, uint32_t mode) {
     return mode == 2 ? 1.0 / w : (mode == 1 ? 2.0 / w : 2.0 / (w + 1.0));
 }
 
-// W-blocks per lane (S = w * nblk windows per lane).  Default: the longest lane whose list
-// (1.3 x expected + 8 + w entries of kListStride bytes) keeps a workgroup near 40 KB of LDS
-// (4 workgroups per CU), but at least 12 W-blocks so that the k+w warm-up of a lane is amortised.
+// Entries per lane list: 1.3 x the expected number of emitted windows + 8 (> 5 sigma on random
+// sequence; denser tiles take the in-kernel redo path).
+uint32_t list_capacity(uint32_t w, uint32_t mode, uint32_t S) {
+    static const uint32_t extra = getenv("MM_CAP_EXTRA") ? (uint32_t)atoi(getenv("MM_CAP_EXTRA")) : 0u;  // experiments
+    uint32_t cap = (uint32_t)(1.3 * emit_density(w, mode) * S) + 8u + extra;
+    return cap > S + w ? S + w : cap;
+}
+
+// W-blocks per lane (S = w * nblk windows per lane).  Default: the longest lane whose list keeps
+// 76 entries of kListStride bytes, i.e. a workgroup near 39 KB of LDS (4 workgroups per CU), but
+// at least 12 W-blocks so that the k+w warm-up of a lane is amortised.
 uint32_t legal_nblk(uint32_t w, uint32_t mode, uint32_t want) {
     if (want == 0) {
-        const double s_lds = (69.0 - (double)w) / (1.3 * emit_density(w, mode));
-        const double s = s_lds > 12.0 * w ? s_lds : 12.0 * w;
-        want = (uint32_t)(s / w + 0.5);
+        want = (uint32_t)(68.0 / (1.3 * emit_density(w, mode)) / w) + 1u;
+        while (want > 12u && list_capacity(w, mode, w * want) > 76u) --want;
+        if (want < 12u) want = 12u;
     }
     if (want < 1u) want = 1u;
     while (w * want > 60000u && want > 1u) --want;  // 16-bit element positions inside a lane
@@ -62,6 +70,13 @@ constexpr uint32_t kMaxLdsBytes = 159u * 1024u;  // 160 KB per CU minus the stat
 Geometry geometry(const RunArgs &a) {
     Geometry g;
     g.nblk = legal_nblk(a.w, a.mode, a.nblk);
+    // Default lanes are as long as the lists allow; a run that would then have fewer than about
+    // eight rounds of tiles (1024 resident workgroups) gets shorter lanes, down to 12 W-blocks:
+    // the last, partly filled round of tiles costs more than the lanes' warm-up.
+    if (a.nblk == 0 && a.work_windows != 0) {
+        const uint64_t fit = a.work_windows / (8192ull * kFusedThreads * a.w);
+        if (fit < g.nblk) g.nblk = fit < 12u ? 12u : (uint32_t)fit;
+    }
     // super-k-mer runs pack (window << shift) + offset-in-window into the 16-bit list entry
     // (kSkShift in mm_fused_impl.h): the lane length is bounded by S << shift <= 65536
     if (a.out.sk && a.mode == 0) {
@@ -71,11 +86,7 @@ Geometry geometry(const RunArgs &a) {
     }
     for (;;) {
         g.S = a.w * g.nblk;
-        // Lane list capacity: 1.3 x the expected number of emitted windows + 8 (> 5 sigma on random
-        // sequence; denser tiles take the in-kernel redo path) + one W-block of head-room, because
-        // the kernel checks the remaining room once per W-block.
-        uint32_t cap = (uint32_t)(1.3 * emit_density(a.w, a.mode) * g.S) + 8u + a.w;
-        if (cap > g.S + a.w) cap = g.S + a.w;
+        const uint32_t cap = list_capacity(a.w, a.mode, g.S);
         g.list_cap = cap;
         g.lds_bytes = cap * kListStride;
         // large w (run-time specialised kernels): shorten the lanes until the lists fit the LDS
@@ -263,7 +274,7 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     // sequence mode (fewer tiles: less look-back and copy-out overhead per window).  MM_READS_PER_LANE
     // overrides (experiments).
     auto cap_for = [&](uint32_t r) {
-        uint32_t c = (uint32_t)(1.3 * emit_density(a.w, a.mode) * S * r) + 8u + a.w;
+        const uint32_t c = (uint32_t)(1.3 * emit_density(a.w, a.mode) * S * r) + 8u;
         return c > (S + a.w) * r ? (S + a.w) * r : c;
     };
     // as many reads per lane (up to 4) as keep the lists near 40 KB, i.e. 4 workgroups per CU

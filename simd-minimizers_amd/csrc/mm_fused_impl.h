@@ -415,6 +415,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 aw_next[g] = aview(ctx.abase + b * (uint32_t)W + 32u * (uint32_t)g);
             }
         }
+#ifdef MM_LIST_PARK
         if (!DIRECT) {
             // keep a whole block of appends inside the list: a lane that is about to run out of
             // slots is parked on its last W slots (its tile is then redone in DIRECT mode)
@@ -424,6 +425,12 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 lp32 = park;
             }
         }
+#endif
+        // (default: no check inside the walk.  Entry c of a lane sits at c * kListStride + 2 * lane, so
+        // entries past the capacity lie past the end of the workgroup's LDS allocation - the lists are
+        // the dynamic part, placed behind the static variables - where the hardware drops the writes;
+        // the slot pointer keeps counting, the overflow shows at the end of the walk and the tile is
+        // redone storing directly.)
 
         const uint32_t e0 = b * (uint32_t)W;  // element index of step j = 0
         uint32_t pl = 0, pr_ = 0;
@@ -608,7 +615,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             if (CANON) ring_r[j] = max(ring_r[j], ring_r[j + 1]);
         }
     }
-    overflowed = dropped != 0;  // a parked list is no longer in order
+    overflowed = dropped != 0 || lp32 > lp_end;  // entries were dropped (or a parked list is out of order)
     if (DIRECT) return (uint32_t)(dst - ctx.dst);
     return (lp32 - list0) / kListStride + dropped;
 }
@@ -700,10 +707,12 @@ template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool READS>
 // VGPRs for W = 19..31 (3 waves per SIMD) and 190-230 for W = 33..47 (2 waves per SIMD); bounding
 // them to 128 / 168 VGPRs costs a few spilled registers outside the main loop and wins a wave per
 // SIMD (measured on 1 Gbp, tools/gpu_w19.py: W = 19..29: -2..4 %, W = 33..47: -7..19 %; W >= 49
-// spill too much and stay unbounded, as do the forward walks, which gain nothing).
+// spill too much for a third wave; w = 48..64 are bounded to 256 registers, which they need anyway
+// for two waves per SIMD - unbounded the scheduler may take more; the forward walks stay unbounded,
+// they gain nothing).
 #ifndef MM_MIN_BLOCKS
 #define MM_MIN_BLOCKS \
-    (W <= 12 ? 4 : (CANON && !READS ? (W >= 19 && W <= 31 ? 4 : (W >= 32 && W <= 47 ? 3 : 1)) : 1))
+    (W <= 12 ? 4 : (CANON && !READS ? (W >= 19 && W <= 31 ? 4 : (W >= 32 && W <= 47 ? 3 : (W >= 48 && W <= 64 ? 2 : 1))) : 1))
 #endif
 __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // lane lists
@@ -946,8 +955,8 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
                 __builtin_amdgcn_readfirstlane((p.debug & 8u) ? 0u : 0xffffffffu);  // timing experiment: no store
             // Fast path (the whole wave fits the caller's capacity, no SK): the lane mask "entry <
             // length of the list" and the list's byte offset are made on the scalar unit (s_bfm ->
-            // exec, soffset), so a list costs 2 v_readlane + 1 v_add; lists of 64 and more entries
-            // are left to the loop below.
+            // exec, soffset), so a list costs 2 v_readlane + 1 v_add; of lists with more than 64 entries
+            // the first 64 are stored here, the rest by the loop below.
 #ifdef MM_NO_FAST
             const bool fast = false;
 #else
@@ -986,11 +995,11 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
                         unsigned long long sv;
                         if (SK)
                             asm volatile(
-                                "s_cmp_lt_u32 %[n], 64\n\t"
-                                "s_cselect_b32 %[t0], %[n], 0\n\t"
-                                "s_and_b32 %[t0], %[t0], %[sm]\n\t"
+                                "s_and_b32 %[t0], %[n], %[sm]\n\t"
                                 "s_mov_b64 %[sv], exec\n\t"
                                 "s_bfm_b64 exec, %[t0], 0\n\t"
+                                "s_cmp_lt_u32 %[t0], 64\n\t"
+                                "s_cselect_b64 exec, exec, -1\n\t"
                                 "s_lshl_b32 %[t0], %[off], 2\n\t"
                                 "buffer_store_dword %[val], %[lane4], %[desc], %[t0] offen " MM_STORE_MOD "\n\t"
                                 "buffer_store_dword %[val2], %[lane4], %[desc2], %[t0] offen " MM_STORE_MOD "\n\t"
@@ -1001,11 +1010,11 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
                                 : "scc", "memory");
                         else
                         asm volatile(
-                            "s_cmp_lt_u32 %[n], 64\n\t"
-                            "s_cselect_b32 %[t0], %[n], 0\n\t"
-                            "s_and_b32 %[t0], %[t0], %[sm]\n\t"
+                            "s_and_b32 %[t0], %[n], %[sm]\n\t"
                             "s_mov_b64 %[sv], exec\n\t"
                             "s_bfm_b64 exec, %[t0], 0\n\t"
+                            "s_cmp_lt_u32 %[t0], 64\n\t"
+                            "s_cselect_b64 exec, exec, -1\n\t"
                             "s_lshl_b32 %[t0], %[off], 2\n\t"
                             "buffer_store_dword %[val], %[lane4], %[desc], %[t0] offen " MM_STORE_MOD "\n\t"
                             "s_mov_b64 exec, %[sv]"
@@ -1037,14 +1046,15 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
                     }
                 }
             }
-            // lists longer than one wave (dense output): the remaining entries, list by list
-            if (__ballot(my_count >= (uint32_t)kWave)) {
-                for (uint32_t L = 0; L < kWave; ++L) {
+            // lists longer than one wave: the entries from the 65th on, list by list (both paths above
+            // have stored the first 64)
+            for (unsigned long long longer = __ballot(my_count > (uint32_t)kWave); longer; longer &= longer - 1ull) {
+                {
+                    const uint32_t L = (uint32_t)__builtin_ctzll(longer);
                     const uint32_t n = __builtin_amdgcn_readlane(my_count, L);
                     const uint32_t off = __builtin_amdgcn_readlane(excl, L);
                     const uint32_t vb = READS ? vb0 : vb0 + L * S;
-                    // (the fast path above skipped lists of 64 and more entries entirely)
-                    for (uint32_t c = (fast && n >= (uint32_t)kWave ? 0u : (uint32_t)kWave) + lane; c < n; c += kWave) {
+                    for (uint32_t c = (uint32_t)kWave + lane; c < n; c += kWave) {
                         const uint8_t *q = rd + 2u * L + (c - lane) * kListStride;
                         const uint32_t e1 = *reinterpret_cast<const uint16_t *>(q);
                         const uint32_t iw = e1 >> kSh;

@@ -28,6 +28,7 @@ struct RunArgs {
     uint64_t batch_tiles;
     // fused path
     uint32_t nblk;  // w-blocks per lane (0 = default)
+    uint64_t work_windows;  // windows of the whole run (0 = unknown): short runs get shorter lanes (more tiles)
     int use_ticket; // tile ids from an atomic ticket instead of blockIdx.x (safe mode)
     // generic path
     void *scratch;
