@@ -389,7 +389,12 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
 #pragma unroll
             for (int g = 0; g < NSUB; ++g) t2[g] = next_base_view(vr, g);
 #pragma unroll
-            for (int g = 0; g < NSUB; ++g) v2[g] = t2[g];
+            for (int g = 0; g < NSUB; ++g) {
+                v2[g] = t2[g];
+                // (made here, not sunk into the next iteration: otherwise the old vr has to be carried
+                // around the loop in a second register)
+                asm volatile("" : "+v"(v2[g]));
+            }
         }
         // views of the next block from the dwords loaded one block ago; issue the loads of the
         // block after it (a harmless over-read after the last block)
