@@ -216,10 +216,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel_ms": round(kern_s * 1e3, 4), "algorithmic_bytes": alg_bytes,
-                         "note": "HBM is the nominal bound (SURVEY.md 8d); the kernel is VALU-issue bound: 22.5 "
-                                 "VALU instructions per window, 86 % VALU-pipe utilisation by PMC "
-                                 "(profiles/r01_v8_pmc_sq.txt, DESIGN.md 4.1); measured HBM traffic is 1.10x "
-                                 "the algorithmic bytes"},
+                         "note": "HBM is the nominal bound (SURVEY.md 8d); the kernel is VALU-issue bound: 21 "
+                                 "VALU instructions per window in the main loop, 86 % VALU-pipe utilisation "
+                                 "by PMC (profiles/r01_v8_pmc_sq.txt, DESIGN.md 4.1); measured HBM traffic "
+                                 "is 1.08x the algorithmic bytes (profiles/traffic.json)"},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
