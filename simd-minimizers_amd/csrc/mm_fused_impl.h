@@ -367,6 +367,14 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // value of an emitted window: mode 0: (bw0 + lw - 1) + element index; syncmers: bw0 + lw + i
     const uint32_t wbase = ctx.wbase;
     const uint32_t vbase = wbase - (MODE == 0 ? 1u : 0u);
+    // Running per-lane registers for the main loop, advanced by literal adds: an add whose other
+    // operand is an SGPR issues at half rate on gfx950 (profiles/r01_valu_issue_rates.txt), and that
+    // is the form the compiler picks for base + block * W.  sh_*: funnel-shift amount of the next
+    // block's view (the hardware uses its low five bits); pl_*: base position of the loads that run
+    // PFD - 1 blocks ahead.
+    uint32_t sh_in = 2u * (uint32_t)pos_in, sh_out = 2u * (uint32_t)pos_out;
+    uint32_t pl_in = (uint32_t)pos_in + (uint32_t)((PFD - 1) * W), pl_out = (uint32_t)pos_out + (uint32_t)((PFD - 1) * W);
+#define MM_BUMP(x, c) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "n"(c))
     for (uint32_t b = 1; b <= nblk; ++b) {
         uint32_t me[NSUB], mo[NSUB], tgw[NSUB];
 #pragma unroll
@@ -384,6 +392,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         pos_in += W;
         pos_out += W;
         pos_r2 += W;
+        MM_BUMP(sh_in, 2 * W);
+        MM_BUMP(sh_out, 2 * W);
+        MM_BUMP(pl_in, W);
+        MM_BUMP(pl_out, W);
         if (CANON && !kV2Load) {  // the next block's strand view, before vr moves on
             uint32_t t2[NSUB];
 #pragma unroll
@@ -400,8 +412,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         // block after it (a harmless over-read after the last block)
 #pragma unroll
         for (int g = 0; g < NSUB; ++g) {
-            va[g] = aligned(qa[0][g], pos_in + 16 * g);
-            vr[g] = aligned(qr[0][g], pos_out + 16 * g);
+            va[g] = __builtin_amdgcn_alignbit(qa[0][g][1], qa[0][g][0], sh_in);
+            vr[g] = __builtin_amdgcn_alignbit(qr[0][g][1], qr[0][g][0], sh_out);
             if (kV2Load) v2[g] = aligned(q2[0][g], pos_r2 + 16 * g);
 #pragma unroll
             for (int d = 0; d + 1 < PFD - 1; ++d) {
@@ -409,8 +421,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 qr[d][g] = qr[d + 1][g];
                 if (kV2Load) q2[d][g] = q2[d + 1][g];
             }
-            qa[PFD - 2][g] = raw(pos_in + (PFD - 1) * W + 16 * g);
-            qr[PFD - 2][g] = raw(pos_out + (PFD - 1) * W + 16 * g);
+            qa[PFD - 2][g] = raw((int32_t)pl_in + 16 * g);
+            qr[PFD - 2][g] = raw((int32_t)pl_out + 16 * g);
             if (kV2Load) q2[PFD - 2][g] = raw(pos_r2 + (PFD - 1) * W + 16 * g);
         }
         if (AMBI) {

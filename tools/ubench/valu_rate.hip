@@ -41,7 +41,25 @@ __global__ __launch_bounds__(256) void k(unsigned *out, unsigned seed, int iters
     if (OP == 24) asm volatile("v_pk_min_u16 %0, %1, %0" : "+v"(x) : "v"(b));                     \
     if (OP == 25) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));           \
     if (OP == 26) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));            \
-    if (OP == 27) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+    if (OP == 27) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));                \
+    if (OP == 28) asm volatile("v_mov_b32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "+v"(x)); \
+    if (OP == 29) asm volatile("v_and_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "+v"(x) : "v"(b)); \
+    if (OP == 30) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(x) : "v"(b)); \
+    if (OP == 31) asm volatile("v_cmp_ne_u32_sdwa vcc, %0, %1 src0_sel:WORD_0 src1_sel:WORD_0" : : "v"(x), "v"(b) : "vcc"); \
+    if (OP == 32) asm volatile("v_bfe_i32 %0, %0, 4, 2" : "+v"(x));                               \
+    if (OP == 33) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(x) : "v"(b), "v"(c));            \
+    if (OP == 34) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(x));                              \
+    if (OP == 35) asm volatile("v_or_b32 %0, %1, %0" : "+v"(x) : "v"(b));                         \
+    if (OP == 36) asm volatile("v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(x) : "v"(b)); \
+    if (OP == 37) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(b));                        \
+    if (OP == 38) asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(x) : "v"(b));                     \
+    if (OP == 39) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xea" : "+v"(x) : "v"(b), "s"(seed)); \
+    if (OP == 40) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "s"(seed));                     \
+    if (OP == 41) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(x) : "s"(seed));                     \
+    if (OP == 42) asm volatile("v_add_u32 %0, 0x204, %0" : "+v"(x));                              \
+    if (OP == 43) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(x) : "s"(seed));                 \
+    if (OP == 44) asm volatile("v_and_b32 %0, %1, %0" : "+v"(x) : "s"(seed));                     \
+    if (OP == 45) asm volatile("v_bitop3_b32 %0, %1, %0, %2 bitop3:0xea" : "+v"(x) : "s"(seed), "v"(b));
             STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
         }
     }
@@ -72,5 +90,10 @@ int main() {
     run<14>("v_ashrrev_i32", d); run<15>("v_cndmask_b32 sgpr-mask", d); run<16>("v_lshl_add_u32", d); run<17>("v_mad_u32_u24", d);
     run<18>("v_sub_u32", d); run<19>("v_max_u32", d); run<20>("v_and_b32 lit", d); run<21>("v_lshl_or_b32", d); run<22>("v_min_i32", d);
     run<23>("v_min_f32", d); run<24>("v_pk_min_u16", d); run<25>("v_add3_u32", d); run<26>("v_xad_u32", d); run<27>("v_perm_b32", d);
+    run<28>("v_mov_b32_sdwa byte", d); run<29>("v_and_b32_sdwa byte", d); run<30>("v_add_u32_sdwa byte", d);
+    run<31>("v_cmp_ne_u32_sdwa", d); run<32>("v_bfe_i32", d); run<33>("v_bfi_b32", d); run<34>("v_lshlrev_b32", d);
+    run<35>("v_or_b32", d); run<36>("v_add_u32_sdwa sext byte", d); run<37>("v_sub_u32 vv", d); run<38>("v_subrev_u32", d);
+    run<39>("v_bitop3_b32 vvs", d); run<40>("v_add_u32 sv", d); run<41>("v_xor_b32 sv", d); run<42>("v_add_u32 literal", d);
+    run<43>("v_lshrrev_b32 sv", d); run<44>("v_and_b32 sv", d); run<45>("v_bitop3_b32 svv", d);
     return 0;
 }
