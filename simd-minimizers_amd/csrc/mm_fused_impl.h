@@ -235,6 +235,11 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // 0xffff0000 kept in a VGPR so that (h & mask) | e is one v_and_or_b32 with e in an SGPR
     uint32_t kmask;
     asm volatile("v_mov_b32 %0, 0xffff0000" : "=v"(kmask));
+    // bit masks of the per-block word merges, in VGPRs for the same reason (v_bitop3 with three VGPR
+    // sources issues at full rate; v_bfi and anything with an SGPR source at half rate)
+    uint32_t m33, m55;
+    asm volatile("v_mov_b32 %0, 0x33333333" : "=v"(m33));
+    asm volatile("v_mov_b32 %0, 0x55555555" : "=v"(m55));
 
     uint32_t va[NSUB], vr[NSUB], v2[NSUB];  // views of the block being processed
     // The base leaving the strand window lags the base leaving the hash by exactly one W-block minus
@@ -379,14 +384,23 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         uint32_t me[NSUB], mo[NSUB], tgw[NSUB];
 #pragma unroll
         for (int g = 0; g < NSUB; ++g) {
+#if !defined(MM_VGPR_MASKS) || MM_VGPR_MASKS
+            me[g] = select3(m33, va[g], vr[g] << 2);
+            mo[g] = select3(m33, va[g] >> 2, vr[g]);
+#else
             me[g] = (va[g] & 0x33333333u) | ((vr[g] << 2) & 0xccccccccu);
             mo[g] = ((va[g] >> 2) & 0x33333333u) | (vr[g] & 0xccccccccu);
+#endif
             // 2-bit two's-complement fields: tg(in) - tg(leaving) in {-1,0,1}
             if (CANON) {
                 // (bit 2j+1 of a view word = T|G of base j: low bit of the field = in ^ out, high bit =
                 // out & ~in; four instructions: xor, shift, and-not, bit-field insert)
                 const uint32_t x = va[g], y = v2[g];
+#if !defined(MM_VGPR_MASKS) || MM_VGPR_MASKS
+                tgw[g] = select3(m55, (x ^ y) >> 1, y & ~x);
+#else
                 tgw[g] = (((x ^ y) >> 1) & 0x55555555u) | ((y & ~x) & 0xAAAAAAAAu);
+#endif
             }
         }
         pos_in += W;
