@@ -59,7 +59,13 @@ __global__ __launch_bounds__(256) void k(unsigned *out, unsigned seed, int iters
     if (OP == 42) asm volatile("v_add_u32 %0, 0x204, %0" : "+v"(x));                              \
     if (OP == 43) asm volatile("v_lshrrev_b32 %0, %1, %0" : "+v"(x) : "s"(seed));                 \
     if (OP == 44) asm volatile("v_and_b32 %0, %1, %0" : "+v"(x) : "s"(seed));                     \
-    if (OP == 45) asm volatile("v_bitop3_b32 %0, %1, %0, %2 bitop3:0xea" : "+v"(x) : "s"(seed), "v"(b));
+    if (OP == 45) asm volatile("v_bitop3_b32 %0, %1, %0, %2 bitop3:0xea" : "+v"(x) : "s"(seed), "v"(b)); \
+    if (OP == 46) asm volatile("v_bitop3_b32 %0, %0, %1, 21 bitop3:0xea" : "+v"(x) : "v"(b));     \
+    if (OP == 47) asm volatile("v_pack_b32_f16 %0, %1, %0 op_sel:[0,1]" : "+v"(x) : "v"(b));     \
+    if (OP == 48) asm volatile("v_pack_b32_f16 %0, 21, %0 op_sel:[0,1]" : "+v"(x));              \
+    if (OP == 49) asm volatile("v_and_or_b32 %0, %0, %1, 21" : "+v"(x) : "v"(b));                \
+    if (OP == 50) asm volatile("v_readlane_b32 s20, %0, 3\n\tv_xor_b32 %0, %1, %0" : "+v"(x) : "v"(b) : "s20"); \
+    if (OP == 51) asm volatile("v_mov_b32 %0, %1" : "+v"(x) : "v"(b));
             STEP(a0) STEP(a1) STEP(a2) STEP(a3) STEP(a4) STEP(a5) STEP(a6) STEP(a7)
         }
     }
@@ -95,5 +101,7 @@ int main() {
     run<35>("v_or_b32", d); run<36>("v_add_u32_sdwa sext byte", d); run<37>("v_sub_u32 vv", d); run<38>("v_subrev_u32", d);
     run<39>("v_bitop3_b32 vvs", d); run<40>("v_add_u32 sv", d); run<41>("v_xor_b32 sv", d); run<42>("v_add_u32 literal", d);
     run<43>("v_lshrrev_b32 sv", d); run<44>("v_and_b32 sv", d); run<45>("v_bitop3_b32 svv", d);
+    run<46>("v_bitop3_b32 vv inline", d); run<47>("v_pack_b32_f16 vv op_sel", d); run<48>("v_pack_b32_f16 inline,v", d);
+    run<49>("v_and_or_b32 vv inline", d); run<50>("v_readlane + v_xor (pair)", d); run<51>("v_mov_b32 vv", d);
     return 0;
 }
