@@ -1008,6 +1008,10 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
             // an SK entry packs (window << shift) + offset-in-window (see kSkShift)
             constexpr uint32_t kSh = (uint32_t)kSkShift<W>, kRelMask = (1u << kSh) - 1u;
             const uint32_t lane4 = (uint32_t)lane * 4u;
+            // length and first slot of a lane's list in one word (one v_readlane per list instead of two;
+            // a list that is copied holds at most 315 entries - 159 KB of LDS - and a wave's lists at most
+            // 64 times that many)
+            const uint32_t pk = (excl << 9) | (my_count & 511u);
             if (fast) {
 #pragma unroll
                 for (int L0 = 0; L0 < kWave; L0 += kBatch) {
@@ -1016,8 +1020,8 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
                     for (int u = 0; u < kBatch; ++u) ent[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u));
 #pragma unroll
                     for (int u = 0; u < kBatch; ++u) {
-                        const uint32_t n = __builtin_amdgcn_readlane(my_count, L0 + u);
-                        const uint32_t off = __builtin_amdgcn_readlane(excl, L0 + u);
+                        const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
+                        const uint32_t n = pkl & 511u, off = pkl >> 9;
                         const uint32_t vbl = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
                         const uint32_t iw = ent[u] >> kSh;
                         const uint32_t val = SK ? vbl + iw + (ent[u] & kRelMask) : vbl + ent[u];
@@ -1065,8 +1069,8 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
                     for (int u = 0; u < kBatch; ++u) ent[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u));
 #pragma unroll
                     for (int u = 0; u < kBatch; ++u) {
-                        const uint32_t n = __builtin_amdgcn_readlane(my_count, L0 + u);
-                        const uint32_t off = __builtin_amdgcn_readlane(excl, L0 + u);
+                        const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
+                        const uint32_t n = pkl & 511u, off = pkl >> 9;
                         const uint32_t vb = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
                         uint32_t voff = (uint32_t)lane < n ? (off + (uint32_t)lane) * 4u : 0xffffffffu;
                         voff |= ~store_mask;
@@ -1082,8 +1086,8 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
             for (unsigned long long longer = __ballot(my_count > (uint32_t)kWave); longer; longer &= longer - 1ull) {
                 {
                     const uint32_t L = (uint32_t)__builtin_ctzll(longer);
-                    const uint32_t n = __builtin_amdgcn_readlane(my_count, L);
-                    const uint32_t off = __builtin_amdgcn_readlane(excl, L);
+                    const uint32_t pkl = __builtin_amdgcn_readlane(pk, L);
+                    const uint32_t n = pkl & 511u, off = pkl >> 9;
                     const uint32_t vb = READS ? vb0 : vb0 + L * S;
                     for (uint32_t c = (uint32_t)kWave + lane; c < n; c += kWave) {
                         const uint8_t *q = rd + 2u * L + (c - lane) * kListStride;
