@@ -48,10 +48,28 @@ uint32_t list_capacity(uint32_t w, uint32_t mode, uint32_t S) {
 // W-blocks per lane (S = w * nblk windows per lane).  Default: the longest lane whose list keeps
 // 76 entries of kListStride bytes, i.e. a workgroup near 39 KB of LDS (4 workgroups per CU), but
 // at least 12 W-blocks so that the k+w warm-up of a lane is amortised.
-uint32_t legal_nblk(uint32_t w, uint32_t mode, uint32_t want) {
+// Longest list a default lane may hold.  76 entries (39 KB of lists, 4 workgroups per CU) is the LDS
+// bound; what decides below it is the cache footprint of the resident lanes: every lane streams its
+// own span of the sequence, S / 4 bytes apart from its neighbour's, and once the spans of all resident
+// lanes of a CU (1024 for the register-bound canonical walks, up to 1792 for the forward walks) no
+// longer fit its share of the XCD's 4 MB L2, the loads of the walk go to HBM line by line.  Measured
+// on 2 Gbp (cap limit 76 / 62 / 51 / 44 / 38): forward w = 19: 0.99 / 0.79 / 0.74 / 0.77 / 0.76 ms,
+// w = 33: 1.45 / 1.34 / 0.95 / 0.75 / 0.71; canonical w = 11: 1.20 / 1.23 / 1.32 / 1.41,
+// w = 25: 1.26 / 1.19 / 1.17 / 1.16, w = 33 (3 workgroups per CU): 1.35 / 1.30 / 1.25 / 1.30.
+uint32_t default_cap_limit(uint32_t w, bool canonical) {
+    if (!canonical) return w <= 20u ? 51u : 38u;
+    if (w <= 16u) return 76u;
+    if (w <= 20u) return 62u;
+    if (w <= 31u) return 44u;
+    if (w <= 36u) return 51u;
+    return 76u;
+}
+
+uint32_t legal_nblk(uint32_t w, uint32_t mode, uint32_t want, uint32_t cap_limit = 76u) {
     if (want == 0) {
+        if (const char *e = getenv("MM_CAP_LIMIT")) cap_limit = (uint32_t)atoi(e);  // experiments
         want = (uint32_t)(68.0 / (1.3 * emit_density(w, mode)) / w) + 1u;
-        while (want > 12u && list_capacity(w, mode, w * want) > 76u) --want;
+        while (want > 12u && list_capacity(w, mode, w * want) > cap_limit) --want;
         // open syncmers come in irregular clumps: their lists overflow far more often at the same
         // relative head-room, so keep the expected length near 30 entries (measured at k=15 w=17 on
         // 3.1 Gbp: 28 blocks 1.77 ms, 36: 2.03, 53: 2.49)
@@ -73,8 +91,8 @@ constexpr uint32_t kMaxLdsBytes = 159u * 1024u;  // 160 KB per CU minus the stat
 
 Geometry geometry(const RunArgs &a) {
     Geometry g;
-    g.nblk = legal_nblk(a.w, a.mode, a.nblk);
-    // Default lanes are as long as the lists allow; a run that would then have fewer than about
+    g.nblk = legal_nblk(a.w, a.mode, a.nblk, default_cap_limit(a.w, a.canonical_windows != 0));
+    // Default lanes are as long as the lists (and the cache, see default_cap_limit) allow; a run that would then have fewer than about
     // eight rounds of tiles (1024 resident workgroups) gets shorter lanes, down to 12 W-blocks:
     // the last, partly filled round of tiles costs more than the lanes' warm-up.
     if (a.nblk == 0 && a.work_windows != 0) {
