@@ -92,12 +92,13 @@ constexpr uint32_t kMaxLdsBytes = 159u * 1024u;  // 160 KB per CU minus the stat
 Geometry geometry(const RunArgs &a) {
     Geometry g;
     g.nblk = legal_nblk(a.w, a.mode, a.nblk, default_cap_limit(a.w, a.canonical_windows != 0));
-    // Default lanes are as long as the lists (and the cache, see default_cap_limit) allow; a run that would then have fewer than about
-    // eight rounds of tiles (1024 resident workgroups) gets shorter lanes, down to 12 W-blocks:
-    // the last, partly filled round of tiles costs more than the lanes' warm-up.
+    // Default lanes are as long as the lists (and the cache, see default_cap_limit) allow; a run too
+    // short to fill the chip once with such tiles (1024 resident workgroups) gets shorter lanes, down
+    // to 6 W-blocks (measured, k=21 w=11 canonical: 64 Mbp 65.7 us with 28 blocks per lane, 58.6 with
+    // 24; 16 Mbp 36.2 with 28, 29.9 with 6..12; from 256 Mbp on the long lanes win).
     if (a.nblk == 0 && a.work_windows != 0) {
-        const uint64_t fit = a.work_windows / (8192ull * kFusedThreads * a.w);
-        if (fit < g.nblk) g.nblk = fit < 12u ? 12u : (uint32_t)fit;
+        const uint64_t fit = a.work_windows / (1024ull * kFusedThreads * a.w);
+        if (fit < g.nblk) g.nblk = fit < 6u ? 6u : (uint32_t)fit;
     }
     // super-k-mer runs pack (window << shift) + offset-in-window into the 16-bit list entry
     // (kSkShift in mm_fused_impl.h): the lane length is bounded by S << shift <= 65536
