@@ -559,8 +559,18 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
     a.batch_n = (uint32_t)n_seqs;
     a.batch_tiles = 0;
     const uint64_t l = (uint64_t)plan->k + plan->w - 1;
+    // lane length: a tile should not be much larger than a typical sequence of the batch (every
+    // sequence starts a tile of its own), nor the batch too short to fill the chip
     a.work_windows = 0;
-    for (uint64_t s = 0; s < n_seqs; ++s) a.work_windows += n_bases[s] >= l ? n_bases[s] - l + 1 : 0;
+    uint64_t nonempty = 0;
+    for (uint64_t s = 0; s < n_seqs; ++s) {
+        a.work_windows += n_bases[s] >= l ? n_bases[s] - l + 1 : 0;
+        nonempty += n_bases[s] >= l ? 1 : 0;
+    }
+    if (nonempty) {
+        const uint64_t per_seq = a.work_windows / nonempty * 1024ull;
+        if (per_seq < a.work_windows) a.work_windows = per_seq ? per_seq : 1;
+    }
     const uint64_t NB = mm::fused_tile_windows(a);
 
     std::vector<mm::BatchSeq> seqs(n_seqs);
