@@ -302,7 +302,10 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     };
     // as many reads per lane (up to 4) as keep the lists near 40 KB, i.e. 4 workgroups per CU
     uint32_t R = 1;
-    while (R < 4u && cap_for(R + 1) * kListStride <= 40u * 1024u) ++R;
+    // ... and as keep the spans of the resident lanes in the L2 (about 100 bytes of sequence per lane, see
+    // default_cap_limit)
+    const uint32_t r_cache = a.read_stride >= 400u ? 1u : 400u / (a.read_stride ? a.read_stride : 1u);
+    while (R < 4u && R < r_cache && cap_for(R + 1) * kListStride <= 40u * 1024u) ++R;
     if (const char *e = getenv("MM_READS_PER_LANE")) R = (uint32_t)atoi(e);
     if (R < 1u) R = 1u;
     if (R > 4u) R = 4u;
