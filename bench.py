@@ -219,7 +219,8 @@ def main():
                          "note": "HBM is the nominal bound (SURVEY.md 8d); the kernel is VALU-issue bound: 21 "
                                  "VALU instructions per window in the main loop, 86 % VALU-pipe utilisation "
                                  "by PMC (profiles/r01_v8_pmc_sq.txt, DESIGN.md 4.1); measured HBM traffic "
-                                 "is 1.08x the algorithmic bytes (profiles/traffic.json)"},
+                                 + (f"is {traffic / alg_bytes:.2f}x the algorithmic bytes (profiles/traffic.json)"
+                                    if traffic else "not available for this size")},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
