@@ -4,9 +4,9 @@
 //
 //   phase 1  every lane of a 256-lane workgroup walks S = nblk*W consecutive windows serially,
 //            everything in registers.  The lane's 2-bit bases come straight from HBM/L2 through
-//            bounds-checked raw buffer loads (three funnel-shifted 16-base views per W-block:
-//            base entering the hash, base leaving the hash, base leaving the strand window),
-//            prefetched one W-block ahead.  Rolling ntHash costs ONE LDS table look-up per base
+//            bounds-checked raw buffer loads (two funnel-shifted 16-base views per W-block: base
+//            entering the hash, base leaving the hash; the base leaving the strand window comes
+//            from the previous block's hash-out view), issued two W-blocks ahead.  Rolling ntHash costs ONE LDS table look-up per base
 //            (s_tab[(out<<2)|in], 16 x uint2 = forward / reverse-complement contribution);
 //            keys are (hash_hi16 | pos16) for the leftmost minimum and the complemented key for
 //            the rightmost one; the two-stacks sliding minimum runs over blocks of W with the
@@ -19,8 +19,9 @@
 //   phase 2  lane counts -> DPP prefix sum -> decoupled look-back across workgroups for the
 //            global output offset; then each wave copies the 64 lists of its lanes, in lane
 //            order, to the output with coalesced u32 stores.  Output order == window order.
-//   redo     a lane list holds `list_cap` entries (about twice the expected number); a tile in
-//            which some list overflowed (low-complexity sequence) is walked a second time with
+//   redo     a lane list holds `list_cap` entries (1.3 x the expected number + 8; entries past it
+//            fall outside the workgroup's LDS allocation and are dropped by the hardware); a tile
+//            in which some list overflowed (low-complexity sequence) is walked a second time with
 //            the now-known output offsets, storing straight to HBM.
 //
 // No MFMA: this is integer / byte work bounded by VALU issue and HBM, not GEMM-shaped.
