@@ -38,7 +38,7 @@ def _length(rng, k, w):
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_fuzz_device_runs(sm, oracle, gpu, seed):
     import torch
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + int(os.environ.get("MM_FUZZ_OFFSET", "0")))  # other streams on demand
     tally = dict(cases=0, bases=0, positions=0, range_checks=0, sk=0)
     for it in range(150):
         k, w, canonical, mode = _plan(rng)
@@ -90,7 +90,7 @@ def test_fuzz_device_runs(sm, oracle, gpu, seed):
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_fuzz_batch_reads_and_ambiguous(sm, oracle, gpu, seed):
     import torch
-    rng = np.random.default_rng(2000 + seed)
+    rng = np.random.default_rng(2000 + seed + int(os.environ.get("MM_FUZZ_OFFSET", "0")))
     tally = dict(batches=0, batch_bases=0, reads=0, reads_checked=0, ambiguous=0, ambiguous_bases=0)
     for it in range(60):
         k, w, canonical, mode = _plan(rng)
