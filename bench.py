@@ -5,14 +5,28 @@ Metric (BASELINE.json): Gbases/s (whole node) for canonical minimizers k=21 w=11
 PackedSeq, with the achieved HBM GB/s against the MI355X roofline.
 
 A "step" is one pass of the hot path (one fused-kernel launch: packed-seq decode -> ntHash ->
-sliding min -> strand vote -> dedup/collect) over one 3.1 Gbp synthetic sequence that is already
-resident in HBM.  With N > 1 GPUs every rank owns one such sequence (independent genomes shard
-with no data-path collective: weak scaling); the barrier / max-over-ranks timing follows the
-driver contract.  Prints ONE JSON line on rank 0.
+sliding min -> strand vote -> dedup/collect) over synthetic input that is already resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W [--workload headline|contigs|strong]
+
+  headline  (default) every rank owns one 3.1 Gbp sequence, canonical k=21 w=11 (BASELINE config 3;
+            independent genomes shard with no data-path collective: weak scaling)
+  contigs   BASELINE config 4: 24 CHM13-like contigs, canonical k=31 w=51, placed on the N ranks
+            greedily longest first, ONE batch launch per rank and step; afterwards the position
+            buffers are gathered to rank 0 (RCCL over xGMI), timed separately (strong scaling)
+  strong    one 3.1 Gbp sequence cut into N window ranges (absolute positions, exact seam)
+
+With N > 1 and no launcher in the environment the script starts its N ranks itself (child processes,
+before anything in this process touches a GPU); under torchrun it uses the ranks it is given.  The
+timed region follows the driver contract: W untimed steps, barrier + synchronize, exactly K steps,
+synchronize + barrier, max over ranks.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -20,18 +34,53 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+N_SIMD = 1024           # 256 CUs x 4 SIMDs
 K, W = 21, 11
 N_BASES = 3_100_000_000
 SEED = 3
 CPU_SAMPLE_CHUNK = 256 * 1024 * 1024
 CPU_SAMPLE_SECONDS = 12.0
 CPU_SAMPLE_MAX_CHUNKS = 12
+METRIC = "Gbases/s (whole node) for canonical minimizers k=21 w=11 on 3.1 Gbp; HBM GB/s %peak"
 
 
+# --------------------------------------------------------------------------- launcher
+def spawn_ranks(args) -> int:
+    """`bench.py --gpus N` without a launcher: start N ranks as child processes of THIS process, which
+    never touches a GPU itself (no re-exec of a process that has initialised HIP).  Rank 0's stdout
+    (the JSON line) is passed through."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus),
+                    "LOCAL_WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0]
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=120 if rc == 0 else 5)
+        except subprocess.TimeoutExpired:
+            p.kill()  # this exact child, by pid
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
+
+
+# --------------------------------------------------------------------------- CPU baseline
 def cpu_baseline():
     """The oracle's one-pass port of the reference algorithm (oracle/mm_oracle.c: mmo_run_fast,
     two-stacks + ntHash, eight AVX2 lanes per thread when the host has them like the reference's
-    SIMD path, window ranges spread over all host cores like the reference's rayon-over-contigs
+    SIMD path, window ranges spread over the host cores like the reference's rayon-over-contigs
     benchmark) timed on this box's host cores on a bounded sample of the same
     workload.  Checker/baseline use only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -46,12 +95,16 @@ def cpu_baseline():
         lib = o.lib(o.build(native=True, out_dir=tempfile.mkdtemp(prefix="mm_oracle_")))
     except Exception:
         lib = o.lib()
-    threads = max(1, min(os.cpu_count() or 1, int(os.environ.get("MM_CPU_THREADS", "128"))))
-    quota = ""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, int(os.environ.get("MM_CPU_THREADS", "128"))))
+    quota = None
     try:  # a container may be allowed fewer CPUs than it sees (cgroup v2 cpu.max: quota period)
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if q != "max":
-            quota = f"; the container's cgroup cpu.max reads {int(q) / int(per):.0f} CPUs"
+            quota = int(q) / int(per)
     except Exception:
         pass
     h = o.default_hasher(True)
@@ -78,6 +131,7 @@ def cpu_baseline():
     lib.mmo_run_fast(g0.ctypes.data_as(C.POINTER(C.c_uint8)), 0, one_n, K, W, C.byref(h), 1, 1,
                      pos.ctypes.data_as(C.POINTER(C.c_uint32)), cap)
     one_thread = one_n / (time.perf_counter() - t0) / 1e9
+    value = total_n / total_t / 1e9
     flavour = "eight-lane AVX2" if lib.mmo_fast_lanes() == 8 else "scalar"
     model = "unknown CPU"
     try:
@@ -87,25 +141,84 @@ def cpu_baseline():
                 break
     except Exception:
         pass
+    limit = ""
+    if quota is not None:
+        # which limit applied: a quota that throttled would cap the speed-up near the quota
+        limit = (f"; cgroup cpu.max reads {quota:.0f} CPUs but the {threads} threads ran {value / one_thread:.0f}x "
+                 f"faster than one, so the quota {'did not throttle' if value / one_thread > 1.5 * quota else 'throttled'} this run")
     return {
-        "value": round(total_n / total_t / 1e9, 5), "unit": "Gbases/s", "cores": threads, "kind": "port",
+        "value": round(value, 5), "unit": "Gbases/s", "cores": threads, "kind": "port",
         "sample": f"{chunks} x {CPU_SAMPLE_CHUNK} bases of the same generator (seed {SEED}), canonical "
                   f"k={K} w={W}; {flavour} two-stacks + ntHash port of the reference (oracle/mm_oracle.c "
-                  f"mmo_run_fast, gcc -O3 -march=native), window ranges over {threads} threads on {model}{quota}; one thread: {one_thread:.3f} Gbases/s; the "
+                  f"mmo_run_fast, gcc -O3 -march=native), window ranges over {threads} threads "
+                  f"(sched_getaffinity: {avail} CPUs) on {model}{limit}; one thread: {one_thread:.3f} Gbases/s; the "
                   f"reference's own published figure (unstated x86 AVX2, 1 thread, not measured here) "
                   f"is 0.455 Gbases/s",
     }
 
 
+# --------------------------------------------------------------------------- recorded counters
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for f in ("mm_fused_impl.h", "mm_common.h"):
+        h.update(open(os.path.join(ROOT, "simd-minimizers_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def recorded_counters(kernel_ms):
+    """HBM traffic and SQ counters cannot be collected from inside this process: rocprofv3 gathers them
+    in separate passes around the same command (tools/prof_head.sh), and the condensed result is
+    committed as profiles/head_counters.json together with the hash of the kernel source it was
+    measured on.  Returns (traffic_bytes_per_launch or None, valu dict or None, provenance text)."""
+    path = os.path.join(ROOT, "profiles", "head_counters.json")
+    try:
+        c = json.load(open(path))
+    except Exception:
+        return None, None, "no profiles/head_counters.json"
+    stale = c.get("kernel_source_sha") != kernel_source_sha()
+    traffic = c.get("hbm_bytes_per_launch")
+    valu = None
+    try:
+        insts = float(c["SQ_INSTS_VALU"])
+        windows = float(c["windows_per_launch"])
+        thread_cyc = float(c["SQ_THREAD_CYCLES_VALU"])
+        sclk_hz = float(c["GRBM_GUI_ACTIVE_per_xcd"]) / (float(c["counter_pass_kernel_us"]) * 1e-6)
+        issue_clk = thread_cyc / (64.0 * insts)            # SIMD clocks one VALU wave-instruction occupies
+        per_window = insts * 64.0 / windows                # wave-instructions per 64 windows = per lane-window
+        # VALU-pipe time of one launch against the measured kernel time of THIS run
+        busy = insts * issue_clk / (N_SIMD * sclk_hz)
+        valu = {"insts_per_window": round(per_window, 2), "issue_clk": round(issue_clk, 2),
+                "frac": round(busy / (kernel_ms * 1e-3), 4), "sclk_mhz": round(sclk_hz / 1e6, 0),
+                "source": "recorded (profiles/head_counters.json), kernel time live" + ("; STALE: kernel source changed since" if stale else "")}
+    except Exception:
+        pass
+    prov = ("recorded by rocprofv3 PMC passes (profiles/head_counters.json: " + c.get("collected", "?") + ")"
+            + ("; STALE: the kernel source changed since" if stale else ""))
+    return traffic, valu, prov
+
+
+# --------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=20,
                     help="untimed steps; the GPU needs about a dozen 2 ms launches after idle to reach steady clocks")
-    ap.add_argument("--bases", type=int, default=N_BASES, help="bases per GPU (default: 3.1 Gbp)")
+    ap.add_argument("--workload", choices=["headline", "contigs", "strong"], default="headline")
+    ap.add_argument("--bases", type=int, default=N_BASES, help="bases per GPU (headline) / in total (strong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the untimed secondary configurations, the median-of-5 and the end-to-end figure")
     args = ap.parse_args()
+
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(spawn_ranks(args))  # before torch / HIP are even imported
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     import torch
     import torch.distributed as dist
@@ -116,15 +229,14 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = "RANK" in os.environ and "MASTER_PORT" in os.environ  # launched by torchrun
+    distributed = world > 1
     # MM_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a box with fewer GPUs
     # than ranks (ranks then share devices; a functional check, not a measurement)
     backend = os.environ.get("MM_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
+    elif distributed and torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPUs visible")
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -133,29 +245,147 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     dev = torch.device(f"cuda:{local_rank}")
+    rdev = dev if backend == "nccl" else torch.device("cpu")
 
     import simd_minimizers_amd as sm
+    from simd_minimizers_amd import sharding
 
-    n = args.bases
+    L = sm.lib()
     stream = torch.cuda.current_stream(dev)
     ws = sm.Workspace(local_rank, stream.cuda_stream)
-    b = sm.canonical_minimizers(K, W).workspace(ws)
 
-    # synthetic input written straight into HBM by the engine's generator kernel (seed per rank)
-    d_packed = torch.zeros((n + 3) // 4 + 64, dtype=torch.uint8, device=dev)
-    sm._check(sm.lib().mm_generate_device_async(ws.h, SEED + rank, 0, n, d_packed.data_ptr()))
-    cap = int(n * 2.3 / (W + 1)) + 4096
-    out = torch.empty(cap, dtype=torch.int32, device=dev)
-    d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+    def generate(n, seed):
+        t = torch.zeros((n + 3) // 4 + 64, dtype=torch.uint8, device=dev)
+        sm._check(L.mm_generate_device_async(ws.h, seed, 0, n, t.data_ptr()))
+        return t
+
+    def timed_kernel_ms(step, repeats=5):
+        """median of `repeats` single steps, each bracketed by HIP events on the workspace stream
+        (bench/src/bin/paper.rs:536-556: warm-up + 5 repeats, median)"""
+        ws.enable_timing(True)
+        ws.kernel_time(True)
+        ms = []
+        for _ in range(repeats):
+            step()
+            torch.cuda.synchronize(dev)
+            t, n = ws.kernel_time(True)
+            ms.append(t / max(1, n))
+        ws.enable_timing(False)
+        return statistics.median(ms), ms
+
+    extras = []
+    if rank == 0 and world == 1 and not args.no_extra and args.workload == "headline" and args.bases == N_BASES:
+        # Secondary configurations of BASELINE.json (untimed region, before the headline so that they
+        # also bring the clocks up): kernel time by HIP events, median of 5 after 3 warm-up steps.
+        def secondary(name, builder, n, seed, density, contigs=None):
+            b = builder.workspace(ws)
+            if contigs is None:
+                d = generate(n, seed)
+                out = torch.empty(int(n * density * 1.15) + 4096, dtype=torch.int32, device=dev)
+                cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+
+                def step():
+                    b.run_device(d, n, out, sync=False, d_count=cnt)
+            else:
+                d = [generate(m, sharding.CHM13_CONTIG_SEED0 + i) for i, m in enumerate(contigs)]
+                n = sum(contigs)
+                out = torch.empty(int(n * density * 1.15) + 4096, dtype=torch.int32, device=dev)
+                offs = [0]
+
+                def step():
+                    offs[:] = sm.run_batch_device(b, d, list(contigs), out)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize(dev)
+            med, _ = timed_kernel_ms(step)
+            ws.check()
+            n_out = int(cnt.item()) if contigs is None else int(offs[-1])
+            alg = (n + 3) // 4 + 4 * n_out
+            extras.append({"config": name, "bases": n, "outputs": n_out, "kernel_ms": round(med, 4),
+                           "Gbases_per_s": round(n / med / 1e6, 1),
+                           "frac": round(alg / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
+            del d, out
+            torch.cuda.empty_cache()
+
+        secondary("C2 forward minimizers k=21 w=11, 256 Mbp (G seed 2)", sm.minimizers(21, 11), 268_435_456, 2, 2 / 12)
+        secondary("forward minimizers k=21 w=11, 3.1 Gbp (G seed 3)", sm.minimizers(21, 11), N_BASES, SEED, 2 / 12)
+        secondary("C4 canonical minimizers k=31 w=51, 24 CHM13-like contigs, one batch launch",
+                  sm.canonical_minimizers(31, 51), 0, 0, 2 / 52, contigs=sharding.CHM13_CONTIG_LENGTHS)
+        secondary("C5 canonical closed syncmers k=15 w=17, 3.1 Gbp (G seed 3)", sm.canonical_closed_syncmers(15, 17),
+                  N_BASES, SEED, 2 / 17)
+
+    # ---------------------------------------------------------------- workload set-up
+    n = args.bases
+    gather_ms = None
+    if args.workload == "headline":
+        k, w = K, W
+        b = sm.canonical_minimizers(k, w).workspace(ws)
+        d_packed = generate(n, SEED + rank)
+        cap = int(n * 2.3 / (w + 1)) + 4096
+        out = torch.empty(cap, dtype=torch.int32, device=dev)
+        d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        my_bases, total_bases = n, n * world
+        scaling = "weak"
+        kernel_name = "mm::fused_kernel<11, true, true, 0, false, false>"
+        workload = (f"canonical minimizers k={k} w={w}, one {n} bp PackedSeq per GPU "
+                    f"(generator G seed {SEED}+rank), device-resident input and output")
+
+        def step():
+            b.run_device(d_packed, n, out, sync=False, d_count=d_count)
+
+        def outputs():
+            return int(d_count.item())
+    elif args.workload == "strong":
+        k, w = K, W
+        b = sm.canonical_minimizers(k, w).workspace(ws)
+        d_packed = generate(n, SEED)
+        nw = n - (k + w - 1) + 1
+        wb, we = sharding.shard_windows(nw, world)[rank]
+        cap = int((we - wb) * 2.3 / (w + 1)) + 4096
+        out = torch.empty(cap, dtype=torch.int32, device=dev)
+        d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        my_bases, total_bases = we - wb, n
+        scaling = "strong"
+        kernel_name = "mm::fused_kernel<11, true, true, 0, false, false>"
+        workload = (f"canonical minimizers k={k} w={w}, ONE {n} bp PackedSeq (G seed {SEED}) cut into {world} window "
+                    f"ranges, absolute positions, exact seam; device-resident")
+
+        def step():
+            b.run_device(d_packed, n, out, win_begin=wb, win_end=we, sync=False, d_count=d_count)
+
+        def outputs():
+            return int(d_count.item())
+    else:  # contigs: BASELINE config 4
+        k, w = 31, 51
+        b = sm.canonical_minimizers(k, w).workspace(ws)
+        lengths = list(sharding.CHM13_CONTIG_LENGTHS)
+        mine = sharding.assign_contigs(lengths, world)[rank]
+        d_seqs = [generate(lengths[i], sharding.CHM13_CONTIG_SEED0 + i) for i in mine]
+        my_lens = [lengths[i] for i in mine]
+        my_bases, total_bases = sum(my_lens), sum(lengths)
+        cap = int(my_bases * 2.3 / (w + 1)) + 4096
+        out = torch.empty(cap, dtype=torch.int32, device=dev)
+        offs = [0]
+        scaling = "strong"
+        kernel_name = "mm::fused_kernel<51, true, true, 0, false, false> (batch mode)"
+        workload = (f"canonical minimizers k={k} w={w}, 24 CHM13-like contigs ({total_bases} bp, G seed 100+contig) "
+                    f"placed greedily on {world} GPUs, one batch launch per GPU and step (mm_run_batch_device, "
+                    f"contig-local positions), RCCL gather of the position buffers to rank 0 timed separately")
+
+        def step():
+            offs[:] = sm.run_batch_device(b, d_seqs, my_lens, out)
+
+        def outputs():
+            return int(offs[-1])
     torch.cuda.synchronize(dev)
-
-    def step():
-        b.run_device(d_packed, n, out, sync=False, d_count=d_count)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
-    n_out = int(d_count.item())
+    if args.warmup == 0:
+        step()
+        torch.cuda.synchronize(dev)
+    n_out = outputs()
     assert 0 < n_out <= cap, (n_out, cap)
 
     ws.enable_timing(True)
@@ -173,55 +403,117 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms, launches = ws.kernel_time(True)
     ws.enable_timing(False)
+    ws.check()  # no asynchronous run of the timed loop reported a look-back time-out / kernel error
 
     if distributed:
-        rdev = dev if backend == "nccl" else torch.device("cpu")
         t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # every rank must have produced a plausible result (density ~ 2/(w+1))
-        ok = torch.tensor([1 if abs(n_out / n - 2.0 / (W + 1)) < 0.01 else 0], dtype=torch.int32, device=rdev)
+        ok = torch.tensor([1 if abs(n_out / my_bases - 2.0 / (w + 1)) < 0.01 else 0], dtype=torch.int32, device=rdev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         assert int(ok.item()) == 1, "a rank produced an implausible number of minimizers"
 
-    if rank == 0:
-        total_bases = float(n) * world * args.steps
-        alg_bytes = (n + 3) // 4 + 4 * n_out  # PackedSeq read + u32 positions written
-        kern_s = kern_ms / 1e3 / max(1, launches)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and n == N_BASES:
+    # ---------------------------------------------------------------- gather (config 4), separately timed
+    if args.workload == "contigs":
+        times = []
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            if distributed:
+                dist.barrier()
+            tg = time.perf_counter()
+            _, _, _, counts, gathered = sharding.run_contig_batch_sharded(
+                lambda idx: (out, offs), lengths, gather_to=0)
+            torch.cuda.synchronize(dev)
+            times.append((time.perf_counter() - tg) * 1e3)
+            if rank == 0:
+                assert gathered is not None and all(int(g.numel()) == int(c) for g, c in zip(gathered, counts))
+            del gathered
+        gather_ms = statistics.median(times)
+        total_out = int(sum(counts))
+    else:
+        total_out = None
+
+    # ---------------------------------------------------------------- untimed extras (rank 0, N = 1)
+    median5 = end_to_end = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        med, allms = timed_kernel_ms(step)
+        median5 = {"kernel_ms": round(med, 4), "Gbases_per_s": round(my_bases / med / 1e6, 1),
+                   "all_ms": [round(x, 4) for x in allms],
+                   "protocol": "warm-up + 5 repeats, median (bench/src/bin/paper.rs:536-556); kernel time by HIP events"}
+        if args.workload == "headline":
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                import ctypes as C
+
+                import numpy as np
+                hp, hp_owner = sm.pinned_array(((n + 3) // 4 + 64,), np.uint8)
+                hp[:] = d_packed.cpu().numpy()
+                ho, ho_owner = sm.pinned_array((n_out + 1024,), np.uint32)
+                ho[:] = 0
+                cnt = C.c_uint64()
+                plan = b.plan()
+                e2e = []
+                for i in range(4):
+                    te = time.perf_counter()
+                    sm._check(L.mm_run_host(plan.h, ws.h, hp.ctypes.data_as(C.POINTER(C.c_uint8)), 0, n,
+                                            ho.ctypes.data_as(C.POINTER(C.c_uint32)), None, n_out + 1024, C.byref(cnt)))
+                    if i:
+                        e2e.append((time.perf_counter() - te) * 1e3)
+                assert cnt.value == n_out
+                m = statistics.median(e2e)
+                end_to_end = {"ms": round(m, 2), "Gbases_per_s": round(n / m / 1e6, 1),
+                              "what": "mm_run_host: H2D of the packed bytes + kernel + D2H of the positions, "
+                                      "page-locked caller buffers (mm_host_alloc), pipelined in 16 chunks; "
+                                      "median of 3 after 1 warm-up; PCIe-bound, never part of `value`"}
+                del hp, ho, hp_owner, ho_owner
+            except Exception as e:  # host memory limits of the box
+                end_to_end = {"error": str(e)[:200]}
+
+    if rank == 0:
+        bases_done = float(total_bases) * args.steps
+        # PackedSeq read + u32 positions written, for the units ONE launch of this rank processes
+        alg_bytes = (my_bases + 3) // 4 + 4 * n_out
+        kern_s = kern_ms / 1e3 / max(1, launches)
         achieved = alg_bytes / kern_s / 1e9
+        traffic, valu, prov = (None, None, "not recorded for this workload")
+        if args.workload == "headline" and n == N_BASES:
+            traffic, valu, prov = recorded_counters(kern_s * 1e3)
+        config = {"workload": workload, "k": k, "w": w, "bases_per_gpu": my_bases, "outputs_per_gpu": n_out,
+                  "kernel": kernel_name, "parallelism": f"shard{world}"}
+        if gather_ms is not None:
+            config["gather_ms"] = round(gather_ms, 3)
+            config["gather"] = ("all-reduce of the per-contig counts + dist.gather of the device-resident position "
+                                f"buffers to rank 0 ({backend}); {total_out} positions in total; median of 3")
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "kernel_ms": round(kern_s * 1e3, 4), "algorithmic_bytes": alg_bytes,
+                    "traffic_source": prov,
+                    "note": "HBM is the nominal bound (SURVEY.md 8d); the kernel is VALU-issue bound, see `valu` "
+                            "(second bound: VALU-pipe time of one launch / kernel time) and DESIGN.md 4.1"}
+        if valu is not None:
+            roofline["valu"] = valu
         line = {
-            "metric": "Gbases/s (whole node) for canonical minimizers k=21 w=11 on 3.1 Gbp; HBM GB/s %peak",
-            "value": round(total_bases / dt / 1e9, 3),
+            "metric": METRIC,
+            "value": round(bases_done / dt / 1e9, 3),
             "unit": "Gbases/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"canonical minimizers k={K} w={W}, one {n} bp PackedSeq per GPU "
-                                   f"(generator G seed {SEED}+rank), device-resident input and output",
-                       "k": K, "w": W, "bases_per_gpu": n, "outputs_per_gpu": n_out,
-                       "kernel": "mm::fused_kernel<11, true, true, 0, false, false>", "parallelism": f"shard{world}"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel_ms": round(kern_s * 1e3, 4), "algorithmic_bytes": alg_bytes,
-                         "note": "HBM is the nominal bound (SURVEY.md 8d); the kernel is VALU-issue bound: 21 "
-                                 "VALU instructions per window in the main loop, 86 % VALU-pipe utilisation "
-                                 "by PMC (profiles/r01_v8_pmc_sq.txt, DESIGN.md 4.1); measured HBM traffic "
-                                 + (f"is {traffic / alg_bytes:.2f}x the algorithmic bytes (profiles/traffic.json)"
-                                    if traffic else "not available for this size")},
+            "config": config,
+            "roofline": roofline,
         }
+        if median5 is not None:
+            line["median_of_5"] = median5
+        if end_to_end is not None:
+            line["end_to_end"] = end_to_end
+        if extras:
+            line["extra"] = extras
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

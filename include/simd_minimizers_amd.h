@@ -63,7 +63,8 @@ enum {
     MM_ERR_VALUE_LEN = -11,           /* values_u64 needs len <= 32, values_u128 len <= 64 */
     MM_ERR_NO_DEVICE = -20,           /* no HIP device: the engine has no CPU fallback */
     MM_ERR_HIP = -21,                 /* a HIP call failed; see mm_last_error() */
-    MM_ERR_ALLOC = -22
+    MM_ERR_ALLOC = -22,
+    MM_ERR_ORDER = -23                /* mm_workspace_check: a look-back of an asynchronous run timed out */
 };
 
 const char *mm_strerror(int code);
@@ -98,6 +99,16 @@ uint32_t mm_plan_value_len(const mm_plan_t *plan);
 int mm_workspace_create(mm_workspace_t **out, int device, void *hip_stream);
 void mm_workspace_destroy(mm_workspace_t *ws);
 int mm_workspace_sync(mm_workspace_t *ws);
+/* Status of the ASYNCHRONOUS runs issued on this workspace since the last check (the reference has
+ * no counterpart: its calls are synchronous; this is the completion half of the *_async entry
+ * points).  Waits for the workspace stream, then returns MM_OK, or
+ *   MM_ERR_ORDER  the fused kernel's look-back timed out in one of them (workgroups were not
+ *                 dispatched in index order): that run's output and count are invalid; every later
+ *                 run on this workspace takes its tile ids from an atomic ticket, so repeating the
+ *                 runs issued since the last check gives the right result;
+ *   MM_ERR_HIP    a kernel refused to run (mm_last_error() says why).
+ * The synchronous entry points check (and repeat the run) themselves. */
+int mm_workspace_check(mm_workspace_t *ws);
 /* Force the generic (any k, any w) kernel family instead of the fused one (testing). */
 int mm_workspace_force_generic(mm_workspace_t *ws, int on);
 /* Windows per lane of the fused kernel, in units of w (0 = built-in default). Tuning knob. */
@@ -128,7 +139,8 @@ int mm_workspace_last_path(const mm_workspace_t *ws);
  *  capacity      elements available in d_out_pos (and d_out_sk)
  *  d_count       optional device uint64 receiving the number of outputs
  *
- * Asynchronous on the workspace stream.  Output order equals window order. */
+ * Asynchronous on the workspace stream.  Output order equals window order.  Completion status:
+ * mm_workspace_check(). */
 int mm_run_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
                         uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
                         uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,

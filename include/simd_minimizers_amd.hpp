@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "simd_minimizers_amd.h"
@@ -74,6 +75,8 @@ class Workspace {
     mm_workspace_t *ws_ = nullptr;
 };
 
+using u128 = unsigned __int128;
+
 template <bool CANONICAL>
 class Output {  // src/lib.rs:232-237
   public:
@@ -84,6 +87,26 @@ class Output {  // src/lib.rs:232-237
         check(mm_values_u64_host(ws_->get(), seq_.data, seq_.offset, seq_.len, len_, CANONICAL, pos_->data(),
                                  pos_->size(), v.data()));
         return v;
+    }
+    std::vector<u128> values_u128() const {  // src/lib.rs:587-593 (len <= 64)
+        std::vector<uint64_t> raw(2 * pos_->size());
+        check(mm_values_u128_host(ws_->get(), seq_.data, seq_.offset, seq_.len, len_, CANONICAL, pos_->data(),
+                                  pos_->size(), raw.data()));
+        std::vector<u128> v(pos_->size());
+        for (size_t i = 0; i < v.size(); ++i) v[i] = ((u128)raw[2 * i + 1] << 64) | raw[2 * i];
+        return v;
+    }
+    std::vector<std::pair<uint32_t, uint64_t>> pos_and_values_u64() const {  // src/lib.rs:598-612
+        const std::vector<uint64_t> v = values_u64();
+        std::vector<std::pair<uint32_t, uint64_t>> r(v.size());
+        for (size_t i = 0; i < v.size(); ++i) r[i] = {(*pos_)[i], v[i]};
+        return r;
+    }
+    std::vector<std::pair<uint32_t, u128>> pos_and_values_u128() const {  // src/lib.rs:615-630
+        const std::vector<u128> v = values_u128();
+        std::vector<std::pair<uint32_t, u128>> r(v.size());
+        for (size_t i = 0; i < v.size(); ++i) r[i] = {(*pos_)[i], v[i]};
+        return r;
     }
     const std::vector<uint32_t> &positions() const { return *pos_; }
 
@@ -118,22 +141,36 @@ class Builder {  // src/lib.rs:225-230
     }
     Output<CANONICAL> run(PackedSeq seq, std::vector<uint32_t> &min_pos) const {  // src/lib.rs:378
         Workspace &ws = ws_ ? *ws_ : Workspace::thread_default();
-        mm_plan_t *plan = nullptr;
-        check(mm_plan_create(&plan, k_, w_, CANONICAL, (mm_mode_t)SYNCMER, has_hasher_ ? &hasher_ : nullptr));
-        const uint64_t l = (uint64_t)k_ + w_ - 1;
-        const uint64_t cap = seq.len >= l ? seq.len - l + 1 : 0;
-        std::vector<uint32_t> pos(cap ? cap : 1), sk(sk_ ? (cap ? cap : 1) : 0);
-        uint64_t n = 0;
-        int r = mm_run_host(plan, ws.get(), seq.data, seq.offset, seq.len, pos.data(), sk_ ? sk.data() : nullptr,
-                            cap, &n);
-        mm_plan_destroy(plan);
-        check(r);
+        std::vector<uint32_t> pos, sk;
+        const uint64_t n = compute(seq, ws, pos, sk);
         size_t first = 0;
         if (SYNCMER == 0)
             while (first < n && !min_pos.empty() && pos[first] == min_pos.back()) ++first;
         min_pos.insert(min_pos.end(), pos.begin() + first, pos.begin() + n);
         if (sk_) sk_->insert(sk_->end(), sk.begin() + first, sk.begin() + n);
         return Output<CANONICAL>(SYNCMER ? k_ + w_ - 1 : k_, seq, &min_pos, &ws);
+    }
+    // src/lib.rs:553-576: `run` with the scratch passed explicitly; the reference's Cache is this
+    // engine's Workspace (device buffers + stream)
+    Output<CANONICAL> run_with_buf(PackedSeq seq, std::vector<uint32_t> &min_pos, Workspace &cache) const {
+        return workspace(&cache).run(seq, min_pos);
+    }
+    // src/lib.rs:370-376, :517-543.  The reference's scalar collectors OVERWRITE min_pos from index 0
+    // and truncate it to the result (src/collect.rs:15-37,39-76, src/syncmers.rs:19-48): no append, no
+    // last() rule; a sequence without a window clears min_pos and leaves the super-k-mer vector
+    // untouched (src/collect.rs:45-48).  Served by the same HIP kernel as `run`.
+    Output<CANONICAL> run_scalar(PackedSeq seq, std::vector<uint32_t> &min_pos) const {
+        Workspace &ws = ws_ ? *ws_ : Workspace::thread_default();
+        std::vector<uint32_t> pos, sk;
+        const uint64_t n = compute(seq, ws, pos, sk);
+        min_pos.assign(pos.begin(), pos.begin() + n);
+        if (sk_ && seq.len >= (uint64_t)k_ + w_ - 1) sk_->assign(sk.begin(), sk.begin() + n);
+        return Output<CANONICAL>(SYNCMER ? k_ + w_ - 1 : k_, seq, &min_pos, &ws);
+    }
+    std::vector<uint32_t> run_scalar_once(PackedSeq seq) const {  // src/lib.rs:358-362, :511-515
+        std::vector<uint32_t> v;
+        run_scalar(seq, v);
+        return v;
     }
     // src/lib.rs:451-496: canonical builders only; windows with an ambiguous base are skipped
     Output<CANONICAL> run_skip_ambiguous_windows(PackedNSeq nseq, std::vector<uint32_t> &min_pos) const {
@@ -154,6 +191,10 @@ class Builder {  // src/lib.rs:225-230
             while (first < n && !min_pos.empty() && pos[first] == min_pos.back()) ++first;
         min_pos.insert(min_pos.end(), pos.begin() + first, pos.begin() + n);
         return Output<CANONICAL>(SYNCMER ? k_ + w_ - 1 : k_, nseq.seq, &min_pos, &ws);
+    }
+    Output<CANONICAL> run_skip_ambiguous_windows_with_buf(PackedNSeq nseq, std::vector<uint32_t> &min_pos,
+                                                          Workspace &cache) const {  // src/lib.rs:465-496
+        return workspace(&cache).run_skip_ambiguous_windows(nseq, min_pos);
     }
     std::vector<uint32_t> run_skip_ambiguous_windows_once(PackedNSeq nseq) const {
         std::vector<uint32_t> v;
@@ -181,6 +222,22 @@ class Builder {  // src/lib.rs:225-230
     }
 
   private:
+    // one pass of the hot path over `seq` on the device; fills pos (and sk), returns the count
+    uint64_t compute(PackedSeq seq, Workspace &ws, std::vector<uint32_t> &pos, std::vector<uint32_t> &sk) const {
+        mm_plan_t *plan = nullptr;
+        check(mm_plan_create(&plan, k_, w_, CANONICAL, (mm_mode_t)SYNCMER, has_hasher_ ? &hasher_ : nullptr));
+        const uint64_t l = (uint64_t)k_ + w_ - 1;
+        const uint64_t cap = seq.len >= l ? seq.len - l + 1 : 0;
+        pos.assign(cap ? cap : 1, 0);
+        sk.assign(sk_ ? (cap ? cap : 1) : 0, 0);
+        uint64_t n = 0;
+        const int r = mm_run_host(plan, ws.get(), seq.data, seq.offset, seq.len, pos.data(),
+                                  sk_ ? sk.data() : nullptr, cap, &n);
+        mm_plan_destroy(plan);
+        check(r);
+        return n;
+    }
+
     uint32_t k_, w_;
     mm_hasher_t hasher_{};
     bool has_hasher_ = false;

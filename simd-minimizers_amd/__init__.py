@@ -24,7 +24,7 @@ U64_MAX = (1 << 64) - 1
 ERR = {
     "W_ZERO": -1, "W_TOO_LARGE": -2, "LEN_TOO_LARGE": -3, "EVEN_L": -4,
     "HASHER_NOT_CANONICAL": -5, "OPEN_EVEN_W": -6, "K_ZERO": -7, "CAPACITY": -8, "BAD_MODE": -9,
-    "NULL": -10, "VALUE_LEN": -11, "NO_DEVICE": -20, "HIP": -21, "ALLOC": -22,
+    "NULL": -10, "VALUE_LEN": -11, "NO_DEVICE": -20, "HIP": -21, "ALLOC": -22, "ORDER": -23,
 }
 
 
@@ -87,6 +87,7 @@ def lib():
         L.mm_workspace_destroy.argtypes = [vp]
         L.mm_workspace_destroy.restype = None
         L.mm_workspace_sync.argtypes = [vp]
+        L.mm_workspace_check.argtypes = [vp]
         L.mm_workspace_force_generic.argtypes = [vp, C.c_int]
         L.mm_workspace_set_blocks_per_lane.argtypes = [vp, C.c_uint32]
         L.mm_workspace_enable_timing.argtypes = [vp, C.c_int]
@@ -140,7 +141,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "mm_strerror", "mm_last_error", "mm_device_count", "mm_default_hasher", "mm_plan_create",
     "mm_plan_destroy", "mm_plan_value_len", "mm_workspace_create", "mm_workspace_destroy",
-    "mm_workspace_sync", "mm_workspace_force_generic", "mm_workspace_set_blocks_per_lane",
+    "mm_workspace_sync", "mm_workspace_check", "mm_workspace_force_generic", "mm_workspace_set_blocks_per_lane",
     "mm_workspace_enable_timing", "mm_workspace_kernel_time", "mm_workspace_last_path",
     "mm_run_device_async", "mm_run_device", "mm_run_host", "mm_run_host_ascii",
     "mm_values_u64_device_async", "mm_values_u64_host", "mm_values_u128_device_async",
@@ -158,7 +159,7 @@ def _check(code: int):
     if code != 0:
         L = lib()
         msg = L.mm_strerror(code).decode()
-        if code in (ERR["HIP"], ERR["ALLOC"], ERR["NO_DEVICE"]):
+        if code in (ERR["HIP"], ERR["ALLOC"], ERR["NO_DEVICE"], ERR["ORDER"]):
             msg += ": " + L.mm_last_error().decode()
         raise MinimizerError(code, msg)
 
@@ -291,6 +292,11 @@ class Workspace:
     def sync(self):
         _check(lib().mm_workspace_sync(self.h))
 
+    def check(self):
+        """Completion status of the asynchronous runs since the last check (mm_workspace_check):
+        raises MinimizerError(ORDER) if one of them has to be repeated."""
+        _check(lib().mm_workspace_check(self.h))
+
     def force_generic(self, on: bool):
         _check(lib().mm_workspace_force_generic(self.h, int(on)))
 
@@ -371,6 +377,10 @@ class Output:
 
     def values_u128(self) -> list:
         """``Output::values_u128`` (src/lib.rs:587-593): Python ints, len <= 64."""
+        return self.pos_and_values_u128()[1]
+
+    def pos_and_values_u128(self):
+        """``Output::pos_and_values_u128`` (src/lib.rs:615-630): (positions, Python ints)."""
         pos = np.ascontiguousarray(self.min_pos, dtype=np.uint32)
         vals = np.zeros(2 * len(pos), dtype=np.uint64)
         seq = self.seq
@@ -380,9 +390,10 @@ class Output:
             _check(lib().mm_values_u128_host(self._ws.h, _p(seq.data, C.c_uint8), seq.offset, seq.length,
                                              self.len, int(self.canonical), _p(pos, C.c_uint32),
                                              len(pos), _p(vals, C.c_uint64)))
-        return [int(vals[2 * i]) | (int(vals[2 * i + 1]) << 64) for i in range(len(pos))]
+        return pos, [int(vals[2 * i]) | (int(vals[2 * i + 1]) << 64) for i in range(len(pos))]
 
     def pos_and_values_u64(self):
+        """``Output::pos_and_values_u64`` (src/lib.rs:598-612)."""
         pos = np.ascontiguousarray(self.min_pos, dtype=np.uint32)
         vals = np.zeros(len(pos), dtype=np.uint64)
         seq = self.seq
@@ -443,6 +454,29 @@ class Builder:
         self.run(seq, out)
         return out
 
+    def run_with_buf(self, seq, min_pos: list, cache: "Workspace") -> Output:
+        """``Builder::run_with_buf`` (src/lib.rs:553-576): ``run`` with the scratch passed explicitly -
+        the reference's ``Cache`` is this engine's ``Workspace`` (device buffers + stream)."""
+        return self.workspace(cache).run(seq, min_pos)
+
+    def run_scalar(self, seq, min_pos: list) -> Output:
+        """``Builder::run_scalar`` (src/lib.rs:370-376, :517-543).  The reference's scalar collectors
+        OVERWRITE ``min_pos`` from index 0 and truncate it to the result (src/collect.rs:15-37,39-76,
+        src/syncmers.rs:19-48) - no append, no ``last()`` rule; a sequence without a window clears
+        ``min_pos`` and (like src/collect.rs:45-48) leaves the super-k-mer vector untouched.  Served by
+        the same HIP kernel as ``run``: the scalar flavour differs in the collector's contract only."""
+        pos, sk = self._run_arrays(seq)
+        min_pos[:] = list(map(int, pos))
+        if self._sk is not None and len(seq) >= self.k + self.w - 1:
+            self._sk[:] = list(map(int, sk))
+        return Output(self, seq, min_pos)
+
+    def run_scalar_once(self, seq) -> list:
+        """``Builder::run_scalar_once`` (src/lib.rs:358-362, :511-515)."""
+        out: list = []
+        self.run_scalar(seq, out)
+        return out
+
     def _run_arrays(self, seq):
         L = lib()
         ws = self._ws()
@@ -493,6 +527,10 @@ class Builder:
                 out = out[1:]
         min_pos.extend(out)
         return Output(self, seq, min_pos)
+
+    def run_skip_ambiguous_windows_with_buf(self, nseq, min_pos: list, cache: "Workspace") -> Output:
+        """``Builder::run_skip_ambiguous_windows_with_buf`` (src/lib.rs:465-496)."""
+        return self.workspace(cache).run_skip_ambiguous_windows(nseq, min_pos)
 
     def run_skip_ambiguous_windows_once(self, nseq) -> list:
         out: list = []

@@ -88,7 +88,8 @@ struct mm_workspace {
     unsigned long long *status = nullptr;
     uint64_t status_words = 0;
     uint32_t *ticket = nullptr;
-    unsigned long long *total = nullptr;    // [0] running total, [1] low word = error flag
+    unsigned long long *total = nullptr;    // [0] running total, [1] low word = error flag of the last run,
+                                            // [2] low word = sticky error flag (mm_workspace_check)
     unsigned long long *h_total = nullptr;  // pinned copy of both words
     bool force_ticket = false;
     // generic-path scratch
@@ -181,6 +182,27 @@ int collect_timing(mm_workspace *ws) {
     return MM_OK;
 }
 
+// The per-run error word of a finished run (h_total[1], see OutParams::error): 0 = fine, 1 = a look-back
+// spin ran out (the caller redoes the run in ticket mode), anything else is a failed launch.
+// Returns 0 (fine), 1 (redo in ticket mode) or a negative MM_ERR_* code.
+int judge_run_error(mm_workspace *ws) {
+    const uint32_t code = (uint32_t)ws->h_total[1];
+    if (code == 0) return 0;
+    if (code == 1u) {
+        if (ws->force_ticket) {
+            g_last_error = "look-back scan timed out in ticket mode";
+            return MM_ERR_HIP;
+        }
+        ws->force_ticket = true;
+        return 1;
+    }
+    char buf[96];
+    snprintf(buf, sizeof(buf), code == 2u ? "kernel error 2: dynamic LDS does not lie behind the static LDS"
+                                          : "kernel error 0x%x (bad batch table)", code);
+    g_last_error = buf;
+    return MM_ERR_HIP;
+}
+
 }  // namespace
 
 extern "C" {
@@ -202,6 +224,7 @@ const char *mm_strerror(int code) {
         case MM_ERR_NO_DEVICE: return "no HIP device (this engine has no CPU fallback)";
         case MM_ERR_HIP: return "HIP call failed";
         case MM_ERR_ALLOC: return "device allocation failed";
+        case MM_ERR_ORDER: return "look-back timed out in an asynchronous run (repeat it; ticket mode is now on)";
         default: return "unknown error";
     }
 }
@@ -288,6 +311,7 @@ int mm_workspace_create(mm_workspace_t **out, int device, void *hip_stream) {
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&ws->ticket), 64);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ws->total), 64);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ws->h_total), 64, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMemset(ws->total, 0, 64);  // [0] total, [1] per-run error, [2] sticky error
     if (e != hipSuccess) {
         mm_workspace_destroy(ws);
         return hip_fail(e, "workspace allocation");
@@ -334,6 +358,29 @@ int mm_workspace_sync(mm_workspace_t *ws) {
     if (!ws) return MM_ERR_NULL;
     MM_HIP(hipStreamSynchronize(ws->stream));
     return MM_OK;
+}
+
+int mm_workspace_check(mm_workspace_t *ws) {
+    if (!ws) return MM_ERR_NULL;
+    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(hipMemcpyAsync(ws->h_total + 2, ws->total + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                          ws->stream));
+    MM_HIP(hipStreamSynchronize(ws->stream));
+    const uint32_t code = (uint32_t)ws->h_total[2];
+    if (code == 0) return MM_OK;
+    MM_HIP(hipMemsetAsync(ws->total + 2, 0, sizeof(unsigned long long), ws->stream));
+    if (code == 1u) {
+        // workgroups were not dispatched in index order: every later run on this workspace takes its
+        // tile ids from an atomic ticket; the caller repeats the runs since the last check
+        ws->force_ticket = true;
+        g_last_error = "a look-back scan timed out in an asynchronous run: its output is invalid";
+        return MM_ERR_ORDER;
+    }
+    char buf[96];
+    snprintf(buf, sizeof(buf), code == 2u ? "kernel error 2: dynamic LDS does not lie behind the static LDS"
+                                          : "kernel error 0x%x (bad batch table)", code);
+    g_last_error = buf;
+    return MM_ERR_HIP;
 }
 
 int mm_workspace_force_generic(mm_workspace_t *ws, int on) {
@@ -644,12 +691,9 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
         MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                               ws->stream));
         MM_HIP(hipStreamSynchronize(ws->stream));
-        if (ws->h_total[1] == 0) break;
-        if (ws->force_ticket) {
-            g_last_error = "look-back scan timed out in ticket mode";
-            return MM_ERR_HIP;
-        }
-        ws->force_ticket = true;  // redo the batch in ticket mode
+        const int je = judge_run_error(ws);
+        if (je < 0) return je;
+        if (je == 0) break;  // (1: redo the batch in ticket mode)
     }
     // sequences without a window own no tile: their slice is empty and starts where the next one does
     offs[n_seqs] = ws->h_total[0];
@@ -699,12 +743,9 @@ int mm_run_batch_device(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_se
         }
         hipHostFree(h);
         if (r) return r;
-        if (ws->h_total[1] == 0) break;
-        if (ws->force_ticket) {
-            g_last_error = "look-back scan timed out in ticket mode";
-            return MM_ERR_HIP;
-        }
-        ws->force_ticket = true;  // redo the whole batch in ticket mode
+        const int je = judge_run_error(ws);
+        if (je < 0) return je;
+        if (je == 0) break;  // (1: redo the batch in ticket mode)
     }
     if (d_out_pos && out_offsets[n_seqs] > capacity) return MM_ERR_CAPACITY;
     return MM_OK;
@@ -852,12 +893,9 @@ static int run_reads_sync(const mm_plan_t *plan, mm_workspace_t *ws, const void 
         MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long),
                               hipMemcpyDeviceToHost, ws->stream));
         MM_HIP(hipStreamSynchronize(ws->stream));
-        if (ws->h_total[1] == 0) break;
-        if (ws->force_ticket) {
-            g_last_error = "look-back scan timed out in ticket mode";
-            return MM_ERR_HIP;
-        }
-        ws->force_ticket = true;
+        const int je = judge_run_error(ws);
+        if (je < 0) return je;
+        if (je == 0) break;  // (1: redo the batch in ticket mode)
     }
     if (out_count) *out_count = ws->h_total[0];
     if (d_out_pos && ws->h_total[0] > capacity) return MM_ERR_CAPACITY;
@@ -940,14 +978,11 @@ static int run_device_sync(const mm_plan_t *plan, mm_workspace_t *ws, const void
         MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long),
                               hipMemcpyDeviceToHost, ws->stream));
         MM_HIP(hipStreamSynchronize(ws->stream));
-        if (ws->h_total[1] == 0) break;
-        // A look-back spin ran out: workgroups were not dispatched in index order. Redo the run
-        // with tile ids taken from an atomic ticket, which defines the order itself.
-        if (ws->force_ticket) {
-            g_last_error = "look-back scan timed out in ticket mode";
-            return MM_ERR_HIP;
-        }
-        ws->force_ticket = true;
+        // (1: a look-back spin ran out - workgroups were not dispatched in index order.  Redo the run
+        // with tile ids taken from an atomic ticket, which defines the order itself.)
+        const int je = judge_run_error(ws);
+        if (je < 0) return je;
+        if (je == 0) break;
     }
     if (out_count) *out_count = ws->h_total[0];
     if (d_out_pos && ws->h_total[0] > capacity) return MM_ERR_CAPACITY;

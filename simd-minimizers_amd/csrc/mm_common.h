@@ -66,8 +66,18 @@ struct OutParams {
     unsigned long long *total;   // device counter: running total of outputs
     unsigned long long *status;  // decoupled look-back words, one per block, zeroed per launch
     uint32_t *ticket;            // dynamic block id counter, zeroed per launch
-    uint32_t *error;             // set to 1 when a look-back spin ran out (see lookback_exclusive)
+    uint32_t *error;             // error[0]: flag of this launch (1 = a look-back spin ran out, see
+                                 // lookback_exclusive; 2 = LDS layout violated; 0xbad..... = bad batch
+                                 // table), cleared per run; error[2]: the same, sticky until
+                                 // mm_workspace_check() reads it (asynchronous callers)
 };
+
+// Raise an error from a kernel: the per-launch word the synchronous entry points read, and the sticky
+// word mm_workspace_check() reports to asynchronous callers.
+__device__ __forceinline__ void flag_error(uint32_t *error, uint32_t code) {
+    error[0] = code;
+    error[2] = code;
+}
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, uint32_t r) {
     return __builtin_amdgcn_alignbit(x, x, (32u - r) & 31u);
@@ -151,7 +161,7 @@ __device__ __forceinline__ unsigned long long lookback_exclusive(unsigned long l
                 // hang the GPU; the launch is then reported as failed and redone in ticket mode
                 for (uint32_t spins = 0; (s[c] >> 62) == 0; ++spins) {
                     if (spins > kMaxLookbackSpins) {
-                        *error = 1u;
+                        flag_error(error, 1u);
                         s[c] = kFlagIncl;
                         break;
                     }

@@ -58,7 +58,8 @@ struct FusedParams {
     uint32_t list_cap;   // entries per lane list
     uint32_t use_ticket; // 1: tile id from an atomic ticket (safe mode), 0: blockIdx.x
     uint32_t debug;      // timing experiments only (MM_DEBUG env): 1 no look-back, 2 no copy-out,
-                         // 4 no phase 1
+                         // 4 no phase 1, 8 copy-out without stores, 16 half-size lists, 32 test hook:
+                         // tile 0 reports a look-back time-out
     // reads mode (READS kernels): one lane per read, reads at a fixed stride in the buffer
     uint32_t n_reads;
     uint32_t reads_per_lane;            // READS: consecutive reads one lane walks one after the other (1..4)
@@ -706,7 +707,7 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
             // a 64-wide poll through the device-coherent path every few hundred clocks by a thousand
             // waiting tiles slows the whole chip down.
             if (++idle > kMaxIdleRounds) {
-                *error = 1u;  // dispatch-order violation: the host redoes the launch in ticket mode
+                flag_error(error, 1u);  // dispatch-order violation: the host redoes the launch in ticket mode
                 if (have_excl) break;
                 have_excl = true;
             }
@@ -761,6 +762,26 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     // src/lib.rs:451-496)
     constexpr bool kAmbi = CANON && !SK;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    // Layout contract of the list overflow (see "redo" in the header comment): the lists are the dynamic
+    // LDS and must lie behind every static variable, so that entries past a list's capacity fall beyond
+    // the lists (into padding or out of the workgroup's allocation, where the hardware drops them) and
+    // never onto the tables or counters.  The addresses are link-time constants; a layout that breaks
+    // the contract fails the launch with error code 2 instead of corrupting the redo.
+    {
+        auto lds_end = [](const void *q, size_t bytes) {
+            return (uint32_t)reinterpret_cast<uintptr_t>(q) + (uint32_t)bytes;
+        };
+        uint32_t st_end = lds_end(s_tab, sizeof(s_tab));
+        st_end = max(st_end, lds_end(&s_bid, sizeof(s_bid)));
+        st_end = max(st_end, lds_end(&s_overflow, sizeof(s_overflow)));
+        st_end = max(st_end, lds_end(&s_done, sizeof(s_done)));
+        st_end = max(st_end, lds_end(s_wave_tot, sizeof(s_wave_tot)));
+        st_end = max(st_end, lds_end(&s_excl, sizeof(s_excl)));
+        if ((uint32_t)reinterpret_cast<uintptr_t>(smem) < st_end) {
+            if (tid == 0) flag_error(p.out.error, 2u);
+            return;
+        }
+    }
     // Tile id.  Default: blockIdx.x (workgroups are dispatched in index order on gfx950, which
     // the look-back needs for forward progress; its spins are bounded and report a violation,
     // upon which the host re-runs in ticket mode where an atomic counter defines the order).
@@ -774,6 +795,9 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     else if (tid < 36) s_tab[tid] = p.ht.t_in2[tid - 20];
     __syncthreads();
     const uint32_t bid = __builtin_amdgcn_readfirstlane(s_bid);  // keep tile scalars in SGPRs
+    // test hook (MM_DEBUG=32): report a look-back time-out although none happened, so that the error
+    // plumbing of the asynchronous entry points (mm_workspace_check) can be exercised
+    if ((p.debug & 32u) && bid == 0 && tid == 0) flag_error(p.out.error, 1u);
     if (p.trace && tid == 0) {
         uint32_t hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -810,7 +834,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         // a table entry that does not describe this tile must never be dereferenced
         if (batch_s >= p.batch_n || win_end == 0u || (uint64_t)local_tile * NB >= win_end || seq_d == nullptr) {
             if (tid == 0) {
-                p.out.error[0] = 0xbad00000u | (bid & 0xfffffu);
+                flag_error(p.out.error, 0xbad00000u | (bid & 0xfffffu));
                 p.out.error[1] = batch_s;
             }
             return;

@@ -20,6 +20,16 @@ from typing import Callable, Sequence
 
 import numpy as np
 
+# T2T-CHM13v2.0 chromosome lengths (chr1..chr22, X, Y without chrM: 3 117 275 501 bp): the contig set of BASELINE.md
+# §4 config 4 ("24 contigs with CHM13-like lengths summing to ~3.1 Gbp"; the assembly itself is not
+# available offline, contig i is generator G with seed 100 + i).
+CHM13_CONTIG_LENGTHS = (
+    248_387_328, 242_696_752, 201_105_948, 193_574_945, 182_045_439, 172_126_628, 160_567_428, 146_259_331,
+    150_617_247, 134_758_134, 135_127_769, 133_324_548, 113_566_686, 101_161_492, 99_753_195, 96_330_374,
+    84_276_897, 80_542_538, 61_707_364, 66_210_255, 45_090_682, 51_324_926, 154_259_566, 62_460_029,
+)
+CHM13_CONTIG_SEED0 = 100
+
 
 def shard_windows(n_windows: int, world: int) -> list[tuple[int, int]]:
     """Equal window ranges, one per rank (the last ranks may be empty for tiny inputs)."""
@@ -153,3 +163,56 @@ def run_contigs_sharded(compute_contig: Callable[[int], np.ndarray], lengths: Se
                     gathered[i] = flat[off: off + int(counts[i])].copy()
                     off += int(counts[i])
     return mine, local, counts.tolist(), gathered
+
+
+def run_contig_batch_sharded(compute_batch: Callable[[list], tuple], lengths: Sequence[int], group=None,
+                             gather_to: int | None = None):
+    """Contigs spread over ranks (greedy longest first), ONE batch call per rank.
+
+    ``compute_batch(indices)`` runs this rank's contigs with one plan and returns ``(positions,
+    offsets)``: the contig-local positions back to back (a torch tensor - device-resident on the GPU
+    box, where it wraps ``run_batch_device``, i.e. ``mm_run_batch_device``: one launch - or a numpy
+    array) and the ``len(indices) + 1`` offsets delimiting them.  Returns ``(mine, positions, offsets,
+    counts, gathered)``: this rank's contig indices, its batch output, the per-contig counts of ALL
+    contigs (one all-reduce of an int64 vector with disjoint supports - the only collective the path
+    needs), and on rank ``gather_to`` the per-contig position arrays in contig order (tensors on the
+    root's device when the shards are device tensors; None elsewhere / when not requested).  The
+    position buffers travel as they are: with the nccl backend HBM -> HBM over xGMI."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    placement = assign_contigs(lengths, world)
+    mine = placement[rank]
+    positions, offsets = compute_batch(list(mine))
+    offsets = [int(o) for o in offsets]
+    assert len(offsets) == len(mine) + 1
+    on_device = isinstance(positions, torch.Tensor)
+    n = len(lengths)
+    counts = np.zeros(n, dtype=np.int64)
+    for j, i in enumerate(mine):
+        counts[i] = offsets[j + 1] - offsets[j]
+    if world > 1:
+        backend = dist.get_backend(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        ct = torch.from_numpy(counts).to(dev)
+        dist.all_reduce(ct, op=dist.ReduceOp.SUM, group=group)  # disjoint supports: sum == gather
+        counts = ct.cpu().numpy()
+    gathered = None
+    if gather_to is not None:
+        flat = positions[: offsets[-1]] if on_device else np.ascontiguousarray(positions[: offsets[-1]], dtype=np.uint32)
+        if world == 1:
+            parts = [flat if on_device else torch.from_numpy(flat.view(np.int32))]
+        else:
+            per_rank = [int(sum(counts[i] for i in placement[r])) for r in range(world)]
+            parts = gather_positions(flat, per_rank, gather_to, group)
+        if parts is not None:
+            gathered = [None] * n
+            for r in range(world):
+                off = 0
+                for i in placement[r]:
+                    seg = parts[r][off: off + int(counts[i])]
+                    gathered[i] = seg if on_device else seg.cpu().numpy().view(np.uint32).copy()
+                    off += int(counts[i])
+    return mine, positions, offsets, counts.tolist(), gathered

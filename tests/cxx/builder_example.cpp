@@ -2,6 +2,7 @@
 // Exit code 0 = all known answers reproduced; 77 = no GPU (the engine has no CPU fallback).
 #include <cstdio>
 #include <cstring>
+#include <string>
 
 #include "simd_minimizers_amd.hpp"
 
@@ -56,6 +57,47 @@ int main() {
         for (uint32_t x : p)
             for (uint32_t j = 0; j < 5; ++j)
                 if (nseq_ascii[x + j] == 'N') return 9;
+    }
+    // scalar flavour (src/lib.rs:358-376): the collectors OVERWRITE the output vector (src/collect.rs:24-25,36)
+    {
+        std::vector<uint32_t> v{111, 222, 333, 444, 555, 666};
+        canonical_minimizers(5, 7).run_scalar(PackedSeq{packed.data(), 0, strlen(seq2)}, v);
+        if (v != std::vector<uint32_t>{0, 7, 9, 15}) return 10;
+        if (canonical_minimizers(5, 7).run_scalar_once(PackedSeq{packed.data(), 0, strlen(seq2)}) != v) return 11;
+        // SIMD flavour appends and drops a leading result equal to last() (src/collect.rs:265-271)
+        std::vector<uint32_t> a{0};
+        canonical_minimizers(5, 7).run(PackedSeq{packed.data(), 0, strlen(seq2)}, a);
+        if (a != std::vector<uint32_t>{0, 7, 9, 15}) return 12;
+        // too short for a window: scalar clears min_pos and leaves the super-k-mer vector alone
+        std::vector<uint32_t> m{1, 2, 3}, s2{9, 9};
+        canonical_minimizers(5, 7).super_kmers(&s2).run_scalar(PackedSeq{packed.data(), 0, 5}, m);
+        if (!m.empty() || s2 != std::vector<uint32_t>{9, 9}) return 13;
+        // explicit scratch (src/lib.rs:553-559): Cache == Workspace
+        Workspace cache(0);
+        std::vector<uint32_t> b;
+        auto o2 = canonical_minimizers(5, 7).run_with_buf(PackedSeq{packed.data(), 0, strlen(seq2)}, b, cache);
+        if (b != std::vector<uint32_t>{0, 7, 9, 15}) return 14;
+        // Output::values_u128 / pos_and_values_u64 / pos_and_values_u128 (src/lib.rs:587-630)
+        auto v128 = o2.values_u128();
+        auto pv64 = o2.pos_and_values_u64();
+        auto pv128 = o2.pos_and_values_u128();
+        const uint64_t want[4] = {0b1011010001, 0b1100110001, 0b0100110011, 0b1100110001};
+        if (v128.size() != 4 || pv64.size() != 4 || pv128.size() != 4) return 15;
+        for (int i = 0; i < 4; ++i) {
+            if (v128[i] != (u128)want[i]) return 16;
+            if (pv64[i].first != b[i] || pv64[i].second != want[i]) return 17;
+            if (pv128[i].first != b[i] || pv128[i].second != (u128)want[i]) return 18;
+        }
+        // l-mer values wider than 64 bits: closed syncmers k=21 w=21 (l = 41) on all-G (src/test.rs:576-597 shape)
+        std::string g(60, 'G');
+        auto pg = pack(g.c_str());
+        std::vector<uint32_t> sp;
+        auto og = closed_syncmers(21, 21).run(PackedSeq{pg.data(), 0, g.size()}, sp);
+        auto gv = og.values_u128();
+        if (gv.empty()) return 19;
+        const u128 allg = (((u128)1 << 82) - 1);  // 41 bases of code 3
+        for (u128 x : gv)
+            if (x != allg) return 20;
     }
     printf("builder_example ok\n");
     return 0;

@@ -124,3 +124,76 @@ def test_two_rank_contig_sharding():
         assert p.exitcode == 0
     assert ok and len(counts) == len(lengths) and counts[3] == 0 and counts[1] == 0 and counts[0] > 0
     assert 0 < len(mine) < len(lengths)
+
+
+def _batch_worker(rank, world, port, lengths, k, w, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mm_oracle as o
+    from simd_minimizers_amd import sharding
+
+    def one(i):
+        return o.run(o.gen_packed(100 + i, max(1, lengths[i])), lengths[i], k, w, canonical=True)
+
+    def compute_batch(idx):
+        # what run_batch_device returns on the GPU box: positions back to back (a tensor) + offsets
+        parts = [one(i) for i in idx]
+        offs = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).tolist()
+        flat = np.concatenate(parts + [np.zeros(5, dtype=np.uint32)])  # a buffer larger than its content
+        return torch.from_numpy(flat.view(np.int32)), offs
+
+    mine, _, offs, counts, gathered = sharding.run_contig_batch_sharded(compute_batch, lengths, gather_to=0)
+    if rank == 0:
+        ok = all(np.array_equal(gathered[i].numpy().view(np.uint32), one(i)) for i in range(len(lengths)))
+        q.put((mine, counts, ok))
+    dist.destroy_process_group()
+
+
+def test_two_rank_contig_batch_sharding():
+    """The config-4 bench path (bench.py --workload contigs): one batch per rank, per-contig counts
+    all-reduced, buffers gathered to rank 0 and split per contig."""
+    lengths = [5003, 40, 12001, 0, 777, 9000, 31, 2500]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + 331
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, lengths, 31, 51, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    mine, counts, ok = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ok and len(counts) == len(lengths) and counts[3] == 0 and counts[0] > 0
+
+
+def test_chm13_contig_set():
+    sys.path.insert(0, ROOT)
+    from simd_minimizers_amd import sharding
+    lens = sharding.CHM13_CONTIG_LENGTHS
+    assert len(lens) == 24 and 3.0e9 < sum(lens) < 3.2e9 and max(lens) < 2 ** 32
+    for world in (1, 2, 4, 8):
+        loads = [sum(lens[i] for i in p) for p in sharding.assign_contigs(lens, world)]
+        assert sum(loads) == sum(lens) and max(loads) < 1.06 * sum(lens) / world
+
+
+def test_bench_launcher_fails_loudly():
+    """`bench.py --gpus N` must start N ranks itself or fail - never print a
+    one-rank line labelled N GPUs.  Without GPUs here the ranks it starts cannot run: the command
+    has to exit non-zero without a JSON line; a launcher/flag mismatch is refused before any import."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and '"n_gpus"' not in r.stdout
+    env2 = dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2, capture_output=True,
+                        text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE=2" in r2.stderr and '"n_gpus"' not in r2.stdout

@@ -1,0 +1,343 @@
+"""GPU tests added in round 2 (all through the C ABI, bit-exact against the oracle):
+
+* the scalar-flavour entry points (overwrite semantics), run_with_buf, pos_and_values_*;
+* completion status of asynchronous runs (mm_workspace_check) and the LDS layout guard;
+* BASELINE config 2 (forward k=21 w=11, 256 Mbp) and config 4's concrete input (24 CHM13-like
+  contigs, canonical k=31 w=51, one batch launch);
+* the sharded (multi-GPU) call path with the REAL kernel: window ranges and contig batches at
+  world size 1, at world size 2 with two ranks sharing this GPU (gloo), and under NCCL when the
+  box has two GPUs.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ boundary
+def test_scalar_flavour_overwrites(sm, oracle, gpu):
+    """run_scalar / run_scalar_once (src/lib.rs:358-376,511-543): the scalar collectors overwrite the
+    output vector and truncate it to the result (src/collect.rs:15-37,39-76; src/syncmers.rs:19-48),
+    where `run` appends with the last() rule (src/collect.rs:252-272).  Same HIP kernel."""
+    ps = sm.PackedSeqVec.from_ascii(b"ACGTGCTCAGAGACTCAGAGGA")
+    b = sm.canonical_minimizers(5, 7)
+    out = [123, 0, 5, 6, 7, 8, 9, 10]
+    o = b.run_scalar(ps, out)
+    assert out == [0, 7, 9, 15]
+    assert [int(v) for v in o.values_u64()] == [0b1011010001, 0b1100110001, 0b0100110011, 0b1100110001]
+    assert b.run_scalar_once(ps) == [0, 7, 9, 15]
+    assert gpu.last_path() == sm.PATH_FUSED  # served by the HIP kernel, not by the oracle
+    # super-k-mer flavour (src/lib.rs:517-543, src/collect.rs:39-76; known answer src/test.rs:344-356 shape)
+    sk = [9, 9, 9, 9, 9, 9, 9]
+    out = [1]
+    b.super_kmers(sk).run_scalar(ps, out)
+    assert out == [0, 7, 9, 15] and sk == [0, 1, 8, 9]
+    # a sequence without a window clears min_pos and leaves the super-k-mer vector alone (collect.rs:45-48)
+    sk2, out2 = [4, 4], [1, 2, 3]
+    b.super_kmers(sk2).run_scalar(ps.slice(0, 10), out2)
+    assert out2 == [] and sk2 == [4, 4]
+    # syncmers: overwrite as well, no dedup
+    n = 5000
+    data = oracle.gen_packed(5, n)
+    seq = sm.PackedSeq(data, 0, n)
+    for mode, builder in ((1, sm.canonical_closed_syncmers(5, 7)), (2, sm.canonical_open_syncmers(5, 7))):
+        want = [int(x) for x in oracle.run(data, n, 5, 7, canonical=True, mode=mode)]
+        v = [7] * 10000
+        builder.run_scalar(seq, v)
+        assert v == want
+        v2 = [7]
+        builder.run(seq, v2)
+        assert v2 == [7] + want  # SIMD flavour appends; no boundary rule for syncmers (syncmers.rs:166-169)
+    # random sweep: scalar flavour == oracle for short and empty inputs
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        k, w = int(rng.integers(1, 30)), int(rng.integers(1, 20))
+        ln = int(rng.integers(0, 300))
+        want = [int(x) for x in oracle.run(data, ln, k, w, canonical=False)]
+        v = [1, 2, 3]
+        sm.minimizers(k, w).run_scalar(sm.PackedSeq(data, 0, ln), v)
+        assert v == want, (k, w, ln)
+
+
+def test_run_with_buf_and_pos_and_values(sm, oracle, gpu):
+    """run_with_buf (src/lib.rs:553-576; Cache == Workspace), run_skip_ambiguous_windows_with_buf
+    (src/lib.rs:465-496), Output::pos_and_values_u64 / _u128 (src/lib.rs:598-630)."""
+    n = 100_000
+    data = oracle.gen_packed(8, n)
+    seq = sm.PackedSeq(data, 0, n)
+    cache = sm.Workspace(0)
+    for k, w, canonical in ((21, 11, True), (33, 9, False), (40, 25, True)):
+        b = sm.Builder(k, w, canonical, 0)
+        a, c = [], []
+        b.run(seq, a)
+        out = b.run_with_buf(seq, c, cache)
+        assert a == c and len(a) > 0
+        assert cache.last_path() == sm.PATH_FUSED
+        pos, vals = out.pos_and_values_u128()
+        want = oracle.values_u128(data, k, np.array(c, dtype=np.uint32), canonical)
+        assert [int(p) for p in pos] == c
+        assert vals == [int(lo) | (int(hi) << 64) for lo, hi in want]
+        if k <= 32:
+            p64, v64 = out.pos_and_values_u64()
+            assert [int(p) for p in p64] == c and [int(v) for v in v64] == vals
+    ascii_seq = (b"ACGTTGCANGT" * 300)[:3000]
+    ns = sm.PackedNSeqVec.from_ascii(ascii_seq)
+    x, y = [], []
+    sm.canonical_minimizers(7, 5).run_skip_ambiguous_windows(ns, x)
+    sm.canonical_minimizers(7, 5).run_skip_ambiguous_windows_with_buf(ns, y, cache)
+    assert x == y and len(x) > 0
+    cache.close()
+
+
+# --------------------------------------------------- asynchronous completion status
+def test_async_status_is_observable(sm, oracle, gpu, monkeypatch):
+    """a look-back time-out in an asynchronous run must be observable.  MM_DEBUG=32
+    makes tile 0 report one; mm_workspace_check returns MM_ERR_ORDER exactly once, switches the
+    workspace to ticket mode, and the repeated run is right."""
+    import torch
+    n, k, w = 2_000_003, 21, 11
+    data = oracle.gen_packed(31, n)
+    want = oracle.run(data, n, k, w, canonical=True)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n // 4, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ws = sm.Workspace(0, torch.cuda.current_stream().cuda_stream)
+    b = sm.canonical_minimizers(k, w).workspace(ws)
+    b.run_device(d, n, out, sync=False, d_count=cnt)
+    ws.check()  # a clean run: no error
+    assert int(cnt.item()) == len(want)
+    monkeypatch.setenv("MM_DEBUG", "32")
+    b.run_device(d, n, out, sync=False, d_count=cnt)
+    b.run_device(d, n, out, sync=False, d_count=cnt)  # the flag is sticky across later runs
+    monkeypatch.delenv("MM_DEBUG")
+    b.run_device(d, n, out, sync=False, d_count=cnt)
+    with pytest.raises(sm.MinimizerError) as e:
+        ws.check()
+    assert e.value.code == sm.ERR["ORDER"]
+    ws.check()  # reported once
+    out.zero_()
+    b.run_device(d, n, out, sync=False, d_count=cnt)  # now in ticket mode
+    ws.check()
+    c = int(cnt.item())
+    assert c == len(want) and np.array_equal(out[:c].cpu().numpy().view(np.uint32), want)
+    # the synchronous entry point handles the same report itself: redo in ticket mode, or fail loudly
+    ws2 = sm.Workspace(0, torch.cuda.current_stream().cuda_stream)
+    monkeypatch.setenv("MM_DEBUG", "32")
+    with pytest.raises(sm.MinimizerError) as e2:
+        sm.canonical_minimizers(k, w).workspace(ws2).run_device(d, n, out)
+    assert e2.value.code == sm.ERR["HIP"]  # the hook fires in ticket mode too: never a silent wrong count
+    monkeypatch.delenv("MM_DEBUG")
+    c = sm.canonical_minimizers(k, w).workspace(ws2).run_device(d, n, out)
+    assert c == len(want) and np.array_equal(out[:c].cpu().numpy().view(np.uint32), want)
+    ws.close()
+    ws2.close()
+
+
+def test_list_overflow_with_lds_padding(sm, oracle, gpu, monkeypatch):
+    """The list-overflow redo with padded dynamic LDS (MM_LDS_PAD): entries past a list's capacity land in
+    the padding instead of being dropped by the hardware; the static tables stay intact (layout guard in
+    the kernel) and the redo gives the oracle's output."""
+    import torch
+    n = 300_000
+    for pad in ("0", "4096", "20000"):
+        monkeypatch.setenv("MM_LDS_PAD", pad)
+        for unit in (b"A", b"ACGTT", b"G"):
+            seq = (unit * (n // len(unit) + 1))[:n]
+            data = oracle.pack_ascii(seq)
+            d = torch.from_numpy(data).cuda()
+            out = torch.zeros(n, dtype=torch.int32, device="cuda")
+            for k, w, canonical, mode in [(21, 11, False, 0), (21, 11, True, 0), (15, 17, True, 1)]:
+                want = oracle.run(data, n, k, w, canonical=canonical, mode=mode)
+                c = sm.Builder(k, w, canonical, mode).run_device(d, n, out)
+                assert gpu.last_path() == sm.PATH_FUSED
+                assert c == len(want) and np.array_equal(out[:c].cpu().numpy().view(np.uint32), want), (pad, unit, k, w)
+    monkeypatch.setenv("MM_LDS_PAD", "0")
+    torch.zeros(1, device="cuda")
+    sm.minimizers(21, 11).run_device(d, n, out)  # resets the process-wide padding for later tests
+
+
+# ------------------------------------------------------------ BASELINE configs
+def _device_checksum(out, c):
+    import torch
+    v = out[:c].to(torch.int64) & 0xFFFFFFFF
+    idx = torch.arange(1, c + 1, dtype=torch.int64, device=out.device)
+    return c, int(v.sum().item()), int((v * idx).sum().item()) & ((1 << 64) - 1)
+
+
+def test_config2_forward_256mbp(sm, oracle, gpu):
+    """BASELINE config 2: forward minimizers k=21 w=11 on 256 Mbp (generator G seed 2): the whole output
+    against the oracle's multi-threaded one-pass port (itself checked against the streaming oracle in
+    tests/test_oracle.py), plus fused == generic and head / tail against the streaming oracle."""
+    import torch
+    n, k, w = 268_435_456, 21, 11
+    d = sm.generate_device(n, 2)
+    out = torch.empty(int(n * 0.2), dtype=torch.int32, device="cuda")
+    b = sm.minimizers(k, w)
+    c = b.run_device(d, n, out)
+    assert gpu.last_path() == sm.PATH_FUSED
+    assert abs(c / n - 2 / 12) < 2e-3
+    host = oracle.gen_packed(2, n)
+    assert np.array_equal(d[: (n + 3) // 4].cpu().numpy(), host[: (n + 3) // 4])  # generator kernel == generator G
+    want = oracle.run_fast(host, n, k, w, canonical=False, threads=min(16, os.cpu_count() or 1))
+    got = out[:c].cpu().numpy().view(np.uint32)
+    assert c == len(want) and np.array_equal(got, want)
+    m = 1_000_000
+    head = oracle.run(host, m, k, w, canonical=False)
+    head = head[head < m - 64]
+    assert np.array_equal(got[: len(head)], head)
+    whole = _device_checksum(out, c)
+    gpu.force_generic(True)
+    try:
+        cg = b.run_device(d, n, out)
+        assert gpu.last_path() == sm.PATH_GENERIC and _device_checksum(out, cg) == whole
+    finally:
+        gpu.force_generic(False)
+
+
+def test_config4_chm13_contig_batch(sm, oracle, gpu):
+    """BASELINE config 4's concrete input on one GPU: the 24 CHM13-like contigs (3.1 Gbp, G seed
+    100+contig), canonical k=31 w=51, ONE batch launch (mm_run_batch_device), contig-local positions.
+    Per contig: fused == an independent single-sequence run (count + order-sensitive checksum); for
+    three contigs the generic family agrees and head and tail equal the oracle."""
+    import torch
+    from simd_minimizers_amd import sharding
+    lens = list(sharding.CHM13_CONTIG_LENGTHS)
+    k, w = 31, 51
+    d = [sm.generate_device(m, sharding.CHM13_CONTIG_SEED0 + i) for i, m in enumerate(lens)]
+    total = sum(lens)
+    out = torch.empty(int(total * 2 / 52 * 1.15), dtype=torch.int32, device="cuda")
+    b = sm.canonical_minimizers(k, w)
+    offs = sm.run_batch_device(b, d, lens, out)
+    assert gpu.last_path() == sm.PATH_FUSED
+    assert offs[0] == 0 and len(offs) == 25 and abs(offs[-1] / total - 2 / 52) < 1e-3
+    single = torch.empty(int(max(lens) * 2 / 52 * 1.2), dtype=torch.int32, device="cuda")
+    m = 400_000
+    for i, n in enumerate(lens):
+        seg = out[offs[i]: offs[i + 1]]
+        c = b.run_device(d[i], n, single)
+        assert c == offs[i + 1] - offs[i], i
+        assert _device_checksum(seg, c) == _device_checksum(single, c), i
+        if i in (0, 13, 20):
+            gpu.force_generic(True)
+            try:
+                cg = b.run_device(d[i], n, single)
+                assert gpu.last_path() == sm.PATH_GENERIC and _device_checksum(single, cg) == _device_checksum(seg, c), i
+            finally:
+                gpu.force_generic(False)
+            seed = sharding.CHM13_CONTIG_SEED0 + i
+            head = oracle.run(oracle.gen_packed(seed, m + 256), m + 256, k, w, canonical=True)
+            head = head[head < m - 256]
+            assert np.array_equal(seg[: len(head)].cpu().numpy().view(np.uint32), head), i
+            tail = oracle.run(oracle.gen_packed(seed, m, first_base=n - m), m, k, w, canonical=True)
+            got_tail = seg[c - len(tail) + 50:].cpu().numpy().view(np.uint32).astype(np.int64) - (n - m)
+            assert np.array_equal(got_tail, tail[50:].astype(np.int64)), i
+
+
+# ------------------------------------------------ sharded call path with the real kernel
+def _sharded_worker(rank, world, port, backend, q):
+    """One rank of the sharded path: sharding.run_sharded -> Builder.run_device(win_begin, win_end) and
+    sharding.run_contig_batch_sharded -> run_batch_device, gathered to rank 0 and compared with the oracle."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    dev_id = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev_id)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{dev_id}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    import mm_oracle as o
+    import simd_minimizers_amd as sm
+    from simd_minimizers_amd import sharding
+
+    ws = sm.Workspace(dev_id, torch.cuda.current_stream().cuda_stream)
+    ok = True
+    n, k, w = 3_000_017, 21, 11
+    data = o.gen_packed(21, n)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n // 3, dtype=torch.int32, device="cuda")
+    for canonical, mode in ((True, 0), (False, 0), (True, 1)):
+        b = sm.Builder(k, w, canonical, mode).workspace(ws)
+
+        def compute(wb, we):
+            c = b.run_device(d, n, out, win_begin=wb, win_end=we)
+            assert ws.last_path() == sm.PATH_FUSED
+            return out[:c].clone()
+
+        local, counts, gathered = sharding.run_sharded(compute, n - (k + w - 1) + 1, gather_to=0)
+        if rank == 0:
+            want = o.run(data, n, k, w, canonical=canonical, mode=mode)
+            got = gathered.cpu().numpy().view(np.uint32)
+            ok = ok and sum(counts) == len(want) and np.array_equal(got, want)
+    # contigs: one batch launch per rank, contig-local positions, gathered per contig
+    lens = [400_003, 250_000, 180_001, 90_000, 60_000, 30, 0, 1_000]
+    seqs = [o.gen_packed(100 + i, max(m, 1)) for i, m in enumerate(lens)]
+    bb = sm.canonical_minimizers(31, 51).workspace(ws)
+    out2 = torch.zeros(sum(lens) // 8 + 64, dtype=torch.int32, device="cuda")
+
+    def compute_batch(idx):
+        offs = sm.run_batch_device(bb, [torch.from_numpy(seqs[i]).cuda() for i in idx], [lens[i] for i in idx], out2)
+        return out2, offs
+
+    mine, _, _, counts, gathered = sharding.run_contig_batch_sharded(compute_batch, lens, gather_to=0)
+    if rank == 0:
+        for i, m in enumerate(lens):
+            want = o.run(seqs[i], m, 31, 51, canonical=True)
+            g = gathered[i].cpu().numpy().view(np.uint32)
+            ok = ok and counts[i] == len(want) and np.array_equal(g, want)
+        q.put(bool(ok))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run_world(world, backend):
+    import socket
+
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        ok = q.get(timeout=600)
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    assert ok
+    assert all(p.exitcode == 0 for p in procs)
+
+
+def test_sharded_path_real_kernel_world1(gpu):
+    """sharding.run_sharded / run_contig_batch_sharded wired to Builder.run_device / run_batch_device."""
+    _run_world(1, "gloo")
+
+
+def test_sharded_path_real_kernel_world2_shared_gpu(gpu):
+    """Two ranks (gloo rendezvous, both on this GPU): every rank computes its own window range / its own
+    contigs with the HIP kernel; counts all-gathered, positions gathered to rank 0 == oracle."""
+    _run_world(2, "gloo")
+
+
+def test_sharded_path_real_kernel_world2_nccl(gpu):
+    """The same over RCCL with device-resident shards (needs two GPUs)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    _run_world(2, "nccl")
