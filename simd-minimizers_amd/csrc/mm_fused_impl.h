@@ -81,6 +81,13 @@ struct FusedParams {
     uint32_t batch_n;
     // timing experiments (MM_TRACE): 4 timestamps per tile (start, phase 1 done, look-back done, end)
     unsigned long long *trace;
+    // pipelined kernel (mm_fused_pipe.h): tiles of the run, per-tile counts (count + 1, zeroed per
+    // launch), per-round output bases (bit 63 = valid, zeroed per launch)
+    uint32_t n_tiles;
+    uint32_t tiles_per_wg;  // 0: tiles from the atomic ticket (persistent grid); M > 0: workgroup b walks tiles
+                            // b * M .. b * M + M - 1 and ends (in-order dispatch, like the unpipelined kernel)
+    uint32_t *pipe_counts;
+    unsigned long long *pipe_round_base;
     OutParams out;
 };
 
@@ -155,13 +162,25 @@ struct LaneCtx {
     uint32_t nblk;           // W-blocks this lane walks
     const uint32_t *seq_d;   // the sequence the tile reads (p.seq, or the batch entry)
     uint32_t seq_dwords;
+    uint32_t hook_block;     // W-block before which the walk runs its hook (wave-uniform; 0 = never)
 };
 
 // One lane walks its S windows.  List mode: appends emitted 16-bit values to the lane's LDS
 // list (entries past the capacity are dropped but counted).  DIRECT mode: stores final values
 // to HBM from ctx.dst on.  Returns the number of emitted windows.
-template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool DIRECT, bool PARTIAL, bool AMBI = false>
-__device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCtx &ctx, bool &overflowed) {
+// EB: bytes per list entry (2; 1 in the pipelined kernel, whose lanes are short enough for 8-bit
+// positions), PITCH: bytes between consecutive entries of one lane's list.  `hook` runs once, at the
+// top of W-block ctx.hook_block (wave-uniform; 0 = never): the pipelined kernel puts the previous
+// tile's look-back there, in the middle of this tile's walk.
+struct NoHook {
+    static constexpr bool kActive = false;
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool DIRECT, bool PARTIAL, bool AMBI = false, int EB = 2,
+          int PITCH = (int)kListStride, class Hook = NoHook>
+__device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCtx &ctx, bool &overflowed,
+                                              Hook hook = Hook()) {
+    static_assert(EB == 2 || (EB == 1 && !SK), "8-bit list entries: positions only");
     constexpr int NSUB = (W + 15) / 16;  // 16-base view words per W-block
     const uint32_t nblk = ctx.nblk;
 
@@ -363,13 +382,13 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // ---- blocks 1..nblk: one window per step
     // next free list slot as a 32-bit LDS address (the low half of the flat address of LDS memory)
     const uint32_t list0 = (uint32_t)reinterpret_cast<uintptr_t>(ctx.list);
-    uint32_t lp32 = list0 + ctx.list_used * kListStride;
+    uint32_t lp32 = list0 + ctx.list_used * (uint32_t)PITCH;
     const uint32_t lp_end = list0 + ctx.list_bytes;
     uint32_t dropped = 0;              // entries that did not fit the list
     uint32_t valreg = 0;
     (void)valreg;
     uint32_t stride_v;  // list stride in a VGPR: v_add with two VGPR sources issues at full rate
-    asm volatile("v_mov_b32 %0, %1" : "=v"(stride_v) : "s"(kListStride));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(stride_v) : "s"((uint32_t)PITCH));
     unsigned long long dst = ctx.dst;  // next output slot (DIRECT mode)
     // value of an emitted window: mode 0: (bw0 + lw - 1) + element index; syncmers: bw0 + lw + i
     const uint32_t wbase = ctx.wbase;
@@ -383,6 +402,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     uint32_t pl_in = (uint32_t)pos_in + (uint32_t)((PFD - 1) * W), pl_out = (uint32_t)pos_out + (uint32_t)((PFD - 1) * W);
 #define MM_BUMP(x, c) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "n"(c))
     for (uint32_t b = 1; b <= nblk; ++b) {
+        if (Hook::kActive && b == ctx.hook_block) hook();
         uint32_t me[NSUB], mo[NSUB], tgw[NSUB];
 #pragma unroll
         for (int g = 0; g < NSUB; ++g) {
@@ -452,9 +472,9 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         if (!DIRECT) {
             // keep a whole block of appends inside the list: a lane that is about to run out of
             // slots is parked on its last W slots (its tile is then redone in DIRECT mode)
-            if (lp32 + (uint32_t)W * kListStride > lp_end) {
-                const uint32_t park = lp_end - (uint32_t)W * kListStride;
-                dropped += (lp32 - park) / kListStride;
+            if (lp32 + (uint32_t)W * (uint32_t)PITCH > lp_end) {
+                const uint32_t park = lp_end - (uint32_t)W * (uint32_t)PITCH;
+                dropped += (lp32 - park) / (uint32_t)PITCH;
                 lp32 = park;
             }
         }
@@ -544,6 +564,18 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                         : [sel] "v"(sel), [prev] "v"(prev), [st] "v"(stride_v), [c] "s"(skc)
                         : "vcc", "scc", "memory");  // s_and_saveexec writes SCC
                     prev = sel;
+                } else if (MODE == 0 && EB == 1) {
+                    // (8-bit entries: positions of a pipelined lane stay below 256, so the low bytes decide)
+                    asm volatile(
+                        "v_cmp_ne_u32_sdwa vcc, %[sel], %[prev] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                        "s_and_saveexec_b64 %[sv], vcc\n\t"
+                        "ds_write_b8 %[lp], %[sel]\n\t"
+                        "v_add_u32 %[lp], %[st], %[lp]\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [lp] "+v"(lp32), [sv] "=&s"(sv)
+                        : [sel] "v"(sel), [prev] "v"(prev), [st] "v"(stride_v)
+                        : "vcc", "scc", "memory");
+                    prev = sel;
                 } else if (MODE == 0) {
                     asm volatile(
                         "v_cmp_ne_u32_sdwa vcc, %[sel], %[prev] src0_sel:WORD_0 src1_sel:WORD_0\n\t"
@@ -558,30 +590,34 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 } else if (MODE == 1) {
                     unsigned long long t2;
                     const uint32_t first = i + 1u;
-                    asm volatile(
-                        "v_cmp_eq_u16 vcc, %[a], %[sel]\n\t"
-                        "v_cmp_eq_u16 %[t2], %[sel], %[b]\n\t"
-                        "s_or_b64 vcc, vcc, %[t2]\n\t"
-                        "v_mov_b32 %[val], %[iv]\n\t"
-                        "s_and_saveexec_b64 %[sv], vcc\n\t"
-                        "ds_write_b16 %[lp], %[val]\n\t"
-                        "v_add_u32 %[lp], %[st], %[lp]\n\t"
-                        "s_mov_b64 exec, %[sv]"
-                        : [lp] "+v"(lp32), [sv] "=&s"(sv), [t2] "=&s"(t2), [val] "=&v"(valreg)
-                        : [sel] "v"(sel), [a] "s"(first), [b] "s"(e), [iv] "s"(i), [st] "v"(stride_v)
-                        : "vcc", "scc", "memory");  // s_and_saveexec writes SCC
+#define MM_EMIT_CLOSED(WR)                                                                              \
+    asm volatile("v_cmp_eq_u16 vcc, %[a], %[sel]\n\t"                                                   \
+                 "v_cmp_eq_u16 %[t2], %[sel], %[b]\n\t"                                                 \
+                 "s_or_b64 vcc, vcc, %[t2]\n\t"                                                         \
+                 "v_mov_b32 %[val], %[iv]\n\t"                                                          \
+                 "s_and_saveexec_b64 %[sv], vcc\n\t" WR " %[lp], %[val]\n\t"                            \
+                 "v_add_u32 %[lp], %[st], %[lp]\n\t"                                                    \
+                 "s_mov_b64 exec, %[sv]"                                                                \
+                 : [lp] "+v"(lp32), [sv] "=&s"(sv), [t2] "=&s"(t2), [val] "=&v"(valreg)                 \
+                 : [sel] "v"(sel), [a] "s"(first), [b] "s"(e), [iv] "s"(i), [st] "v"(stride_v)          \
+                 : "vcc", "scc", "memory") /* s_and_saveexec writes SCC */
+                    if (EB == 1) MM_EMIT_CLOSED("ds_write_b8");
+                    else MM_EMIT_CLOSED("ds_write_b16");
+#undef MM_EMIT_CLOSED
                 } else {
                     const uint32_t mid = i + 1u + (uint32_t)(W / 2);
-                    asm volatile(
-                        "v_cmp_eq_u16 vcc, %[a], %[sel]\n\t"
-                        "v_mov_b32 %[val], %[iv]\n\t"
-                        "s_and_saveexec_b64 %[sv], vcc\n\t"
-                        "ds_write_b16 %[lp], %[val]\n\t"
-                        "v_add_u32 %[lp], %[st], %[lp]\n\t"
-                        "s_mov_b64 exec, %[sv]"
-                        : [lp] "+v"(lp32), [sv] "=&s"(sv), [val] "=&v"(valreg)
-                        : [sel] "v"(sel), [a] "s"(mid), [iv] "s"(i), [st] "v"(stride_v)
-                        : "vcc", "scc", "memory");  // s_and_saveexec writes SCC
+#define MM_EMIT_OPEN(WR)                                                                   \
+    asm volatile("v_cmp_eq_u16 vcc, %[a], %[sel]\n\t"                                      \
+                 "v_mov_b32 %[val], %[iv]\n\t"                                             \
+                 "s_and_saveexec_b64 %[sv], vcc\n\t" WR " %[lp], %[val]\n\t"               \
+                 "v_add_u32 %[lp], %[st], %[lp]\n\t"                                       \
+                 "s_mov_b64 exec, %[sv]"                                                   \
+                 : [lp] "+v"(lp32), [sv] "=&s"(sv), [val] "=&v"(valreg)                    \
+                 : [sel] "v"(sel), [a] "s"(mid), [iv] "s"(i), [st] "v"(stride_v)           \
+                 : "vcc", "scc", "memory") /* s_and_saveexec writes SCC */
+                    if (EB == 1) MM_EMIT_OPEN("ds_write_b8");
+                    else MM_EMIT_OPEN("ds_write_b16");
+#undef MM_EMIT_OPEN
                 }
             } else {
                 bool flag;
@@ -605,9 +641,12 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                         ++dst;
                     } else {
                         uint8_t *lp = ctx.list + (lp32 - list0);
-                        *reinterpret_cast<uint16_t *>(lp) =
-                            (uint16_t)(MODE == 0 ? (SK ? sel + i * ((1u << kSkShift<W>) - 1u) : sel) : i);
-                        lp32 += kListStride;
+                        if (EB == 1)
+                            *lp = (uint8_t)(MODE == 0 ? sel : i);
+                        else
+                            *reinterpret_cast<uint16_t *>(lp) =
+                                (uint16_t)(MODE == 0 ? (SK ? sel + i * ((1u << kSkShift<W>) - 1u) : sel) : i);
+                        lp32 += (uint32_t)PITCH;
                     }
                 }
             }
@@ -650,7 +689,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     }
     overflowed = dropped != 0 || lp32 > lp_end;  // entries were dropped (or a parked list is out of order)
     if (DIRECT) return (uint32_t)(dst - ctx.dst);
-    return (lp32 - list0) / kListStride + dropped;
+    return (lp32 - list0) / (uint32_t)PITCH + dropped;
 }
 
 // a no-progress round of lookback_overlapped sleeps up to 64 x 3.5 us: give up after about a second
@@ -729,6 +768,97 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
     return excl;
 }
 
+// One-round-trip look-back (round 2).  Every tile publishes its count (count + 1, one 4-byte word;
+// 0 = not yet); the tiles are grouped in chunks of 1024, and the output offset of a tile is the base
+// of its chunk + the counts of the tiles before it in the chunk: at most 1023 INDEPENDENT loads, 16
+// per lane of the look-back wave, all in flight together - instead of a chain of dependent 64-wide
+// hops back to the nearest tile that already knows its own offset (lookback_overlapped above).  The
+// base of chunk c + 1 is published by the last tile of chunk c.
+// MEASURED SLOWER than the chain in this kernel (3.1 Gbp, MI355X: canonical k=21 w=11 1.88 against
+// 1.85 ms, forward 1.41 against 1.35 ms): both have to wait until every earlier tile has finished its
+// walk, and the chain waits for that with ONE lane polling ONE word, where this one keeps re-reading
+// whatever is missing.  Compiled only with -DMM_LB_CHUNKED (A/B through MM_JIT_DEFS); the pipelined
+// kernel (mm_fused_pipe.h), whose look-backs run half a walk late, uses the same scheme.
+constexpr uint32_t kLbChunk = 1024;
+constexpr unsigned long long kLbBaseValid = 1ull << 63;
+#ifndef MM_LB_POLL_SLEEP
+#define MM_LB_POLL_SLEEP 24
+#endif
+__device__ __forceinline__ uint32_t *lb_counts(unsigned long long *status) { return reinterpret_cast<uint32_t *>(status); }
+__device__ __forceinline__ unsigned long long *lb_bases(unsigned long long *status, uint32_t n_tiles) {
+    return status + ((n_tiles + 1u) >> 1);
+}
+__device__ __forceinline__ void publish_count(unsigned long long *status, uint32_t bid, uint32_t total) {
+    __hip_atomic_store(&lb_counts(status)[bid], total + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long lookback_chunked(unsigned long long *status, uint32_t bid, uint32_t n_tiles,
+                                                               unsigned long long carry_in, uint32_t *error,
+                                                               uint32_t *done, const uint32_t *wave_tot) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t chunk = bid / kLbChunk, g = bid % kLbChunk;
+    uint32_t *cnt = lb_counts(status) + (size_t)chunk * kLbChunk;
+    constexpr int NL = 8;
+    uint32_t sum = 0;
+    for (uint32_t i0 = 0; i0 < g; i0 += (uint32_t)(kWave * NL)) {
+        uint32_t v[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const uint32_t idx = i0 + (uint32_t)(kWave * u) + (uint32_t)lane;
+            v[u] = idx < g ? __hip_atomic_load(&cnt[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+        }
+        for (uint32_t spins = 0;; ++spins) {
+            bool missing = false;
+#pragma unroll
+            for (int u = 0; u < NL; ++u) missing = missing || v[u] == 0u;
+            if (__ballot(missing) == 0ull) break;
+            if (spins > kMaxIdleRounds * 16u) {
+                flag_error(error, 1u);  // dispatch-order violation: the host redoes the launch in ticket mode
+                break;
+            }
+            __builtin_amdgcn_s_sleep(MM_LB_POLL_SLEEP);
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                const uint32_t idx = i0 + (uint32_t)(kWave * u) + (uint32_t)lane;
+                if (v[u] == 0u) v[u] = __hip_atomic_load(&cnt[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) sum += v[u] == 0u ? 0u : v[u] - 1u;
+    }
+    const uint32_t before = __builtin_amdgcn_readlane(wave_scan_dpp(sum), kWave - 1);
+    unsigned long long base = carry_in;
+    if (chunk != 0) {
+        unsigned long long s0 = 0;
+        for (uint32_t spins = 0;; ++spins) {
+            if (lane == 0) s0 = ld_status(&lb_bases(status, n_tiles)[chunk]);
+            s0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(s0 >> 32)) << 32) |
+                 (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)s0);
+            if (s0 & kLbBaseValid) break;
+            if (spins > kMaxIdleRounds * 16u) {
+                flag_error(error, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(MM_LB_POLL_SLEEP);
+        }
+        base = s0 & ~kLbBaseValid;
+    }
+    const unsigned long long excl = base + before;
+    if (g == kLbChunk - 1u && bid + 1u < n_tiles) {
+        // the last tile of a chunk owes the next chunk its base: wait for the other waves of this tile
+        uint32_t block_total = 0;
+        for (uint32_t spins = 0;; ++spins) {
+            const uint32_t dn = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t *>(done));
+            if (dn == (uint32_t)kFusedWaves) break;
+            if (spins > (1u << 24)) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+#pragma unroll
+        for (int v = 0; v < kFusedWaves; ++v) block_total += reinterpret_cast<const volatile uint32_t *>(wave_tot)[v];
+        if (lane == 0) st_status(&lb_bases(status, n_tiles)[chunk + 1u], kLbBaseValid | (excl + block_total));
+    }
+    return excl;
+}
+
 // READS = false: one sequence (range of windows), lane t walks windows [t*S, (t+1)*S) of the tile.
 // READS = true : a batch of short reads at a fixed stride, lane t walks read (tile*256 + t) alone;
 //                positions are read-local and read_offsets[] delimits the reads in the output.
@@ -756,6 +886,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     __shared__ uint32_t s_done;  // waves 1.. that have finished phase 1
     __shared__ uint32_t s_wave_tot[kFusedWaves];
     __shared__ unsigned long long s_excl;
+    __shared__ unsigned long long s_carry;  // outputs before this launch (append mode), read before any tile ends
 
     // kernels that also carry the skip-ambiguous walk: canonical windows, positions only (the
     // reference offers run_skip_ambiguous_windows on canonical builders without super-k-mers,
@@ -777,6 +908,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         st_end = max(st_end, lds_end(&s_done, sizeof(s_done)));
         st_end = max(st_end, lds_end(s_wave_tot, sizeof(s_wave_tot)));
         st_end = max(st_end, lds_end(&s_excl, sizeof(s_excl)));
+        st_end = max(st_end, lds_end(&s_carry, sizeof(s_carry)));
         if ((uint32_t)reinterpret_cast<uintptr_t>(smem) < st_end) {
             if (tid == 0) flag_error(p.out.error, 2u);
             return;
@@ -789,6 +921,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         s_bid = p.use_ticket ? atomicAdd(p.out.ticket, 1u) : blockIdx.x;
         s_overflow = 0;
         s_done = 0;
+        s_carry = *p.out.total;
     }
     if (tid < 16) s_tab[tid] = p.ht.t_in_out[tid];
     else if (tid < 20) s_tab[tid] = p.ht.t_in[tid - 16];
@@ -857,6 +990,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     ctx.list_bytes = p.list_cap * kListStride;
     ctx.dst = 0;
     ctx.nblk = p.nblk;
+    ctx.hook_block = 0;
     ctx.seq_d = seq_d;
     ctx.seq_dwords = seq_dwords;
     bool lane_active = false;
@@ -943,20 +1077,36 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         s_wave_tot[wave] = wave_total;
         // LDS, in order behind the store above.  The wave that finishes phase 1 last publishes the
         // tile's aggregate at once (successors wait for that, never for this tile's look-back).
+#ifndef MM_LB_CHUNKED
         if (atomicAdd(&s_done, 1u) == (uint32_t)(kFusedWaves - 1) && bid != 0 && !(p.debug & 1u)) {
             uint32_t tot = 0;
 #pragma unroll
             for (int v = 0; v < kFusedWaves; ++v) tot += reinterpret_cast<volatile uint32_t *>(s_wave_tot)[v];
             publish_aggregate(p.out.status, bid, tot);
         }
+#else
+        if (atomicAdd(&s_done, 1u) == (uint32_t)(kFusedWaves - 1) && !(p.debug & 1u)) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int v = 0; v < kFusedWaves; ++v) tot += reinterpret_cast<volatile uint32_t *>(s_wave_tot)[v];
+            publish_count(p.out.status, bid, tot);
+        }
+#endif
     }
     if (wave == 0) {
         // Wave 0 runs the look-back (non-blocking, see lookback_overlapped) as soon as its own lanes
         // are done; the wave that finishes last has published the tile's aggregate.
+#ifndef MM_LB_CHUNKED
         const unsigned long long carry = (bid == 0) ? *p.out.total : 0ull;
         const unsigned long long ex =
             (p.debug & 1u) ? (unsigned long long)bid * (NB / 6u)
                            : lookback_overlapped(p.out.status, bid, carry, p.out.error, &s_done, s_wave_tot);
+#else
+        const unsigned long long carry = s_carry;  // base of chunk 0: every tile of that chunk needs it
+        const unsigned long long ex =
+            (p.debug & 1u) ? (unsigned long long)bid * (NB / 6u)
+                           : lookback_chunked(p.out.status, bid, gridDim.x, carry, p.out.error, &s_done, s_wave_tot);
+#endif
         if (lane == 0) s_excl = ex;
         if (p.trace && lane == 0) p.trace[10 * (size_t)bid + 2] = wall_clock64();
     }
@@ -1006,7 +1156,10 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
                 __builtin_amdgcn_make_buffer_rsrc(p.out.pos + run0_u, 0, (int)room_bytes, 0x00020000);
             const __amdgpu_buffer_rsrc_t osk = __builtin_amdgcn_make_buffer_rsrc(
                 SK ? p.out.sk + run0_u : p.out.pos + run0_u, 0, (int)room_bytes, 0x00020000);
-            constexpr int kBatch = 8;
+#ifndef MM_COPY_BATCH
+#define MM_COPY_BATCH 8
+#endif
+            constexpr int kBatch = MM_COPY_BATCH;
             const uint32_t store_mask =
                 __builtin_amdgcn_readfirstlane((p.debug & 8u) ? 0u : 0xffffffffu);  // timing experiment: no store
             // Fast path (the whole wave fits the caller's capacity, no SK): the lane mask "entry <
@@ -1037,6 +1190,43 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
             // a list that is copied holds at most 315 entries - 159 KB of LDS - and a wave's lists at most
             // 64 times that many)
             const uint32_t pk = (excl << 9) | (my_count & 511u);
+            // (Tried in round 2: a lane-owned copy-out - every lane streams its own list with 16-byte stores,
+            // a third of the instructions - ran the whole kernel 2.8 x slower, 5.2 ms: a wave's 64 scattered
+            // segments per store defeat the memory pipeline.  The stores have to stay coalesced.)
+            {
+#ifndef MM_COPY_EXEC
+            if (fast) {
+                // The lanes of a list are selected by the bounds check of its store: a descriptor whose
+                // num_records ends behind the list's last entry drops the lanes past it.  No EXEC write, so
+                // consecutive lists do not serialise on the mask (a wave's time off the walk is what the
+                // copy-out costs: the walk runs where VALU issue and per-wave latency both bind).
+                const uint32_t *obase32 = p.out.pos + run0_u;
+                const uint32_t *sbase32 = (SK ? p.out.sk : p.out.pos) + run0_u;
+#pragma unroll
+                for (int L0 = 0; L0 < kWave; L0 += kBatch) {
+                    uint32_t ent[kBatch];
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) ent[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u));
+#pragma unroll
+                    for (int u = 0; u < kBatch; ++u) {
+                        const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
+                        const uint32_t n = pkl & 511u, off = pkl >> 9;
+                        const uint32_t vbl = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
+                        const uint32_t iw = ent[u] >> kSh;
+                        const uint32_t val = SK ? vbl + iw + (ent[u] & kRelMask) : vbl + ent[u];
+                        const uint32_t end_bytes = ((off + n) * 4u) & store_mask;  // (store_mask 0: timing experiment)
+                        const __amdgpu_buffer_rsrc_t dl = __builtin_amdgcn_make_buffer_rsrc(
+                            const_cast<uint32_t *>(obase32), 0, (int)end_bytes, 0x00020000);
+                        __builtin_amdgcn_raw_buffer_store_b32(val, dl, lane4, off * 4u, MM_STORE_AUX);
+                        if (SK) {
+                            const __amdgpu_buffer_rsrc_t dl2 = __builtin_amdgcn_make_buffer_rsrc(
+                                const_cast<uint32_t *>(sbase32), 0, (int)end_bytes, 0x00020000);
+                            __builtin_amdgcn_raw_buffer_store_b32(vbl + 1u + iw, dl2, lane4, off * 4u, MM_STORE_AUX);
+                        }
+                    }
+                }
+            } else
+#endif
             if (fast) {
 #pragma unroll
                 for (int L0 = 0; L0 < kWave; L0 += kBatch) {
@@ -1123,6 +1313,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
                         if (SK) __builtin_amdgcn_raw_buffer_store_b32(vb + 1u + iw, osk, (off + c) * 4u, 0, 0);
                     }
                 }
+            }
             }
         }
     } else if (READS) {

@@ -1,0 +1,19 @@
+// Explicit instantiations of the pipelined kernel (mm_fused_pipe.h), split over several files so that
+// the build parallelises; the launcher in mm_fused.hip looks them up through pipe_instances_a().
+// Window sizes 16 and 1, canonical and forward.
+#include "mm_fused_inst.h"
+
+namespace mm {
+
+const PipeInstance *pipe_instances_a(int *count) {
+    static const PipeInstance kInst[] = {
+        MM_PIPE_INST(16, true, true),
+        MM_PIPE_INST(16, false, false),
+        MM_PIPE_INST(1, true, true),
+        MM_PIPE_INST(1, false, false),
+    };
+    *count = (int)(sizeof(kInst) / sizeof(kInst[0]));
+    return kInst;
+}
+
+}  // namespace mm

@@ -1,0 +1,19 @@
+// Explicit instantiations of the pipelined kernel (mm_fused_pipe.h), split over several files so that
+// the build parallelises; the launcher in mm_fused.hip looks them up through pipe_instances_f().
+// Window sizes 11 and 6, canonical and forward.
+#include "mm_fused_inst.h"
+
+namespace mm {
+
+const PipeInstance *pipe_instances_f(int *count) {
+    static const PipeInstance kInst[] = {
+        MM_PIPE_INST(11, true, true),
+        MM_PIPE_INST(11, false, false),
+        MM_PIPE_INST(6, true, true),
+        MM_PIPE_INST(6, false, false),
+    };
+    *count = (int)(sizeof(kInst) / sizeof(kInst[0]));
+    return kInst;
+}
+
+}  // namespace mm

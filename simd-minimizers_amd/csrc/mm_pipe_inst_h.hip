@@ -1,0 +1,19 @@
+// Explicit instantiations of the pipelined kernel (mm_fused_pipe.h), split over several files so that
+// the build parallelises; the launcher in mm_fused.hip looks them up through pipe_instances_h().
+// Window sizes 9 and 8, canonical and forward.
+#include "mm_fused_inst.h"
+
+namespace mm {
+
+const PipeInstance *pipe_instances_h(int *count) {
+    static const PipeInstance kInst[] = {
+        MM_PIPE_INST(9, true, true),
+        MM_PIPE_INST(9, false, false),
+        MM_PIPE_INST(8, true, true),
+        MM_PIPE_INST(8, false, false),
+    };
+    *count = (int)(sizeof(kInst) / sizeof(kInst[0]));
+    return kInst;
+}
+
+}  // namespace mm

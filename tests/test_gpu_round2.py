@@ -71,7 +71,7 @@ def test_run_with_buf_and_pos_and_values(sm, oracle, gpu):
     data = oracle.gen_packed(8, n)
     seq = sm.PackedSeq(data, 0, n)
     cache = sm.Workspace(0)
-    for k, w, canonical in ((21, 11, True), (33, 9, False), (40, 25, True)):
+    for k, w, canonical in ((21, 11, True), (33, 9, False), (41, 25, True)):
         b = sm.Builder(k, w, canonical, 0)
         a, c = [], []
         b.run(seq, a)
