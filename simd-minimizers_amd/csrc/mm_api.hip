@@ -618,6 +618,13 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
         const uint64_t per_seq = a.work_windows / nonempty * 1024ull;
         if (per_seq < a.work_windows) a.work_windows = per_seq ? per_seq : 1;
     }
+    {
+        // lanes sized so that the batch fills whole rounds of resident workgroups (mm_fused.hip)
+        std::vector<uint64_t> nws(n_seqs);
+        for (uint64_t s = 0; s < n_seqs; ++s) nws[s] = n_bases[s] >= l ? n_bases[s] - l + 1 : 0;
+        const uint32_t nb = mm::fused_batch_nblk(a, nws.data(), n_seqs);
+        if (nb) a.nblk = nb;
+    }
     const uint64_t NB = mm::fused_tile_windows(a);
 
     std::vector<mm::BatchSeq> seqs(n_seqs);

@@ -60,8 +60,8 @@ uint32_t default_cap_limit(uint32_t w, bool canonical) {
     if (!canonical) return w <= 20u ? 51u : 38u;
     if (w <= 16u) return 76u;
     if (w <= 20u) return 62u;
-    if (w <= 31u) return 44u;
-    if (w <= 36u) return 51u;
+    if (w <= 31u) return 51u;  // (round 2, with the short look-ahead: w = 25: 1.737 ms at 51 against 1.778 at 44)
+    if (w <= 37u) return 44u;  // (four workgroups per CU since round 2: w = 33: 1.813 at 44, 1.838 at 51, 2.10 at 76)
     return 76u;
 }
 
@@ -89,11 +89,6 @@ struct Geometry {
 
 constexpr uint32_t kMaxLdsBytes = 159u * 1024u;  // 160 KB per CU minus the static tables
 
-// workgroups per CU the forward pipelined kernels are built for (MM_PIPE_MIN_BLOCKS in mm_fused_pipe.h)
-uint32_t pipe_forward_blocks() {
-    static const uint32_t v = getenv("MM_PIPE_FWD_BLOCKS") ? (uint32_t)atoi(getenv("MM_PIPE_FWD_BLOCKS")) : 5u;
-    return v < 1u ? 1u : v;
-}
 
 Geometry geometry(const RunArgs &a) {
     Geometry g;
@@ -129,63 +124,6 @@ Geometry geometry(const RunArgs &a) {
         const uint64_t nwin = a.win_end - a.win_begin;
         g.nblocks = (nwin + g.NB - 1) / g.NB;
     }
-    return g;
-}
-
-// ------------------------------------------------------------------ pipelined kernel (mm_fused_pipe.h)
-const PipeInstance *find_pipe_instance(uint32_t w, int canonical_windows, int hasher_canonical) {
-    using Getter = const PipeInstance *(*)(int *);
-    static const Getter kGroups[] = {pipe_instances_a, pipe_instances_b, pipe_instances_c, pipe_instances_d,
-                                     pipe_instances_e, pipe_instances_f, pipe_instances_g, pipe_instances_h};
-    for (Getter get : kGroups) {
-        int n = 0;
-        const PipeInstance *inst = get(&n);
-        for (int i = 0; i < n; ++i)
-            if (inst[i].w == w && inst[i].canon == (canonical_windows != 0) &&
-                inst[i].hash_rc == (hasher_canonical != 0))
-                return &inst[i];
-    }
-    return nullptr;
-}
-
-// One sequence or window range, positions only, no ticket mode, a prebuilt instance (w <= 16):
-// everything else stays on the unpipelined kernel.  MM_PIPE=0 switches the pipelined kernel off.
-bool pipe_eligible(const RunArgs &a) {
-    static const bool enabled = !(getenv("MM_PIPE") && atoi(getenv("MM_PIPE")) == 0);
-    if (!enabled || a.batch_tile_seq || a.wamb || a.out.sk || a.use_ticket || a.mode > 2) return false;
-    if (getenv("MM_DEBUG") || getenv("MM_TRACE") || getenv("MM_JIT_FORCE")) return false;  // experiments: old kernel
-    return find_pipe_instance(a.w, a.canonical_windows, (int)a.ht.canonical) != nullptr;
-}
-
-struct PipeGeometry {
-    uint32_t nblk, S, NB, list_cap, lds_bytes;
-    uint64_t n_tiles;
-};
-
-// Lanes of the pipelined kernel: positions inside a lane are 8 bits (S + w <= 255), and the two list
-// buffers of a workgroup (list_cap rows of kPipePitch bytes) have to leave room for `per_cu`
-// workgroups per CU.
-PipeGeometry pipe_geometry(const RunArgs &a) {
-    PipeGeometry g;
-    const uint32_t per_cu = a.canonical_windows ? 4u : pipe_forward_blocks();
-    const uint32_t lds_budget = (kMaxLdsBytes - per_cu * 1024u) / per_cu;  // minus the static tables
-    uint32_t nblk = a.nblk ? a.nblk : (255u - a.w) / a.w;
-    if (nblk > (255u - a.w) / a.w) nblk = (255u - a.w) / a.w;
-    if (nblk < 1u) nblk = 1u;
-    // open syncmers come in clumps (see legal_nblk): keep the expected list near 30 entries
-    while (a.nblk == 0 && a.mode == 2 && nblk > 6u && emit_density(a.w, a.mode) * a.w * nblk > 30.0) --nblk;
-    while (a.nblk == 0 && nblk > 1u && list_capacity(a.w, a.mode, a.w * nblk) * kPipePitch > lds_budget) --nblk;
-    // a run too short to fill the chip once gets shorter lanes (as in geometry())
-    if (a.nblk == 0 && a.work_windows != 0) {
-        const uint64_t fit = a.work_windows / ((uint64_t)per_cu * 256ull * kFusedThreads * a.w);
-        if (fit < nblk) nblk = fit < 6u ? (nblk < 6u ? nblk : 6u) : (uint32_t)fit;
-    }
-    g.nblk = nblk;
-    g.S = a.w * nblk;
-    g.NB = kFusedThreads * g.S;
-    g.list_cap = list_capacity(a.w, a.mode, g.S);
-    g.lds_bytes = g.list_cap * kPipePitch;
-    g.n_tiles = (a.win_end - a.win_begin + g.NB - 1) / g.NB;
     return g;
 }
 
@@ -251,99 +189,106 @@ bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_c
 }
 
 uint64_t fused_status_words(const RunArgs &a) {
-    uint64_t need = geometry(a).nblocks + 8;  // per-tile counts (4 bytes) + per-chunk bases (lookback_chunked)
-    if (pipe_eligible(a)) {
-        // per-tile counts (4 bytes each) followed by the per-round bases (8 bytes each, at most one per tile)
-        const PipeGeometry g = pipe_geometry(a);
-        const uint64_t words = (g.n_tiles + 1) / 2 + g.n_tiles / 64 + 8;
-        if (words > need) need = words;
-    }
-    return need;
+    // (x 1.2: tune_whole_rounds may shorten the lanes by 15 %; + 8: the chunked look-back variant keeps
+    // per-tile counts and per-chunk bases in the same words)
+    return geometry(a).nblocks * 6 / 5 + 8;
 }
 uint32_t fused_tile_windows(const RunArgs &a) { return geometry(a).NB; }
 
 static uint32_t g_lds_pad = 0;
 
-// Launch of the pipelined kernel: the grid is one workgroup per resident slot of the chip.
-// Returns 0, -1 (HIP failure) or -2 (not possible here: take the unpipelined kernel).
-static int launch_pipe(const RunArgs &a, hipStream_t stream) {
-    const PipeInstance *inst = find_pipe_instance(a.w, a.canonical_windows, (int)a.ht.canonical);
-    if (!inst) return -2;
-    const PipeGeometry g = pipe_geometry(a);
-    if (g.n_tiles == 0) return 0;
-    if (g.n_tiles >= (1ull << 31) || g.lds_bytes > kMaxLdsBytes) return -2;
-    const KernelFn fn = inst->fn[a.mode];
-    if (g.lds_bytes > 64u * 1024u &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)g.lds_bytes) != hipSuccess)
-        return -2;
-    // co-resident workgroups: what the occupancy calculator says for this kernel and this much LDS
-    int dev = 0, cus = 0, per_cu = 0;
+// Whole rounds.  A long run is walked in "rounds" of as many tiles as the chip holds workgroups
+// (occupancy x CUs); with long lanes and few workgroups per CU there are only about ten of them
+// (canonical k=31 w=51 on 3.1 Gbp: 8 794 tiles over 768 slots), and a last round that is one third full
+// costs as much as a full one.  Within +-15 % of the default lane length, pick the one that wastes
+// least: cost = ceil(tiles / slots) x (blocks per lane + the per-tile overhead in blocks).  Measured on
+// 3.1 Gbp, k=31 w=51: 27 blocks (default) 1.974 ms, 29 blocks 1.904 ms, 30 blocks 2.005 ms; w=33: 12
+// blocks 1.829, 13 blocks 1.890, 14 blocks 1.816 (tools/gpu_nblk2.py).  Runs of 24 rounds or more are
+// left alone (at most 4 % to win), as are batches (their tile table is built from the default).
+// tiles(S) = tiles of the run with S windows per lane; returns the chosen blocks per lane (g.nblk if
+// nothing is to be gained)
+template <class TilesFn>
+static uint32_t whole_rounds_nblk(const RunArgs &a, const KernelRef &kr, const Geometry &g, TilesFn tiles_of) {
+    static const bool off = getenv("MM_NO_ROUNDS") != nullptr;
+    if (off || a.nblk != 0 || g.nblocks <= 512) return g.nblk;
+    int per_cu = 0, cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(fn), kFusedThreads,
-                                                     g.lds_bytes) != hipSuccess ||
-        per_cu < 1 || cus < 1) {
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return g.nblk;
+    const hipError_t e =
+        kr.host ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kr.host),
+                                                               kFusedThreads, g.lds_bytes)
+                : hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kr.mod, kFusedThreads, g.lds_bytes);
+    if (e != hipSuccess || per_cu < 1 || cus < 1) {
         (void)hipGetLastError();
-        return -2;
+        return g.nblk;
     }
-    if (const char *e = getenv("MM_PIPE_PER_CU")) per_cu = atoi(e) > 0 && atoi(e) < per_cu ? atoi(e) : per_cu;  // experiments
-    uint64_t grid = (uint64_t)per_cu * (uint64_t)cus;
-    if (grid > g.n_tiles) grid = g.n_tiles;
-    // MM_PIPE_TILES=M: every workgroup walks M consecutive tiles and ends (in-order dispatch) instead of
-    // a persistent grid on tickets
-    static const uint32_t tiles_per_wg = getenv("MM_PIPE_TILES") ? (uint32_t)atoi(getenv("MM_PIPE_TILES")) : 0u;
-    if (tiles_per_wg) grid = (g.n_tiles + tiles_per_wg - 1) / tiles_per_wg;
-    const uint64_t chunks = (g.n_tiles + kPipeChunk - 1) / kPipeChunk;
+    const double slots = 0.98 * per_cu * cus;  // (a round that is 99 % full spills into the next one)
+    const double kOverheadBlocks = 2.4;  // warm-up, look-back and copy-out of a tile, in W-blocks of walking
+    if ((double)g.nblocks / slots >= 24.0 || (double)g.nblocks / slots <= 1.0) return g.nblk;
+    const uint32_t lds_limit = (kMaxLdsBytes - (uint32_t)per_cu * 512u) / (uint32_t)per_cu;
+    uint32_t sh = 0;
+    if (a.out.sk && a.mode == 0)
+        for (sh = 1; (1u << sh) <= a.w;) ++sh;
+    double best = 0.0;
+    uint32_t best_nb = g.nblk;
+    const uint32_t lo = g.nblk * 85u / 100u > 6u ? g.nblk * 85u / 100u : 6u, hi = g.nblk * 115u / 100u;
+    for (uint32_t nb = lo; nb <= hi; ++nb) {
+        const uint64_t S = (uint64_t)a.w * nb;
+        if (S > 60000u || (sh && (S << sh) > 65536u)) continue;
+        if (list_capacity(a.w, a.mode, (uint32_t)S) * kListStride > lds_limit) continue;
+        const double rounds = (double)tiles_of(S) / slots;
+        const double cost = (double)(uint64_t)(rounds + 0.999999) * (nb + kOverheadBlocks);
+        if (best == 0.0 || cost < best * 0.995 || (nb == g.nblk && cost <= best * 1.005)) {
+            best = cost;
+            best_nb = nb;
+        }
+    }
+    return best_nb;
+}
 
-    FusedParams p;
-    p.seq = a.seq;
-    p.ht = a.ht;
-    p.k = a.k;
-    p.nblk = g.nblk;
-    p.win_begin = (uint32_t)a.win_begin;
-    p.win_end = (uint32_t)a.win_end;
-    p.list_cap = g.list_cap;
-    p.use_ticket = 0;
-    p.debug = getenv("MM_PIPE_DEBUG") ? (uint32_t)atoi(getenv("MM_PIPE_DEBUG")) : 0u;  // timing experiments
-    p.n_reads = 0;
-    p.reads_per_lane = 1;
-    p.read_stride = p.read_len = 0;
-    p.read_lens = nullptr;
-    p.read_offsets = nullptr;
-    p.wamb = nullptr;
-    p.wamb_dwords = 0;
-    p.batch_seqs = nullptr;
-    p.batch_tile_seq = nullptr;
-    p.batch_offsets = nullptr;
-    p.batch_n = 0;
-    p.trace = nullptr;
-    p.out = a.out;
-    p.n_tiles = (uint32_t)g.n_tiles;
-    p.tiles_per_wg = tiles_per_wg;
-    p.pipe_counts = reinterpret_cast<uint32_t *>(a.out.status);
-    const uint64_t count_words = (g.n_tiles + 1) / 2;  // 8-byte words holding the 4-byte counts
-    p.pipe_round_base = a.out.status + count_words;
-    if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (count_words + chunks + 2), stream) != hipSuccess)
-        return -1;
-    if (hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
-    if (a.timing_start) hipEventRecord(a.timing_start, stream);
-    hipLaunchKernelGGL(fn, dim3((uint32_t)grid), dim3(kFusedThreads), g.lds_bytes, stream, p);
-    if (a.timing_stop) hipEventRecord(a.timing_stop, stream);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+static void tune_whole_rounds(const RunArgs &a, const KernelRef &kr, Geometry &g) {
+    if (a.batch_tile_seq) return;  // (a batch's tile table is already built: see fused_batch_nblk)
+    const uint64_t nwin = a.win_end - a.win_begin;
+    const uint32_t nb = whole_rounds_nblk(a, kr, g, [&](uint64_t S) {
+        return (nwin + kFusedThreads * S - 1) / (kFusedThreads * S);
+    });
+    if (nb == g.nblk) return;
+    g.nblk = nb;
+    g.S = a.w * g.nblk;
+    g.list_cap = list_capacity(a.w, a.mode, g.S);
+    g.lds_bytes = g.list_cap * kListStride;
+    g.NB = kFusedThreads * g.S;
+    g.nblocks = (nwin + g.NB - 1) / g.NB;
+}
+
+// The same for a batch of sequences (every sequence starts a tile of its own): blocks per lane to
+// build the tile table with, or 0 to keep the default.  `n_windows[s]` = windows of sequence s.
+uint32_t fused_batch_nblk(const RunArgs &a, const uint64_t *n_windows, uint64_t n_seqs) {
+    if (a.nblk != 0) return 0;
+    Geometry g = geometry(a);
+    uint64_t tiles = 0;
+    for (uint64_t s = 0; s < n_seqs; ++s) tiles += (n_windows[s] + g.NB - 1) / g.NB;
+    g.nblocks = tiles;
+    if (tiles <= 512) return 0;
+    const KernelRef kr = resolve_kernel(a.w, a.canonical_windows, (int)a.ht.canonical, a.mode, a.out.sk != nullptr);
+    if (!kr) return 0;
+    const uint32_t nb = whole_rounds_nblk(a, kr, g, [&](uint64_t S) {
+        uint64_t t = 0;
+        for (uint64_t s = 0; s < n_seqs; ++s) t += (n_windows[s] + kFusedThreads * S - 1) / (kFusedThreads * S);
+        return t;
+    });
+    return nb == g.nblk ? 0u : nb;
 }
 
 int launch_fused(const RunArgs &a, hipStream_t stream) {
-    if (pipe_eligible(a)) {
-        const int r = launch_pipe(a, stream);
-        if (r != -2) return r;
-    }
-    const Geometry g = geometry(a);
+    Geometry g = geometry(a);
     if (g.nblocks == 0) return 0;
     if (g.lds_bytes > kMaxLdsBytes) return -2;
     const KernelRef kr = resolve_kernel(a.w, a.canonical_windows, (int)a.ht.canonical, a.mode,
                                         a.out.sk != nullptr);
     if (!kr) return -2;
+    tune_whole_rounds(a, kr, g);
 
     FusedParams p;
     p.seq = a.seq;
@@ -365,10 +310,6 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.batch_offsets = a.batch_offsets;
     p.batch_n = a.batch_n;
     p.out = a.out;
-    p.n_tiles = 0;
-    p.tiles_per_wg = 0;
-    p.pipe_counts = nullptr;
-    p.pipe_round_base = nullptr;
     p.use_ticket = a.use_ticket ? 1u : 0u;
     {
         const char *dbg = getenv("MM_DEBUG");
@@ -502,10 +443,6 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.batch_offsets = nullptr;
     p.batch_n = 0;
     p.trace = nullptr;
-    p.n_tiles = 0;
-    p.tiles_per_wg = 0;
-    p.pipe_counts = nullptr;
-    p.pipe_round_base = nullptr;
     p.out = a.out;
     if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (nblocks + 8), stream) != hipSuccess) return -1;
     // (the ticket is only read in ticket mode: one stream operation less per run otherwise)

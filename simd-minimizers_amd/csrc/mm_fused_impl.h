@@ -81,13 +81,6 @@ struct FusedParams {
     uint32_t batch_n;
     // timing experiments (MM_TRACE): 4 timestamps per tile (start, phase 1 done, look-back done, end)
     unsigned long long *trace;
-    // pipelined kernel (mm_fused_pipe.h): tiles of the run, per-tile counts (count + 1, zeroed per
-    // launch), per-round output bases (bit 63 = valid, zeroed per launch)
-    uint32_t n_tiles;
-    uint32_t tiles_per_wg;  // 0: tiles from the atomic ticket (persistent grid); M > 0: workgroup b walks tiles
-                            // b * M .. b * M + M - 1 and ends (in-order dispatch, like the unpipelined kernel)
-    uint32_t *pipe_counts;
-    unsigned long long *pipe_round_base;
     OutParams out;
 };
 
@@ -162,25 +155,13 @@ struct LaneCtx {
     uint32_t nblk;           // W-blocks this lane walks
     const uint32_t *seq_d;   // the sequence the tile reads (p.seq, or the batch entry)
     uint32_t seq_dwords;
-    uint32_t hook_block;     // W-block before which the walk runs its hook (wave-uniform; 0 = never)
 };
 
 // One lane walks its S windows.  List mode: appends emitted 16-bit values to the lane's LDS
 // list (entries past the capacity are dropped but counted).  DIRECT mode: stores final values
 // to HBM from ctx.dst on.  Returns the number of emitted windows.
-// EB: bytes per list entry (2; 1 in the pipelined kernel, whose lanes are short enough for 8-bit
-// positions), PITCH: bytes between consecutive entries of one lane's list.  `hook` runs once, at the
-// top of W-block ctx.hook_block (wave-uniform; 0 = never): the pipelined kernel puts the previous
-// tile's look-back there, in the middle of this tile's walk.
-struct NoHook {
-    static constexpr bool kActive = false;
-    __device__ __forceinline__ void operator()() const {}
-};
-template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool DIRECT, bool PARTIAL, bool AMBI = false, int EB = 2,
-          int PITCH = (int)kListStride, class Hook = NoHook>
-__device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCtx &ctx, bool &overflowed,
-                                              Hook hook = Hook()) {
-    static_assert(EB == 2 || (EB == 1 && !SK), "8-bit list entries: positions only");
+template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool DIRECT, bool PARTIAL, bool AMBI = false>
+__device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCtx &ctx, bool &overflowed) {
     constexpr int NSUB = (W + 15) / 16;  // 16-base view words per W-block
     const uint32_t nblk = ctx.nblk;
 
@@ -382,13 +363,13 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // ---- blocks 1..nblk: one window per step
     // next free list slot as a 32-bit LDS address (the low half of the flat address of LDS memory)
     const uint32_t list0 = (uint32_t)reinterpret_cast<uintptr_t>(ctx.list);
-    uint32_t lp32 = list0 + ctx.list_used * (uint32_t)PITCH;
+    uint32_t lp32 = list0 + ctx.list_used * kListStride;
     const uint32_t lp_end = list0 + ctx.list_bytes;
     uint32_t dropped = 0;              // entries that did not fit the list
     uint32_t valreg = 0;
     (void)valreg;
     uint32_t stride_v;  // list stride in a VGPR: v_add with two VGPR sources issues at full rate
-    asm volatile("v_mov_b32 %0, %1" : "=v"(stride_v) : "s"((uint32_t)PITCH));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(stride_v) : "s"(kListStride));
     unsigned long long dst = ctx.dst;  // next output slot (DIRECT mode)
     // value of an emitted window: mode 0: (bw0 + lw - 1) + element index; syncmers: bw0 + lw + i
     const uint32_t wbase = ctx.wbase;
@@ -402,7 +383,6 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     uint32_t pl_in = (uint32_t)pos_in + (uint32_t)((PFD - 1) * W), pl_out = (uint32_t)pos_out + (uint32_t)((PFD - 1) * W);
 #define MM_BUMP(x, c) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "n"(c))
     for (uint32_t b = 1; b <= nblk; ++b) {
-        if (Hook::kActive && b == ctx.hook_block) hook();
         uint32_t me[NSUB], mo[NSUB], tgw[NSUB];
 #pragma unroll
         for (int g = 0; g < NSUB; ++g) {
@@ -472,9 +452,9 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         if (!DIRECT) {
             // keep a whole block of appends inside the list: a lane that is about to run out of
             // slots is parked on its last W slots (its tile is then redone in DIRECT mode)
-            if (lp32 + (uint32_t)W * (uint32_t)PITCH > lp_end) {
-                const uint32_t park = lp_end - (uint32_t)W * (uint32_t)PITCH;
-                dropped += (lp32 - park) / (uint32_t)PITCH;
+            if (lp32 + (uint32_t)W * kListStride > lp_end) {
+                const uint32_t park = lp_end - (uint32_t)W * kListStride;
+                dropped += (lp32 - park) / kListStride;
                 lp32 = park;
             }
         }
@@ -493,9 +473,12 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
 #ifdef MM_PF
         constexpr int PF = W < MM_PF ? W : MM_PF;
 #else
-        // (canonical w = 42..47 are bounded to 168 VGPRs: the shallower look-ahead keeps their
-        // rings out of scratch, w = 47: 0.753 -> 0.686 ms per Gbp)
-        constexpr int PF = W < 12 ? W : (CANON && W >= 42 && W <= 47 ? 4 : 12);
+        // Canonical walks with w >= 19 look only one or two steps ahead: the registers a deeper look-ahead
+        // costs are worth more as an extra wave per SIMD, which hides the LDS latency just as well
+        // (round 2, 3.1 Gbp, against 12 steps ahead: w = 25 +4 %, 31 +5 %, and together with the tighter
+        // register bounds below w = 33 +11 %, 37 +19 %, 51 +18 %; tools/gpu_jit_w.py).  Smaller windows
+        // and forward walks are indifferent to it.
+        constexpr int PF = W < 12 ? W : (CANON && W >= 19 ? (W >= 48 ? 1 : 2) : 12);
 #endif
         uint2 tq[W];
         auto lookup = [&](int j) -> uint2 {
@@ -564,18 +547,6 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                         : [sel] "v"(sel), [prev] "v"(prev), [st] "v"(stride_v), [c] "s"(skc)
                         : "vcc", "scc", "memory");  // s_and_saveexec writes SCC
                     prev = sel;
-                } else if (MODE == 0 && EB == 1) {
-                    // (8-bit entries: positions of a pipelined lane stay below 256, so the low bytes decide)
-                    asm volatile(
-                        "v_cmp_ne_u32_sdwa vcc, %[sel], %[prev] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
-                        "s_and_saveexec_b64 %[sv], vcc\n\t"
-                        "ds_write_b8 %[lp], %[sel]\n\t"
-                        "v_add_u32 %[lp], %[st], %[lp]\n\t"
-                        "s_mov_b64 exec, %[sv]"
-                        : [lp] "+v"(lp32), [sv] "=&s"(sv)
-                        : [sel] "v"(sel), [prev] "v"(prev), [st] "v"(stride_v)
-                        : "vcc", "scc", "memory");
-                    prev = sel;
                 } else if (MODE == 0) {
                     asm volatile(
                         "v_cmp_ne_u32_sdwa vcc, %[sel], %[prev] src0_sel:WORD_0 src1_sel:WORD_0\n\t"
@@ -601,8 +572,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                  : [lp] "+v"(lp32), [sv] "=&s"(sv), [t2] "=&s"(t2), [val] "=&v"(valreg)                 \
                  : [sel] "v"(sel), [a] "s"(first), [b] "s"(e), [iv] "s"(i), [st] "v"(stride_v)          \
                  : "vcc", "scc", "memory") /* s_and_saveexec writes SCC */
-                    if (EB == 1) MM_EMIT_CLOSED("ds_write_b8");
-                    else MM_EMIT_CLOSED("ds_write_b16");
+                    MM_EMIT_CLOSED("ds_write_b16");
 #undef MM_EMIT_CLOSED
                 } else {
                     const uint32_t mid = i + 1u + (uint32_t)(W / 2);
@@ -615,8 +585,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                  : [lp] "+v"(lp32), [sv] "=&s"(sv), [val] "=&v"(valreg)                    \
                  : [sel] "v"(sel), [a] "s"(mid), [iv] "s"(i), [st] "v"(stride_v)           \
                  : "vcc", "scc", "memory") /* s_and_saveexec writes SCC */
-                    if (EB == 1) MM_EMIT_OPEN("ds_write_b8");
-                    else MM_EMIT_OPEN("ds_write_b16");
+                    MM_EMIT_OPEN("ds_write_b16");
 #undef MM_EMIT_OPEN
                 }
             } else {
@@ -641,12 +610,9 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                         ++dst;
                     } else {
                         uint8_t *lp = ctx.list + (lp32 - list0);
-                        if (EB == 1)
-                            *lp = (uint8_t)(MODE == 0 ? sel : i);
-                        else
-                            *reinterpret_cast<uint16_t *>(lp) =
-                                (uint16_t)(MODE == 0 ? (SK ? sel + i * ((1u << kSkShift<W>) - 1u) : sel) : i);
-                        lp32 += (uint32_t)PITCH;
+                        *reinterpret_cast<uint16_t *>(lp) =
+                            (uint16_t)(MODE == 0 ? (SK ? sel + i * ((1u << kSkShift<W>) - 1u) : sel) : i);
+                        lp32 += kListStride;
                     }
                 }
             }
@@ -689,7 +655,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     }
     overflowed = dropped != 0 || lp32 > lp_end;  // entries were dropped (or a parked list is out of order)
     if (DIRECT) return (uint32_t)(dst - ctx.dst);
-    return (lp32 - list0) / (uint32_t)PITCH + dropped;
+    return (lp32 - list0) / kListStride + dropped;
 }
 
 // a no-progress round of lookback_overlapped sleeps up to 64 x 3.5 us: give up after about a second
@@ -777,8 +743,7 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
 // MEASURED SLOWER than the chain in this kernel (3.1 Gbp, MI355X: canonical k=21 w=11 1.88 against
 // 1.85 ms, forward 1.41 against 1.35 ms): both have to wait until every earlier tile has finished its
 // walk, and the chain waits for that with ONE lane polling ONE word, where this one keeps re-reading
-// whatever is missing.  Compiled only with -DMM_LB_CHUNKED (A/B through MM_JIT_DEFS); the pipelined
-// kernel (mm_fused_pipe.h), whose look-backs run half a walk late, uses the same scheme.
+// whatever is missing.  Compiled only with -DMM_LB_CHUNKED (A/B through MM_JIT_DEFS).
 constexpr uint32_t kLbChunk = 1024;
 constexpr unsigned long long kLbBaseValid = 1ull << 63;
 #ifndef MM_LB_POLL_SLEEP
@@ -866,16 +831,16 @@ template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool READS>
 // (small W: at least 4 waves per SIMD, i.e. at most 128 VGPRs - the two-body walks sit right at that
 // limit; larger W need more registers and get no such bound)
 // Workgroups per CU the register allocation is bounded for.  Small W: 4 (128 VGPRs; the lists allow
-// 4 workgroups per CU).  Canonical walks keep two rings of W registers: unbounded they take 134-138
-// VGPRs for W = 19..31 (3 waves per SIMD) and 190-230 for W = 33..47 (2 waves per SIMD); bounding
-// them to 128 / 168 VGPRs costs a few spilled registers outside the main loop and wins a wave per
-// SIMD (measured on 1 Gbp, tools/gpu_w19.py: W = 19..29: -2..4 %, W = 33..47: -7..19 %; W >= 49
-// spill too much for a third wave; w = 48..64 are bounded to 256 registers, which they need anyway
-// for two waves per SIMD - unbounded the scheduler may take more; the forward walks stay unbounded,
-// they gain nothing).
+// 4 workgroups per CU).  Canonical walks keep two rings of W registers; with the short look-ahead (PF
+// above) they fit 128 VGPRs up to w = 37 (4 waves per SIMD), 168 up to w = 54 (3 waves) and 256 up to
+// w = 64 with a handful of spills outside - or a few per W-block inside - the main loop (w = 51 at
+// 168 VGPRs: 8 scratch operations per 51-window block).  Measured on 3.1 Gbp (tools/gpu_jit_w.py,
+// round 2): the next tighter bound loses everywhere (w = 39 at 128: 1207 against 1687 Gbases/s at 168;
+// w = 55 at 168: 1270 against 1449 at 256; w = 100 bounded to 256: 519 against 784 unbounded).  Forward
+// walks and the reads-mode kernels gain nothing from bounds and stay unbounded.
 #ifndef MM_MIN_BLOCKS
 #define MM_MIN_BLOCKS \
-    (W <= 12 ? 4 : (CANON && !READS ? (W >= 19 && W <= 31 ? 4 : (W >= 32 && W <= 47 ? 3 : (W >= 48 && W <= 64 ? 2 : 1))) : 1))
+    (W <= 12 ? 4 : (CANON && !READS ? (W >= 19 && W <= 37 ? 4 : (W >= 38 && W <= 54 ? 3 : (W >= 55 && W <= 64 ? 2 : 1))) : 1))
 #endif
 __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // lane lists
@@ -990,7 +955,6 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     ctx.list_bytes = p.list_cap * kListStride;
     ctx.dst = 0;
     ctx.nblk = p.nblk;
-    ctx.hook_block = 0;
     ctx.seq_d = seq_d;
     ctx.seq_dwords = seq_dwords;
     bool lane_active = false;

@@ -1,7 +1,6 @@
 // mm_fused_inst.h — table entry describing one specialisation of the fused kernel.
 #pragma once
 #include "mm_fused_impl.h"
-#include "mm_fused_pipe.h"
 
 namespace mm {
 
@@ -31,26 +30,6 @@ const FusedInstance *fused_instances_f(int *count);
 const FusedInstance *fused_instances_g(int *count);
 const FusedInstance *fused_instances_h(int *count);
 const FusedInstance *fused_instances_i(int *count);
-
-// pipelined kernel (mm_fused_pipe.h), mm_pipe_inst_*.hip: minimizers, closed syncmers, open syncmers
-struct PipeInstance {
-    uint32_t w;
-    bool canon;
-    bool hash_rc;
-    FusedKernelFn fn[3];
-};
-#define MM_PIPE_INST(W, C, R)                                                                     \
-    {                                                                                             \
-        W, C, R, { &fused_pipe_kernel<W, C, R, 0>, &fused_pipe_kernel<W, C, R, 1>, &fused_pipe_kernel<W, C, R, 2> } \
-    }
-const PipeInstance *pipe_instances_a(int *count);
-const PipeInstance *pipe_instances_b(int *count);
-const PipeInstance *pipe_instances_c(int *count);
-const PipeInstance *pipe_instances_d(int *count);
-const PipeInstance *pipe_instances_e(int *count);
-const PipeInstance *pipe_instances_f(int *count);
-const PipeInstance *pipe_instances_g(int *count);
-const PipeInstance *pipe_instances_h(int *count);
 
 // reads-mode instances (minimizers only), mm_fused_inst_reads_*.hip
 struct FusedReadsInstance {

@@ -42,6 +42,9 @@ bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_c
 uint64_t fused_status_words(const RunArgs &a);
 // windows per tile for this plan / output flavour (what a batch's tile table is built from)
 uint32_t fused_tile_windows(const RunArgs &a);
+// blocks per lane that make a batch fill whole rounds of resident workgroups (0 = keep the default);
+// the caller puts it into RunArgs::nblk before building the tile table
+uint32_t fused_batch_nblk(const RunArgs &a, const uint64_t *n_windows, uint64_t n_seqs);
 // returns 0, -1 (HIP failure) or -2 (no kernel for this plan: take the generic family;
 // fused_unavailable_reason() says why)
 int launch_fused(const RunArgs &a, hipStream_t stream);
