@@ -167,29 +167,39 @@ def kernel_source_sha():
 
 def recorded_counters(kernel_ms):
     """HBM traffic and SQ counters cannot be collected from inside this process: rocprofv3 gathers them
-    in separate passes around the same command (tools/prof_head.sh), and the condensed result is
+    in separate passes around the same command (tools/prof_head.py), and the condensed result is
     committed as profiles/head_counters.json together with the hash of the kernel source it was
-    measured on.  Returns (traffic_bytes_per_launch or None, valu dict or None, provenance text)."""
-    path = os.path.join(ROOT, "profiles", "head_counters.json")
+    measured on; the static instruction census of the kernel's main loop (tools/isa_census.py, hipcc -S
+    on the build box) is profiles/head_isa_census.json.  Returns (traffic_bytes_per_launch or None,
+    valu dict or None, provenance text).
+
+    roofline.valu - the bound that actually binds: VALU-pipe time of one launch / kernel time, where
+    VALU-pipe time = (wave-instructions issued, PMC SQ_INSTS_VALU) x (issue clocks per instruction, from
+    the census of the main loop at the issue rates measured on MI355X) / (1024 SIMDs x shader clock, PMC
+    GRBM_GUI_ACTIVE / kernel time of the counter pass)."""
+    sha = kernel_source_sha()
     try:
-        c = json.load(open(path))
+        c = json.load(open(os.path.join(ROOT, "profiles", "head_counters.json")))
     except Exception:
         return None, None, "no profiles/head_counters.json"
-    stale = c.get("kernel_source_sha") != kernel_source_sha()
+    stale = c.get("kernel_source_sha") != sha
     traffic = c.get("hbm_bytes_per_launch")
     valu = None
     try:
+        isa = json.load(open(os.path.join(ROOT, "profiles", "head_isa_census.json")))
         insts = float(c["SQ_INSTS_VALU"])
         windows = float(c["windows_per_launch"])
-        thread_cyc = float(c["SQ_THREAD_CYCLES_VALU"])
         sclk_hz = float(c["GRBM_GUI_ACTIVE_per_xcd"]) / (float(c["counter_pass_kernel_us"]) * 1e-6)
-        issue_clk = thread_cyc / (64.0 * insts)            # SIMD clocks one VALU wave-instruction occupies
-        per_window = insts * 64.0 / windows                # wave-instructions per 64 windows = per lane-window
-        # VALU-pipe time of one launch against the measured kernel time of THIS run
-        busy = insts * issue_clk / (N_SIMD * sclk_hz)
-        valu = {"insts_per_window": round(per_window, 2), "issue_clk": round(issue_clk, 2),
-                "frac": round(busy / (kernel_ms * 1e-3), 4), "sclk_mhz": round(sclk_hz / 1e6, 0),
-                "source": "recorded (profiles/head_counters.json), kernel time live" + ("; STALE: kernel source changed since" if stale else "")}
+        issue_clk = float(isa["issue_clk_per_valu"])
+        busy = insts * issue_clk / (N_SIMD * sclk_hz)  # seconds of VALU-pipe time per launch
+        valu = {"insts_per_window": round(insts * 64.0 / windows, 2),
+                "main_loop_insts_per_window": isa["valu_per_window"],
+                "issue_clk": round(issue_clk, 3), "sclk_mhz": round(sclk_hz / 1e6, 0),
+                "frac": round(busy / (kernel_ms * 1e-3), 4),
+                "source": "SQ_INSTS_VALU and shader clock recorded (profiles/head_counters.json), issue clocks per "
+                          "instruction from the main loop's census (profiles/head_isa_census.json), kernel time live"
+                          + ("; STALE counters: kernel source changed since" if stale else "")
+                          + ("; STALE census" if isa.get("kernel_source_sha") != sha else "")}
     except Exception:
         pass
     prov = ("recorded by rocprofv3 PMC passes (profiles/head_counters.json: " + c.get("collected", "?") + ")"

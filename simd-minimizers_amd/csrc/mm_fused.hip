@@ -163,6 +163,8 @@ int launch_kernel(const KernelRef &kr, uint32_t grid, uint32_t lds_bytes, hipStr
         if (ev1) hipEventRecord(ev1, stream);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
+    // (module functions: the runtime takes the dynamic LDS size from the launch; the attribute call is a
+    // hint that some runtimes reject for a hipFunction_t - its result does not matter)
     if (lds_bytes > 64u * 1024u)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kr.mod),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -172,7 +174,14 @@ int launch_kernel(const KernelRef &kr, uint32_t grid, uint32_t lds_bytes, hipStr
     const hipError_t e = hipModuleLaunchKernel(kr.mod, grid, 1, 1, kFusedThreads, 1, 1, lds_bytes, stream, args,
                                                nullptr);
     if (ev1) hipEventRecord(ev1, stream);
-    return e == hipSuccess ? 0 : -1;
+    if (e != hipSuccess) {
+        // a launch the runtime rejects (too much dynamic LDS for a module function) is not a failed
+        // run: the caller takes the generic family
+        (void)hipGetLastError();
+        t_jit_error = std::string("launch of the run-time specialised kernel rejected: ") + hipGetErrorString(e);
+        return -2;
+    }
+    return 0;
 }
 
 }  // namespace

@@ -212,7 +212,11 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // hash of element 0: k add-only steps, 16 bases per view word, two bases per look-up
     // (s_tab[20 + ((second << 2) | first)]), a last odd base through the one-base table
     const uint32_t rot2_l = (32u - 2u * p.ht.rot) & 31u, rot2_r = (2u * p.ht.rot) & 31u;
+#ifdef MM_EXP_NOWARM  // timing experiment (wrong results): what the hash warm-up of a lane costs
+    for (uint32_t g = 0; g * 16u < 0u; ++g) {
+#else
     for (uint32_t g = 0; g * 16u < k; ++g) {
+#endif
         const uint32_t wa = g == 0 ? view_first(pb) : view(pb + 16 * (int32_t)g);
         const uint32_t rem = k - 16u * g;
 #pragma unroll
@@ -326,7 +330,11 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     if (CANON) {
         // window -1 covers bases [pb, pb + l)
         uint32_t c = 0;
+#ifdef MM_EXP_NOWARM
+        for (uint32_t g = 0; g * 16u < 0u; ++g) {
+#else
         for (uint32_t g = 0; g * 16u < l; ++g) {
+#endif
             uint32_t wd = (g == 0 ? view_first(pb) : view(pb + 16 * (int32_t)g)) & 0xAAAAAAAAu;
             const uint32_t rem = l - 16u * g;
             if (rem < 16u) wd &= (1u << (2u * rem)) - 1u;

@@ -73,9 +73,20 @@ bool read_file(const std::string &path, std::vector<char> &out) {
     return ok;
 }
 
+// The cache holds code this process will load and run: the directory is private to the user (0700)
+// and an entry is only trusted if it is a regular file owned by this user that nobody else can write.
+bool trusted_file(const std::string &path) {
+    struct stat st;
+    if (lstat(path.c_str(), &st) != 0) return false;
+    return S_ISREG(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+
 void write_file_atomic(const std::string &dir, const std::string &path, const std::vector<char> &data) {
     mkdir(dir.substr(0, dir.find_last_of('/')).c_str(), 0755);
-    mkdir(dir.c_str(), 0755);
+    mkdir(dir.c_str(), 0700);
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid()) return;  // not ours: no cache
+    if (st.st_mode & (S_IWGRP | S_IWOTH)) chmod(dir.c_str(), 0700);
     const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return;
@@ -87,6 +98,17 @@ void write_file_atomic(const std::string &dir, const std::string &path, const st
 std::mutex g_mu;
 std::map<std::string, hipFunction_t> g_functions;  // "<device>:<kernel name>"
 std::map<std::string, std::string> g_failed;       // kernel name -> why (do not retry)
+
+// "gfx950" of the current device's gcnArchName ("gfx950:sramecc+:xnack-")
+std::string device_arch() {
+    int device = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) return "gfx950";
+    std::string a = prop.gcnArchName;
+    const size_t colon = a.find(':');
+    if (colon != std::string::npos) a.resize(colon);
+    return a.empty() ? std::string("gfx950") : a;
+}
 
 bool compile(const std::string &name, std::vector<char> &code, std::string &lowered, std::string *err) {
     hiprtcProgram prog = nullptr;
@@ -110,7 +132,8 @@ bool compile(const std::string &name, std::vector<char> &code, std::string &lowe
             }
         }
     }
-    std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", threads.c_str()};
+    const std::string arch = "--offload-arch=" + device_arch();
+    std::vector<const char *> opts = {arch.c_str(), "-O3", "-std=c++17", threads.c_str()};
     for (const std::string &e : extra) opts.push_back(e.c_str());
     const hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     if (r != HIPRTC_SUCCESS) {
@@ -179,7 +202,7 @@ hipFunction_t jit_fused_kernel(uint32_t w, bool canon, bool hash_rc, int mode, b
     // disk cache: <hash of source, name, compiler>.hsaco + .name (the lowered symbol)
     int rtc_major = 0, rtc_minor = 0;
     hiprtcVersion(&rtc_major, &rtc_minor);
-    const uint64_t h = fnv1a(name + "|" + (defs ? defs : "") + "|gfx950|" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
+    const uint64_t h = fnv1a(name + "|" + (defs ? defs : "") + "|" + device_arch() + "|" + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
                              "|" + std::to_string(kFusedThreads), fnv1a(kernel_source()));
     char hex[32];
     snprintf(hex, sizeof hex, "%016llx", (unsigned long long)h);
@@ -188,7 +211,8 @@ hipFunction_t jit_fused_kernel(uint32_t w, bool canon, bool hash_rc, int mode, b
     std::vector<char> code, lowered_buf;
     std::string lowered;
     bool from_disk = false;
-    if (!path.empty() && read_file(path, code) && read_file(path + ".name", lowered_buf)) {
+    if (!path.empty() && trusted_file(path) && trusted_file(path + ".name") && read_file(path, code) &&
+        read_file(path + ".name", lowered_buf)) {
         lowered.assign(lowered_buf.begin(), lowered_buf.end());
         from_disk = true;
     }

@@ -85,7 +85,7 @@ def test_run_with_buf_and_pos_and_values(sm, oracle, gpu):
         if k <= 32:
             p64, v64 = out.pos_and_values_u64()
             assert [int(p) for p in p64] == c and [int(v) for v in v64] == vals
-    ascii_seq = (b"ACGTTGCANGT" * 300)[:3000]
+    ascii_seq = (b"ACGTTGCAGGTTACCAGTNACGGATCCAT" * 120)[:3000]  # an N every 29 bases, windows of 11
     ns = sm.PackedNSeqVec.from_ascii(ascii_seq)
     x, y = [], []
     sm.canonical_minimizers(7, 5).run_skip_ambiguous_windows(ns, x)

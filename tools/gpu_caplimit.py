@@ -16,7 +16,7 @@ def t(b, warm=10, reps=12):
     return ms / l
 for kw in sys.argv[1].split(","):
     k, w = map(int, kw.split(":"))
-    b = sm.canonical_minimizers(k, w)
+    b = sm.Builder(k, w, os.environ.get("FWD") != "1", 0)
     res = []
     for lim in sys.argv[2:]:
         if lim == "0": os.environ.pop("MM_CAP_LIMIT", None)

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Static census of the dominant kernel's main loop (runs on the build box, no GPU): compiles
+mm::fused_kernel<W, CANON, ...> to gfx950 assembly with hipcc -S, finds the W-block loop of the plain
+walk (fast emit, no range / ambiguity checks) and counts its VALU instructions by issue rate
+(full / half rate as measured on MI355X, profiles/r01_valu_issue_rates.txt: 2.5 / 4.3 clocks per wave64
+instruction; any SGPR source operand makes an instruction half rate).  Writes profiles/head_isa_census.json,
+which bench.py reads for roofline.valu.issue_clk.  usage: isa_census.py [W] [canon 0|1]"""
+import collections
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from isa_loops import classify  # noqa: E402
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 11
+CANON = (sys.argv[2] != "0") if len(sys.argv) > 2 else True
+csrc = os.path.join(ROOT, "simd-minimizers_amd", "csrc")
+tmp = tempfile.mkdtemp(prefix="mm_census_")
+src = os.path.join(tmp, "k.hip")
+c = "true" if CANON else "false"
+open(src, "w").write('#include "mm_fused_impl.h"\n'
+                     f"template __global__ void mm::fused_kernel<{W}, {c}, {c}, 0, false, false>(const mm::FusedParams);\n")
+asm = os.path.join(tmp, "k.s")
+subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + csrc, "-S",
+                "--cuda-device-only", "-o", asm, src], check=True, stderr=subprocess.DEVNULL)
+lines = open(asm).read().split("\n")
+labels, insts = {}, []
+for ln in lines:
+    s = ln.strip()
+    m = re.match(r"^(\.LBB\d+_\d+):", s)
+    if m:
+        labels[m.group(1)] = len(insts)
+        continue
+    if not s or s.startswith((".", ";", "//")) or s.endswith(":"):
+        continue
+    s = s.split(";")[0].strip()
+    if s:
+        insts.append(s)
+best = None
+for i, s in enumerate(insts):
+    m = re.match(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", s)
+    if not m or m.group(1) not in labels or labels[m.group(1)] > i:
+        continue
+    body = insts[labels[m.group(1)]:i + 1]
+    ops = collections.Counter(b.split()[0] for b in body)
+    if ops["v_cmp_ne_u32_sdwa"] != W or ops["s_and_saveexec_b64"] != W or ops["ds_write_b16"] != W:
+        continue
+    if sum(v for o, v in ops.items() if o.startswith("ds_read")) != W or not any(o.startswith("buffer_load") for o in ops):
+        continue  # (the block loop proper: W table look-ups, W list appends, the sequence loads of a later block)
+    if any(o.startswith(("v_cmp_lt_i32", "buffer_store", "global_store")) for o in ops):
+        continue  # range-checked or direct-store walks
+    if best is None or len(body) < len(best):
+        best = body
+assert best, "main loop not found"
+cls = collections.Counter(classify(b.split()[0], b) for b in best)
+meta = {}
+for ln in lines:
+    for key in (".vgpr_count:", ".sgpr_count:", ".vgpr_spill_count:"):
+        if key in ln:
+            meta[key.strip(".:")] = int(ln.split(":")[1])
+h = hashlib.sha256()
+for f in ("mm_fused_impl.h", "mm_common.h"):
+    h.update(open(os.path.join(csrc, f), "rb").read())
+full, half = cls["valu_full"], cls["valu_half"]
+rec = {"kernel": f"mm::fused_kernel<{W}, {c}, {c}, 0, false, false>", "kernel_source_sha": h.hexdigest()[:16],
+       "main_loop_windows": W, "main_loop_instructions": len(best), "valu_full_rate": full, "valu_half_rate": half,
+       "salu": cls["salu"], "lds": cls["lds"], "vmem": cls["vmem"],
+       "valu_per_window": round((full + half) / W, 2),
+       "issue_clk_per_valu": round((2.5 * full + 4.3 * half) / (full + half), 3),
+       "issue_clk_per_window": round((2.5 * full + 4.3 * half) / W, 1),
+       "rates": "2.5 / 4.3 clocks per full- / half-rate wave64 VALU instruction (profiles/r01_valu_issue_rates.txt)",
+       **meta}
+out = os.path.join(ROOT, "profiles", "head_isa_census.json" if (W, CANON) == (11, True) else f"isa_census_w{W}_{'canon' if CANON else 'fwd'}.json")
+json.dump(rec, open(out, "w"), indent=1)
+print(json.dumps(rec))
