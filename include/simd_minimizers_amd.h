@@ -25,17 +25,25 @@ extern "C" {
 
 /* ------------------------------------------------------------------ types */
 
-/* seq-hash NtHasher<CANONICAL> (call sites src/minimizers.rs:24,44,61,85,143; src/lib.rs:391).
- *   h_fw(i) = XOR_j rotl(fw[s[i+j]], rot*(k-1-j));  h_rc(i) = XOR_j rotl(rc[s[i+j]], rot*j)
+/* seq-hash KmerHasher as data (call sites src/minimizers.rs:24,44,61,85,143; src/lib.rs:391).
+ *   h_fw(i) = fw_xor ^ XOR_j rotl(fw[s[i+j]], rot*(k-1-j));  h_rc(i) = rc_xor ^ XOR_j rotl(rc[s[i+j]], rot*j)
  *   h = canonical ? h_fw + h_rc (wrapping) : h_fw
- * The tables cross the ABI as data, so a seeded hasher (`new_with_seed`, src/lib.rs:157)
- * is a parameter and not a rebuild. */
+ * The tables cross the ABI as data, so a seeded hasher (`new_with_seed`, src/lib.rs:157) or another
+ * hasher of this rolling rot-xor form is a parameter and not a rebuild.  fw_xor / rc_xor are constants
+ * XORed onto the strand hashes (0 for NtHasher; folded into the kernels' tables, no cost per base);
+ * `kind` says which seq-hash type the tables stand for (informational: the kernels only see the
+ * tables). */
 typedef struct mm_hasher {
     uint32_t fw[4];
     uint32_t rc[4];
     uint32_t rot;
     uint32_t canonical;
+    uint32_t fw_xor;
+    uint32_t rc_xor;
+    uint32_t kind; /* mm_hasher_kind_t */
 } mm_hasher_t;
+
+typedef enum mm_hasher_kind { MM_HASHER_NT = 0, MM_HASHER_MUL = 1, MM_HASHER_ANTILEX = 2 } mm_hasher_kind_t;
 
 /* Builder<_, _, _, SYNCMER> (src/lib.rs:221-225): 0 minimizers, 1 closed, 2 open syncmers */
 typedef enum mm_mode { MM_MINIMIZERS = 0, MM_CLOSED_SYNCMERS = 1, MM_OPEN_SYNCMERS = 2 } mm_mode_t;
@@ -77,6 +85,15 @@ int mm_device_count(void);
 
 /* NtHasher::<CANONICAL>::new(k) (seq-hash 0.2.0; src/lib.rs:391). */
 int mm_default_hasher(mm_hasher_t *out, int canonical);
+/* MulHasher::<CANONICAL>::new(k) and AntiLexHasher::<CANONICAL>::new(k) (seq-hash 0.2.0; src/lib.rs:71-72,
+ * exercised by src/test.rs:81-83,107-109).  PARITY UNPINNED: their arithmetic is not in the reference
+ * tree and the reference holds no known-answer vector for them, so these fill the tables with this
+ * engine's restatement of the published idea - mulHash: the character value times a pseudo-random
+ * constant in NtHasher's rolling form; anti-lex: the k-mer's own base-4 value with the first base
+ * inverted - and a caller who has the real crate puts ITS per-base values into mm_hasher_t instead.
+ * Everything downstream (windows, ties, strand vote, collectors) is the pinned path. */
+int mm_mul_hasher(mm_hasher_t *out, int canonical);
+int mm_antilex_hasher(mm_hasher_t *out, uint32_t k, int canonical);
 
 /* ------------------------------------------------------------------- plan */
 

@@ -58,6 +58,23 @@ struct NtHasher {
     explicit NtHasher(uint32_t k_) : k(k_) { check(mm_default_hasher(&tables, CANONICAL)); }
     bool is_canonical() const { return CANONICAL; }
 };
+// seq-hash MulHasher<CANONICAL>::new(k) / AntiLexHasher<CANONICAL>::new(k) (src/lib.rs:71-72; src/test.rs:81-83,
+// 107-109).  PARITY UNPINNED: their arithmetic is not in the reference tree (see mm_mul_hasher /
+// mm_antilex_hasher in the C header); a caller who knows the real per-base values fills `tables` itself.
+template <bool CANONICAL = true>
+struct MulHasher {
+    mm_hasher_t tables;
+    uint32_t k;
+    explicit MulHasher(uint32_t k_) : k(k_) { check(mm_mul_hasher(&tables, CANONICAL)); }
+    bool is_canonical() const { return CANONICAL; }
+};
+template <bool CANONICAL = true>
+struct AntiLexHasher {
+    mm_hasher_t tables;
+    uint32_t k;
+    explicit AntiLexHasher(uint32_t k_) : k(k_) { check(mm_antilex_hasher(&tables, k_, CANONICAL)); }
+    bool is_canonical() const { return CANONICAL; }
+};
 
 class Workspace {
   public:
@@ -121,8 +138,8 @@ template <bool CANONICAL, int SYNCMER>
 class Builder {  // src/lib.rs:225-230
   public:
     Builder(uint32_t k, uint32_t w) : k_(k), w_(w) {}
-    template <bool C>
-    Builder hasher(const NtHasher<C> &h) const {  // src/lib.rs:327
+    template <class H>
+    Builder hasher(const H &h) const {  // src/lib.rs:327 (any KmerHasher: NtHasher, MulHasher, AntiLexHasher)
         Builder b = *this;
         b.hasher_ = h.tables;
         b.has_hasher_ = true;

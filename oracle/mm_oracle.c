@@ -33,6 +33,42 @@ void mmo_default_hasher(mmo_hasher *h, int canonical) {
     }
     h->rot = 7;
     h->canonical = canonical ? 1u : 0u;
+    h->fw_xor = h->rc_xor = 0;
+    h->kind = 0;
+}
+
+/* PARITY UNPINNED (seq-hash MulHasher is not in the reference tree): character value (code + 1) times
+ * the 32-bit golden-ratio constant, one bit of rotation per base... the structure is the rolling
+ * rot-xor form of NtHasher with the table look-up replaced by a multiplication (src/lib.rs:71-72). */
+void mmo_mul_hasher(mmo_hasher *h, int canonical) {
+    for (uint32_t c = 0; c < 4; ++c) {
+        h->fw[c] = (c + 1u) * 0x9E3779B1u;
+        h->rc[c] = ((c ^ 2u) + 1u) * 0x9E3779B1u;
+    }
+    h->rot = 7;
+    h->canonical = canonical ? 1u : 0u;
+    h->fw_xor = h->rc_xor = 0;
+    h->kind = 1;
+}
+
+/* PARITY UNPINNED (seq-hash AntiLexHasher is not in the reference tree): h_fw = the k-mer read as a
+ * base-4 number, first base most significant, left-aligned in 32 bits (for k > 16 the older bases
+ * wrap around and overlap), with the FIRST base inverted - the anti-lexicographic order; h_rc = the
+ * same of the reverse complement. */
+void mmo_antilex_hasher(mmo_hasher *h, uint32_t k, int canonical) {
+    const uint32_t sh = (32u - ((2u * k) & 31u)) & 31u; /* base j of the k-mer lands at bits 2(k-1-j) + sh */
+    for (uint32_t c = 0; c < 4; ++c) {
+        h->fw[c] = rotl32(c, sh);
+        /* reverse complement: base j of the window is base k-1-j of the rc k-mer, i.e. rotation 2j + sh */
+        h->rc[c] = rotl32(c ^ 2u, sh);
+    }
+    h->rot = 2;
+    h->canonical = canonical ? 1u : 0u;
+    /* the first base of the forward k-mer sits at rotation 2(k-1) + sh = bits 30..31 (mod 32), and so
+     * does the first base of the reverse-complement k-mer (window base k-1, rotation 2(k-1) + sh) */
+    h->fw_xor = 3u << 30;
+    h->rc_xor = 3u << 30;
+    h->kind = 2;
 }
 
 void mmo_pack_ascii(const uint8_t *ascii, uint64_t n, uint8_t *packed) {
@@ -84,6 +120,8 @@ int64_t mmo_hash_kmers_naive(const uint8_t *packed, uint64_t off, uint64_t n, ui
             fw ^= rotl32(h->fw[c], h->rot * (k - 1 - j));
             rc ^= rotl32(h->rc[c], h->rot * j);
         }
+        fw ^= h->fw_xor;
+        rc ^= h->rc_xor;
         out[i] = h->canonical ? fw + rc : fw;
     }
     return (int64_t)nk;
@@ -116,7 +154,8 @@ static inline void roll_step(roll_state *st, uint32_t in, uint32_t out) {
     st->rc = rotr32(st->rc ^ st->h->rc[out], st->h->rot) ^ st->rc_in[in];
 }
 static inline uint32_t roll_value(const roll_state *st) {
-    return st->h->canonical ? st->fw + st->rc : st->fw;
+    const uint32_t fw = st->fw ^ st->h->fw_xor, rc = st->rc ^ st->h->rc_xor;
+    return st->h->canonical ? fw + rc : fw;
 }
 
 int64_t mmo_hash_kmers_rolling(const uint8_t *packed, uint64_t off, uint64_t n, uint32_t k,
@@ -729,7 +768,8 @@ static int avx2_range(const fast_job *jb, uint64_t vb, uint64_t per8, fast_seg *
             rc = _mm256_xor_si256(vrotl(_mm256_xor_si256(rc, _mm256_permutevar8x32_epi32(T_rc, out)), 32u - (rot & 31u)),
                                   _mm256_permutevar8x32_epi32(T_rcin, in));
         }
-        const __m256i val = hash_rc ? _mm256_add_epi32(fw, rc) : fw;
+        const __m256i fwx = _mm256_xor_si256(fw, _mm256_set1_epi32((int)h->fw_xor));
+        const __m256i val = hash_rc ? _mm256_add_epi32(fwx, _mm256_xor_si256(rc, _mm256_set1_epi32((int)h->rc_xor))) : fwx;
         /* two-stacks minimum, same steps as lrmin_push */
         if (pos == 0xffffu) {
             const uint32_t delta = (1u << 16) - 2u - w;

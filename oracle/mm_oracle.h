@@ -29,15 +29,22 @@ extern "C" {
 
 /* ntHash-style k-mer hasher (seq-hash 0.2.0 NtHasher<CANONICAL>, not in tree;
  * call sites src/minimizers.rs:24,44,61,85,143; src/lib.rs:391).
- *   h_fw(i) = XOR_j rotl(fw[s[i+j]], rot*(k-1-j))
- *   h_rc(i) = XOR_j rotl(rc[s[i+j]], rot*j)
+ *   h_fw(i) = fw_xor ^ XOR_j rotl(fw[s[i+j]], rot*(k-1-j))
+ *   h_rc(i) = rc_xor ^ XOR_j rotl(rc[s[i+j]], rot*j)
  *   h       = canonical ? h_fw + h_rc (wrapping) : h_fw
- * Tables are data so that a seeded hasher is a parameter, not a rebuild. */
+ * Tables are data so that a seeded hasher is a parameter, not a rebuild; fw_xor / rc_xor (0 for
+ * NtHasher) let the same form carry the alternative hashers of seq-hash (MulHasher, AntiLexHasher:
+ * src/lib.rs:71-72, src/test.rs:81-83,107-109), whose arithmetic is NOT in the reference tree and has
+ * no known-answer vector: PARITY UNPINNED - mmo_mul_hasher / mmo_antilex_hasher restate the published
+ * idea with this repo's own constants. */
 typedef struct mmo_hasher {
     uint32_t fw[4];
     uint32_t rc[4];
     uint32_t rot;
     uint32_t canonical;
+    uint32_t fw_xor;
+    uint32_t rc_xor;
+    uint32_t kind; /* 0 NtHasher, 1 MulHasher, 2 AntiLexHasher (informational) */
 } mmo_hasher;
 
 enum { MMO_MINIMIZERS = 0, MMO_CLOSED_SYNCMERS = 1, MMO_OPEN_SYNCMERS = 2 };
@@ -59,6 +66,12 @@ enum {
 
 /* Default NtHasher tables ("model M"). */
 void mmo_default_hasher(mmo_hasher *h, int canonical);
+/* MulHasher<CANONICAL>::new(k): "multiplies each character value by a pseudo-random constant"
+ * (src/lib.rs:71-72).  PARITY UNPINNED: the constant and the character offset are this repo's. */
+void mmo_mul_hasher(mmo_hasher *h, int canonical);
+/* AntiLexHasher<CANONICAL>::new(k): the k-mer's own 2-bit value, first base most significant and
+ * inverted (anti-lexicographic order), left-aligned in 32 bits.  PARITY UNPINNED. */
+void mmo_antilex_hasher(mmo_hasher *h, uint32_t k, int canonical);
 
 /* packed-seq layout: 4 bases/byte, base i at bits 2(i%4) of byte i/4; codes A0 C1 T2 G3 */
 static inline uint32_t mmo_base(const uint8_t *packed, uint64_t i) {

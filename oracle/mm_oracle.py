@@ -19,7 +19,7 @@ NAIVE, STREAMING = 0, 1
 
 class Hasher(C.Structure):
     _fields_ = [("fw", C.c_uint32 * 4), ("rc", C.c_uint32 * 4), ("rot", C.c_uint32),
-                ("canonical", C.c_uint32)]
+                ("canonical", C.c_uint32), ("fw_xor", C.c_uint32), ("rc_xor", C.c_uint32), ("kind", C.c_uint32)]
 
 
 def build(native: bool = False, out_dir: str | None = None) -> str:
@@ -38,6 +38,10 @@ def _bind(lib):
     hp = C.POINTER(Hasher)
     lib.mmo_default_hasher.argtypes = [hp, C.c_int]
     lib.mmo_default_hasher.restype = None
+    lib.mmo_mul_hasher.argtypes = [hp, C.c_int]
+    lib.mmo_mul_hasher.restype = None
+    lib.mmo_antilex_hasher.argtypes = [hp, C.c_uint32, C.c_int]
+    lib.mmo_antilex_hasher.restype = None
     lib.mmo_pack_ascii.argtypes = [u8p, C.c_uint64, u8p]
     lib.mmo_pack_ascii.restype = None
     lib.mmo_revcomp_packed.argtypes = [u8p, C.c_uint64, C.c_uint64, u8p]
@@ -107,6 +111,20 @@ def _p(a, t):
 def default_hasher(canonical: bool) -> Hasher:
     h = Hasher()
     lib().mmo_default_hasher(C.byref(h), int(canonical))
+    return h
+
+
+def mul_hasher(canonical: bool) -> Hasher:
+    """seq-hash MulHasher restated (PARITY UNPINNED, see mm_oracle.h)."""
+    h = Hasher()
+    lib().mmo_mul_hasher(C.byref(h), int(canonical))
+    return h
+
+
+def antilex_hasher(k: int, canonical: bool) -> Hasher:
+    """seq-hash AntiLexHasher restated (PARITY UNPINNED, see mm_oracle.h)."""
+    h = Hasher()
+    lib().mmo_antilex_hasher(C.byref(h), k, int(canonical))
     return h
 
 

@@ -37,7 +37,7 @@ class MinimizerError(RuntimeError):
 class Hasher(C.Structure):
     """seq-hash NtHasher tables (see include/simd_minimizers_amd.h: mm_hasher_t)."""
     _fields_ = [("fw", C.c_uint32 * 4), ("rc", C.c_uint32 * 4), ("rot", C.c_uint32),
-                ("canonical", C.c_uint32)]
+                ("canonical", C.c_uint32), ("fw_xor", C.c_uint32), ("rc_xor", C.c_uint32), ("kind", C.c_uint32)]
 
     @staticmethod
     def from_tables(fw, rc, rot=7, canonical=True) -> "Hasher":
@@ -47,6 +47,7 @@ class Hasher(C.Structure):
             h.rc[i] = int(rc[i]) & 0xFFFFFFFF
         h.rot = rot
         h.canonical = 1 if canonical else 0
+        h.fw_xor = h.rc_xor = h.kind = 0
         return h
 
     def is_canonical(self) -> bool:
@@ -77,6 +78,8 @@ def lib():
         L.mm_last_error.restype = C.c_char_p
         L.mm_device_count.restype = C.c_int
         L.mm_default_hasher.argtypes = [C.POINTER(Hasher), C.c_int]
+        L.mm_mul_hasher.argtypes = [C.POINTER(Hasher), C.c_int]
+        L.mm_antilex_hasher.argtypes = [C.POINTER(Hasher), C.c_uint32, C.c_int]
         L.mm_plan_create.argtypes = [C.POINTER(vp), C.c_uint32, C.c_uint32, C.c_int, C.c_int,
                                      C.POINTER(Hasher)]
         L.mm_plan_destroy.argtypes = [vp]
@@ -139,7 +142,8 @@ def lib():
 
 
 EXPORTED_SYMBOLS = [
-    "mm_strerror", "mm_last_error", "mm_device_count", "mm_default_hasher", "mm_plan_create",
+    "mm_strerror", "mm_last_error", "mm_device_count", "mm_default_hasher", "mm_mul_hasher", "mm_antilex_hasher",
+    "mm_plan_create",
     "mm_plan_destroy", "mm_plan_value_len", "mm_workspace_create", "mm_workspace_destroy",
     "mm_workspace_sync", "mm_workspace_check", "mm_workspace_force_generic", "mm_workspace_set_blocks_per_lane",
     "mm_workspace_enable_timing", "mm_workspace_kernel_time", "mm_workspace_last_path",
@@ -340,6 +344,22 @@ def NtHasher(k: int | None = None, canonical: bool = True) -> Hasher:
     """seq-hash ``NtHasher::<CANONICAL>::new(k)`` (k only rotates tables inside the plan)."""
     h = Hasher()
     _check(lib().mm_default_hasher(C.byref(h), int(canonical)))
+    return h
+
+
+def MulHasher(k: int | None = None, canonical: bool = True) -> Hasher:
+    """seq-hash ``MulHasher::<CANONICAL>::new(k)`` (src/lib.rs:71-72).  PARITY UNPINNED: this engine's
+    restatement of the published idea (see mm_mul_hasher in the C header); plug the real per-base values
+    in through ``Hasher.from_tables`` where they are known."""
+    h = Hasher()
+    _check(lib().mm_mul_hasher(C.byref(h), int(canonical)))
+    return h
+
+
+def AntiLexHasher(k: int, canonical: bool = True) -> Hasher:
+    """seq-hash ``AntiLexHasher::<CANONICAL>::new(k)`` (src/test.rs:83,109).  PARITY UNPINNED."""
+    h = Hasher()
+    _check(lib().mm_antilex_hasher(C.byref(h), k, int(canonical)))
     return h
 
 

@@ -65,6 +65,22 @@ mm::HashTables make_tables(const mm_hasher_t &h, uint32_t k) {
             t.t_in2[(b << 2) | a].x = rotl32(t.t_in[a].x, R) ^ t.t_in[b].x;
             t.t_in2[(b << 2) | a].y = rotr32(t.t_in[a].y, R) ^ t.t_in[b].y;
         }
+    // constant XOR terms of the hasher (0 for NtHasher): with g = state ^ C, one step maps
+    // g -> rot(g) ^ T ^ rot(C) ^ C, so every table entry carries D = rot(C) ^ C (two-step entries
+    // rot(D) ^ D) and the walk starts from C instead of 0 - nothing to do per base
+    const uint32_t df = rotl32(h.fw_xor, R) ^ h.fw_xor, dr = rotr32(h.rc_xor, R) ^ h.rc_xor;
+    for (int i = 0; i < 16; ++i) {
+        t.t_in_out[i].x ^= df;
+        t.t_in_out[i].y ^= dr;
+        t.t_in2[i].x ^= rotl32(df, R) ^ df;
+        t.t_in2[i].y ^= rotr32(dr, R) ^ dr;
+    }
+    for (int i = 0; i < 4; ++i) {
+        t.t_in[i].x ^= df;
+        t.t_in[i].y ^= dr;
+    }
+    t.fw0 = h.fw_xor;
+    t.rc0 = h.rc_xor;
     t.rot = R;
     t.canonical = h.canonical ? 1u : 0u;
     return t;
@@ -245,6 +261,41 @@ int mm_default_hasher(mm_hasher_t *out, int canonical) {
     }
     out->rot = 7;
     out->canonical = canonical ? 1u : 0u;
+    out->fw_xor = out->rc_xor = 0;
+    out->kind = MM_HASHER_NT;
+    return MM_OK;
+}
+
+// PARITY UNPINNED (seq-hash 0.2.0 is not in the reference tree; no known-answer vector exists): the
+// published idea - "multiplies each character value by a pseudo-random constant" (src/lib.rs:71-72) -
+// in NtHasher's rolling rot-xor form; constant and character offset are this engine's.
+int mm_mul_hasher(mm_hasher_t *out, int canonical) {
+    if (!out) return MM_ERR_NULL;
+    for (uint32_t c = 0; c < 4; ++c) {
+        out->fw[c] = (c + 1u) * 0x9E3779B1u;
+        out->rc[c] = ((c ^ 2u) + 1u) * 0x9E3779B1u;
+    }
+    out->rot = 7;
+    out->canonical = canonical ? 1u : 0u;
+    out->fw_xor = out->rc_xor = 0;
+    out->kind = MM_HASHER_MUL;
+    return MM_OK;
+}
+
+// PARITY UNPINNED: the k-mer read as a base-4 number, first base most significant and inverted
+// (anti-lexicographic order), left-aligned in 32 bits; the reverse strand likewise.
+int mm_antilex_hasher(mm_hasher_t *out, uint32_t k, int canonical) {
+    if (!out) return MM_ERR_NULL;
+    if (k == 0) return MM_ERR_K_ZERO;
+    const uint32_t sh = (32u - ((2u * k) & 31u)) & 31u;
+    for (uint32_t c = 0; c < 4; ++c) {
+        out->fw[c] = rotl32(c, sh);
+        out->rc[c] = rotl32(c ^ 2u, sh);
+    }
+    out->rot = 2;
+    out->canonical = canonical ? 1u : 0u;
+    out->fw_xor = out->rc_xor = 3u << 30;  // the first base of either strand's k-mer sits at bits 30..31
+    out->kind = MM_HASHER_ANTILEX;
     return MM_OK;
 }
 

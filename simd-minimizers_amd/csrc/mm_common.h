@@ -38,6 +38,9 @@ struct HashTables {
     uint2 t_in2[16];     // two warm-up steps at once: index = (second << 2) | first
     uint32_t rot;
     uint32_t canonical;  // 1: h = fw + rc, 0: h = fw
+    // state before the first base: the hasher's constant XOR terms (mm_hasher_t::fw_xor / rc_xor; 0 for
+    // NtHasher).  The tables above carry rot(C) ^ C per step, so the rolled state IS hash ^ C throughout.
+    uint32_t fw0, rc0;
 };
 
 // A PackedSeq seen as little-endian dwords: base i of the sequence sits at

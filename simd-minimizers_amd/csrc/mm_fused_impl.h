@@ -206,7 +206,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     const uint32_t rot_l = (32u - p.ht.rot) & 31u;  // alignbit amount for rotl(x, rot)
     const uint32_t rot_r = p.ht.rot & 31u;
     const uint32_t k = p.k;
-    uint32_t fw = 0, rc = 0;
+    uint32_t fw = p.ht.fw0, rc = p.ht.rc0;  // (the hasher's constant XOR terms; 0 for NtHasher)
     const uint8_t *tabb = reinterpret_cast<const uint8_t *>(ctx.tab);
 
     // hash of element 0: k add-only steps, 16 bases per view word, two bases per look-up

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(kBlockThreads) void generic_hash_kernel(
     uint64_t last = first + kKmersPerLane;
     if (last > km_end) last = km_end;
     long long p = (long long)seq.base0 + (long long)first;  // first base of k-mer `first`
-    uint32_t fw = 0, rc = 0;
+    uint32_t fw = ht.fw0, rc = ht.rc0;  // (the hasher's constant XOR terms; 0 for NtHasher)
     for (uint32_t j = 0; j < k; ++j) {
         uint32_t a = base_at(seq, p + j);
         uint2 t = ht.t_in[a];

@@ -94,6 +94,49 @@ def test_run_with_buf_and_pos_and_values(sm, oracle, gpu):
     cache.close()
 
 
+def test_alternative_hashers(sm, oracle, gpu):
+    """MulHasher / AntiLexHasher (src/lib.rs:71-72; src/test.rs:81-83,107-109 run the naive == product
+    sweep for them too).  PARITY UNPINNED for the hash arithmetic itself (not in the reference tree, no
+    known-answer vector: the tables are this engine's restatement, identical in oracle and product);
+    what IS checked bit-exactly is that the HIP path with those tables - constant XOR terms folded into
+    the kernels' tables - equals the oracle's definition-level flavour, on both kernel families, plus the
+    reverse-complement symmetry of the canonical flavours (src/test.rs:112-152 shape)."""
+    rng = np.random.default_rng(2024)
+    n = 20_000
+    data = oracle.gen_packed(77, n)
+    seq = sm.PackedSeq(data, 0, n)
+    rc_seq = sm.PackedSeqVec.from_codes((seq.codes()[::-1] ^ 2).astype(np.uint8))
+    for k, w in [(5, 7), (16, 11), (21, 11), (31, 19), (8, 4), (33, 5)]:
+        for canon in (False, True):
+            if canon and (k + w - 1) % 2 == 0:
+                continue
+            for name, hp, ho in (("mul", sm.MulHasher(k, canon), oracle.mul_hasher(canon)),
+                                 ("antilex", sm.AntiLexHasher(k, canon), oracle.antilex_hasher(k, canon))):
+                assert list(hp.fw) == list(ho.fw) and list(hp.rc) == list(ho.rc)
+                assert (hp.rot, hp.fw_xor, hp.rc_xor, hp.kind) == (ho.rot, ho.fw_xor, ho.rc_xor, ho.kind)
+                want = oracle.run(data, n, k, w, hasher=ho, canonical=canon, flavour=oracle.NAIVE)
+                b = sm.Builder(k, w, canon, 0).hasher(hp)
+                for force_generic in (False, True):
+                    gpu.force_generic(force_generic)
+                    try:
+                        got, _ = b._run_arrays(seq)
+                    finally:
+                        gpu.force_generic(False)
+                    assert np.array_equal(got, want), (name, k, w, canon, force_generic)
+                if canon:
+                    fwd, _ = b._run_arrays(seq)
+                    rev, _ = b._run_arrays(rc_seq)
+                    mirrored = np.sort((n - k) - rev.astype(np.int64))
+                    assert np.array_equal(np.sort(fwd.astype(np.int64)), mirrored), (name, k, w)
+                # syncmers and super-k-mer indices run on the same tables
+                for mode in (1, 2):
+                    if mode == 2 and w % 2 == 0:
+                        continue
+                    want_s = oracle.run(data, n, k, w, hasher=ho, canonical=canon, mode=mode)
+                    got_s, _ = sm.Builder(k, w, canon, mode).hasher(hp)._run_arrays(seq)
+                    assert np.array_equal(got_s, want_s), (name, k, w, canon, mode)
+
+
 # --------------------------------------------------- asynchronous completion status
 def test_async_status_is_observable(sm, oracle, gpu, monkeypatch):
     """a look-back time-out in an asynchronous run must be observable.  MM_DEBUG=32

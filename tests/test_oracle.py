@@ -246,3 +246,39 @@ def test_skip_ambiguous_without_n_equals_plain(oracle):
     for k, w, mode in [(21, 11, 0), (15, 17, 1), (15, 17, 2), (5, 7, 0)]:
         assert np.array_equal(oracle.run_skip_ambiguous(packed, amb, 5000, k, w, mode=mode),
                               oracle.run(packed, 5000, k, w, canonical=True, mode=mode))
+
+
+def test_alternative_hashers_naive_equals_streaming(oracle):
+    """src/test.rs:53-110 run the same naive == product check for MulHasher and AntiLexHasher as for
+    NtHasher.  Their arithmetic is not in the reference tree (PARITY UNPINNED, oracle/mm_oracle.h): what
+    can be checked is the restatement's self-consistency - definition == rolling hash == streaming
+    two-stacks - and, for the canonical flavours, that the hash of a k-mer equals the hash of its
+    reverse complement (which is what makes canonical minimizers strand-symmetric)."""
+    rng = np.random.default_rng(77)
+    n = 3000
+    data = oracle.gen_packed(31, n)
+    rc = oracle.revcomp_packed(data, n)
+    for k in [1, 2, 5, 15, 16, 17, 21, 31, 33]:
+        for canon in (False, True):
+            for name, h in (("mul", oracle.mul_hasher(canon)), ("antilex", oracle.antilex_hasher(k, canon))):
+                a = oracle.hash_kmers(data, n, k, h)
+                b = oracle.hash_kmers(data, n, k, h, rolling=True)
+                assert np.array_equal(a, b), (name, k, canon)
+                if canon:
+                    assert np.array_equal(a, oracle.hash_kmers(rc, n, k, h)[::-1]), (name, k)
+                for w in [1, 4, 11, 20]:
+                    if canon and (k + w - 1) % 2 == 0:
+                        continue
+                    x = oracle.run(data, n, k, w, hasher=h, canonical=canon, flavour=oracle.NAIVE)
+                    y = oracle.run(data, n, k, w, hasher=h, canonical=canon)
+                    assert np.array_equal(x, y), (name, k, w, canon)
+    # anti-lex really is the k-mer's own value with the first base inverted (k <= 16, forward)
+    k = 7
+    h = oracle.antilex_hasher(k, False)
+    hv = oracle.hash_kmers(data, 200, k, h)
+    codes = [(int(data[i >> 2]) >> (2 * (i & 3))) & 3 for i in range(200)]
+    for i in range(200 - k + 1):
+        v = 0
+        for j in range(k):
+            v = (v << 2) | (codes[i + j] ^ (3 if j == 0 else 0))
+        assert int(hv[i]) == v << (32 - 2 * k)
