@@ -196,8 +196,10 @@ def recorded_counters(kernel_ms):
                 "main_loop_insts_per_window": isa["valu_per_window"],
                 "issue_clk": round(issue_clk, 3), "sclk_mhz": round(sclk_hz / 1e6, 0),
                 "frac": round(busy / (kernel_ms * 1e-3), 4),
-                "source": "SQ_INSTS_VALU and shader clock recorded (profiles/head_counters.json), issue clocks per "
-                          "instruction from the main loop's census (profiles/head_isa_census.json), kernel time live"
+                "source": "SQ_INSTS_VALU and shader clock recorded (profiles/head_counters.json; the clock is that of "
+                          "the counter pass, about 2 % below an un-profiled run, so frac may read a little above 1), "
+                          "issue clocks per instruction from the main loop's census (profiles/head_isa_census.json), "
+                          "kernel time live"
                           + ("; STALE counters: kernel source changed since" if stale else "")
                           + ("; STALE census" if isa.get("kernel_source_sha") != sha else "")}
     except Exception:
@@ -286,7 +288,7 @@ def main():
     extras = []
     if rank == 0 and world == 1 and not args.no_extra and args.workload == "headline" and args.bases == N_BASES:
         # Secondary configurations of BASELINE.json (untimed region, before the headline so that they
-        # also bring the clocks up): kernel time by HIP events, median of 5 after 3 warm-up steps.
+        # also bring the clocks up): kernel time by HIP events, median of 5 after 12 warm-up steps.
         def secondary(name, builder, n, seed, density, contigs=None):
             b = builder.workspace(ws)
             if contigs is None:
@@ -304,7 +306,7 @@ def main():
 
                 def step():
                     offs[:] = sm.run_batch_device(b, d, list(contigs), out)
-            for _ in range(3):
+            for _ in range(12):  # (the first configuration also brings the clocks up from idle)
                 step()
             torch.cuda.synchronize(dev)
             med, _ = timed_kernel_ms(step)

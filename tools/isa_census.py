@@ -49,7 +49,7 @@ for i, s in enumerate(insts):
         continue
     body = insts[labels[m.group(1)]:i + 1]
     ops = collections.Counter(b.split()[0] for b in body)
-    if ops["v_cmp_ne_u32_sdwa"] != W or ops["s_and_saveexec_b64"] != W or ops["ds_write_b16"] != W:
+    if ops["v_cmp_ne_u32_sdwa"] + ops["v_cmpx_ne_u32_sdwa"] != W or ops["ds_write_b16"] != W:
         continue
     if sum(v for o, v in ops.items() if o.startswith("ds_read")) != W or not any(o.startswith("buffer_load") for o in ops):
         continue  # (the block loop proper: W table look-ups, W list appends, the sequence loads of a later block)
