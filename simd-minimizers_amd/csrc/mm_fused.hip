@@ -56,8 +56,11 @@ uint32_t list_capacity(uint32_t w, uint32_t mode, uint32_t S) {
 // on 2 Gbp (cap limit 76 / 62 / 51 / 44 / 38): forward w = 19: 0.99 / 0.79 / 0.74 / 0.77 / 0.76 ms,
 // w = 33: 1.45 / 1.34 / 0.95 / 0.75 / 0.71; canonical w = 11: 1.20 / 1.23 / 1.32 / 1.41,
 // w = 25: 1.26 / 1.19 / 1.17 / 1.16, w = 33 (3 workgroups per CU): 1.35 / 1.30 / 1.25 / 1.30.
-uint32_t default_cap_limit(uint32_t w, bool canonical) {
-    if (!canonical) return w <= 20u ? 51u : 38u;
+uint32_t default_cap_limit(uint32_t w, bool canonical, bool e8 = false) {
+    // (forward w <= 13: 8-bit list entries, half the LDS per list - a slightly longer lane pays: round 2, 3.1 Gbp,
+    // limit 51 -> 60: w = 7 1.629 -> 1.579 ms, w = 10 1.395 -> 1.343, w = 11 1.340 -> 1.318; the lane length is
+    // bounded by S + w <= 255 anyway)
+    if (!canonical) return e8 ? 60u : (w <= 20u ? 51u : 38u);
     if (w <= 16u) return 76u;
     if (w <= 20u) return 62u;
     if (w <= 31u) return 51u;  // (round 2, with the short look-ahead: w = 25: 1.737 ms at 51 against 1.778 at 44)
@@ -90,9 +93,18 @@ struct Geometry {
 constexpr uint32_t kMaxLdsBytes = 159u * 1024u;  // 160 KB per CU minus the static tables
 
 
+// 8-bit list entries (kEntry8 in mm_fused_impl.h; sequence and batch mode): the lane length is bounded by
+// S + w <= 255 so that every element index of a lane fits a byte
+bool entry8(const RunArgs &a) { return kEntry8Rule(a.w, a.canonical_windows != 0, a.out.sk != nullptr && a.mode == 0); }
+uint32_t stride_of(const RunArgs &a) { return list_stride(entry8(a)); }
+
 Geometry geometry(const RunArgs &a) {
     Geometry g;
-    g.nblk = legal_nblk(a.w, a.mode, a.nblk, default_cap_limit(a.w, a.canonical_windows != 0));
+    g.nblk = legal_nblk(a.w, a.mode, a.nblk, default_cap_limit(a.w, a.canonical_windows != 0, entry8(a)));
+    if (entry8(a)) {
+        const uint32_t max_nblk = (255u - a.w) / a.w;
+        if (g.nblk > max_nblk) g.nblk = max_nblk;
+    }
     // Default lanes are as long as the lists (and the cache, see default_cap_limit) allow; a run too
     // short to fill the chip once with such tiles (1024 resident workgroups) gets shorter lanes, down
     // to 6 W-blocks (measured, k=21 w=11 canonical: 64 Mbp 65.7 us with 28 blocks per lane, 58.6 with
@@ -112,7 +124,7 @@ Geometry geometry(const RunArgs &a) {
         g.S = a.w * g.nblk;
         const uint32_t cap = list_capacity(a.w, a.mode, g.S);
         g.list_cap = cap;
-        g.lds_bytes = cap * kListStride;
+        g.lds_bytes = cap * stride_of(a);
         // large w (run-time specialised kernels): shorten the lanes until the lists fit the LDS
         if (g.lds_bytes <= kMaxLdsBytes || g.nblk == 1) break;
         g.nblk = g.nblk > 4 ? g.nblk * 7 / 8 : g.nblk - 1;
@@ -245,7 +257,8 @@ static uint32_t whole_rounds_nblk(const RunArgs &a, const KernelRef &kr, const G
     for (uint32_t nb = lo; nb <= hi; ++nb) {
         const uint64_t S = (uint64_t)a.w * nb;
         if (S > 60000u || (sh && (S << sh) > 65536u)) continue;
-        if (list_capacity(a.w, a.mode, (uint32_t)S) * kListStride > lds_limit) continue;
+        if (list_capacity(a.w, a.mode, (uint32_t)S) * stride_of(a) > lds_limit) continue;
+        if (entry8(a) && S + a.w > 255u) continue;
         const double rounds = (double)tiles_of(S) / slots;
         const double cost = (double)(uint64_t)(rounds + 0.999999) * (nb + kOverheadBlocks);
         if (best == 0.0 || cost < best * 0.995 || (nb == g.nblk && cost <= best * 1.005)) {
@@ -266,7 +279,7 @@ static void tune_whole_rounds(const RunArgs &a, const KernelRef &kr, Geometry &g
     g.nblk = nb;
     g.S = a.w * g.nblk;
     g.list_cap = list_capacity(a.w, a.mode, g.S);
-    g.lds_bytes = g.list_cap * kListStride;
+    g.lds_bytes = g.list_cap * stride_of(a);
     g.NB = kFusedThreads * g.S;
     g.nblocks = (nwin + g.NB - 1) / g.NB;
 }
@@ -331,7 +344,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     uint32_t lds_bytes = g.lds_bytes;
     if (p.debug & 16u) {  // timing experiment (wrong results): lists of half the capacity, overflow ignored
         p.list_cap = g.list_cap / 2 > a.w + 2 ? g.list_cap / 2 : a.w + 2;
-        lds_bytes = p.list_cap * kListStride;
+        lds_bytes = p.list_cap * stride_of(a);
     }
     if (const char *pad = getenv("MM_LDS_PAD")) g_lds_pad = (uint32_t)atoi(pad);  // occupancy experiments
     p.trace = nullptr;

@@ -47,6 +47,18 @@ namespace mm {
 // (256 lanes + pad) = 129 dwords, odd, so that both the per-lane appends of phase 1 and the
 // per-entry reads of phase 2 spread over all LDS banks.
 constexpr uint32_t kListStride = 2u * (kFusedThreads + 2u);
+// Forward walks over small windows keep 8-bit list entries: their default lanes are short enough
+// (S + W <= 255, enforced by the launcher) for an element index to fit a byte, and lists half the size
+// let a CU hold seven workgroups instead of six - the forward walk needs its resident waves to cover
+// the time its tiles spend in look-back and copy-out (round 2: 34 % of the run).  Rows are then
+// kFusedThreads + 4 bytes apart (65 dwords, odd).  Canonical walks are bounded by registers, not LDS,
+// and want longer lanes; reads-mode positions are read-local (up to the read length); super-k-mer
+// entries pack two fields: all of those keep 16 bits.
+constexpr bool kEntry8Rule(uint32_t w, bool canon, bool sk) { return !canon && !sk && w <= 13u; }
+template <int W, bool CANON, bool SK, bool READS>
+constexpr bool kEntry8 = !READS && kEntry8Rule((uint32_t)W, CANON, SK);
+constexpr uint32_t kListStride8 = kFusedThreads + 4u;
+constexpr uint32_t list_stride(bool e8) { return e8 ? kListStride8 : kListStride; }
 
 struct FusedParams {
     SeqView seq;
@@ -160,8 +172,10 @@ struct LaneCtx {
 // One lane walks its S windows.  List mode: appends emitted 16-bit values to the lane's LDS
 // list (entries past the capacity are dropped but counted).  DIRECT mode: stores final values
 // to HBM from ctx.dst on.  Returns the number of emitted windows.
-template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool DIRECT, bool PARTIAL, bool AMBI = false>
+template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool DIRECT, bool PARTIAL, bool AMBI = false, bool E8 = false>
 __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCtx &ctx, bool &overflowed) {
+    static_assert(!E8 || !SK, "8-bit list entries hold positions only");
+    constexpr uint32_t kStride = list_stride(E8);  // bytes between consecutive entries of the lane's list
     constexpr int NSUB = (W + 15) / 16;  // 16-base view words per W-block
     const uint32_t nblk = ctx.nblk;
 
@@ -371,13 +385,13 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // ---- blocks 1..nblk: one window per step
     // next free list slot as a 32-bit LDS address (the low half of the flat address of LDS memory)
     const uint32_t list0 = (uint32_t)reinterpret_cast<uintptr_t>(ctx.list);
-    uint32_t lp32 = list0 + ctx.list_used * kListStride;
+    uint32_t lp32 = list0 + ctx.list_used * kStride;
     const uint32_t lp_end = list0 + ctx.list_bytes;
     uint32_t dropped = 0;              // entries that did not fit the list
     uint32_t valreg = 0;
     (void)valreg;
     uint32_t stride_v;  // list stride in a VGPR: v_add with two VGPR sources issues at full rate
-    asm volatile("v_mov_b32 %0, %1" : "=v"(stride_v) : "s"(kListStride));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(stride_v) : "s"(kStride));
     unsigned long long dst = ctx.dst;  // next output slot (DIRECT mode)
     // value of an emitted window: mode 0: (bw0 + lw - 1) + element index; syncmers: bw0 + lw + i
     const uint32_t wbase = ctx.wbase;
@@ -460,14 +474,14 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         if (!DIRECT) {
             // keep a whole block of appends inside the list: a lane that is about to run out of
             // slots is parked on its last W slots (its tile is then redone in DIRECT mode)
-            if (lp32 + (uint32_t)W * kListStride > lp_end) {
-                const uint32_t park = lp_end - (uint32_t)W * kListStride;
-                dropped += (lp32 - park) / kListStride;
+            if (lp32 + (uint32_t)W * kStride > lp_end) {
+                const uint32_t park = lp_end - (uint32_t)W * kStride;
+                dropped += (lp32 - park) / kStride;
                 lp32 = park;
             }
         }
 #endif
-        // (default: no check inside the walk.  Entry c of a lane sits at c * kListStride + 2 * lane, so
+        // (default: no check inside the walk.  Entry c of a lane sits at c * kStride + 2 * lane, so
         // entries past the capacity lie past the end of the workgroup's LDS allocation - the lists are
         // the dynamic part, placed behind the static variables - where the hardware drops the writes;
         // the slot pointer keeps counting, the overflow shows at the end of the walk and the tile is
@@ -556,6 +570,16 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                         : "vcc", "scc", "memory");  // s_and_saveexec writes SCC
                     prev = sel;
 #ifndef MM_EMIT_SAVEEXEC
+                } else if (MODE == 0 && !PARTIAL && !AMBI && E8) {
+                    asm volatile(
+                        "v_cmpx_ne_u32_sdwa vcc, %[sel], %[prev] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                        "ds_write_b8 %[lp], %[sel]\n\t"
+                        "v_add_u32 %[lp], %[st], %[lp]\n\t"
+                        "s_mov_b64 exec, -1"
+                        : [lp] "+v"(lp32)
+                        : [sel] "v"(sel), [prev] "v"(prev), [st] "v"(stride_v)
+                        : "vcc", "memory");
+                    prev = sel;
                 } else if (MODE == 0 && !PARTIAL && !AMBI) {
                     // every lane of the wave walks (full tile): the compare writes EXEC itself and all-ones
                     // comes back afterwards - one scalar instruction and the VCC round trip less per step
@@ -570,6 +594,18 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                         : "vcc", "memory");
                     prev = sel;
 #endif
+                } else if (MODE == 0 && E8) {
+                    // (8-bit entries: every element index of the lane is below 256, the low bytes decide)
+                    asm volatile(
+                        "v_cmp_ne_u32_sdwa vcc, %[sel], %[prev] src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"
+                        "s_and_saveexec_b64 %[sv], vcc\n\t"
+                        "ds_write_b8 %[lp], %[sel]\n\t"
+                        "v_add_u32 %[lp], %[st], %[lp]\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [lp] "+v"(lp32), [sv] "=&s"(sv)
+                        : [sel] "v"(sel), [prev] "v"(prev), [st] "v"(stride_v)
+                        : "vcc", "scc", "memory");
+                    prev = sel;
                 } else if (MODE == 0) {
                     asm volatile(
                         "v_cmp_ne_u32_sdwa vcc, %[sel], %[prev] src0_sel:WORD_0 src1_sel:WORD_0\n\t"
@@ -595,7 +631,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                  : [lp] "+v"(lp32), [sv] "=&s"(sv), [t2] "=&s"(t2), [val] "=&v"(valreg)                 \
                  : [sel] "v"(sel), [a] "s"(first), [b] "s"(e), [iv] "s"(i), [st] "v"(stride_v)          \
                  : "vcc", "scc", "memory") /* s_and_saveexec writes SCC */
-                    MM_EMIT_CLOSED("ds_write_b16");
+                    if (E8) MM_EMIT_CLOSED("ds_write_b8");
+                    else MM_EMIT_CLOSED("ds_write_b16");
 #undef MM_EMIT_CLOSED
                 } else {
                     const uint32_t mid = i + 1u + (uint32_t)(W / 2);
@@ -608,7 +645,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                  : [lp] "+v"(lp32), [sv] "=&s"(sv), [val] "=&v"(valreg)                    \
                  : [sel] "v"(sel), [a] "s"(mid), [iv] "s"(i), [st] "v"(stride_v)           \
                  : "vcc", "scc", "memory") /* s_and_saveexec writes SCC */
-                    MM_EMIT_OPEN("ds_write_b16");
+                    if (E8) MM_EMIT_OPEN("ds_write_b8");
+                    else MM_EMIT_OPEN("ds_write_b16");
 #undef MM_EMIT_OPEN
                 }
             } else {
@@ -633,9 +671,12 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                         ++dst;
                     } else {
                         uint8_t *lp = ctx.list + (lp32 - list0);
-                        *reinterpret_cast<uint16_t *>(lp) =
-                            (uint16_t)(MODE == 0 ? (SK ? sel + i * ((1u << kSkShift<W>) - 1u) : sel) : i);
-                        lp32 += kListStride;
+                        if (E8)
+                            *lp = (uint8_t)(MODE == 0 ? sel : i);
+                        else
+                            *reinterpret_cast<uint16_t *>(lp) =
+                                (uint16_t)(MODE == 0 ? (SK ? sel + i * ((1u << kSkShift<W>) - 1u) : sel) : i);
+                        lp32 += kStride;
                     }
                 }
             }
@@ -678,7 +719,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     }
     overflowed = dropped != 0 || lp32 > lp_end;  // entries were dropped (or a parked list is out of order)
     if (DIRECT) return (uint32_t)(dst - ctx.dst);
-    return (lp32 - list0) / kListStride + dropped;
+    return (lp32 - list0) / kStride + dropped;
 }
 
 // a no-progress round of lookback_overlapped sleeps up to 64 x 3.5 us: give up after about a second
@@ -880,6 +921,8 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     // reference offers run_skip_ambiguous_windows on canonical builders without super-k-mers,
     // src/lib.rs:451-496)
     constexpr bool kAmbi = CANON && !SK;
+    constexpr bool kE8 = kEntry8<W, CANON, SK, READS>;       // 8-bit list entries (see kEntry8)
+    constexpr uint32_t kStride = list_stride(kE8), kEB = kE8 ? 1u : 2u;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     // Layout contract of the list overflow (see "redo" in the header comment): the lists are the dynamic
     // LDS and must lie behind every static variable, so that entries past a list's capacity fall beyond
@@ -974,8 +1017,8 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
 
     LaneCtx ctx;
     ctx.tab = s_tab;
-    ctx.list = smem + 2u * (uint32_t)tid;
-    ctx.list_bytes = p.list_cap * kListStride;
+    ctx.list = smem + kEB * (uint32_t)tid;
+    ctx.list_bytes = p.list_cap * kStride;
     ctx.dst = 0;
     ctx.nblk = p.nblk;
     ctx.seq_d = seq_d;
@@ -1022,8 +1065,8 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
             if (act && !(p.debug & 4u)) {
                 bool over = false;
                 const uint32_t tot = (kAmbi && p.wamb)
-                                         ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi>(p, ctx, over)
-                                         : lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over);
+                                         ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi, kE8>(p, ctx, over)
+                                         : lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, false, kE8>(p, ctx, over);
                 c = tot - my_count;
                 if (over) s_overflow = 1;  // benign race: every writer stores 1
             }
@@ -1045,10 +1088,10 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
             bool over = false;
             if (kAmbi && p.wamb)
                 my_count = (partial || !kTwoBodies<W>)
-                               ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi>(p, ctx, over)
-                               : lane_walk<W, CANON, HASH_RC, MODE, SK, false, kAmbi && !kTwoBodies<W>, kAmbi>(p, ctx, over);
-            else my_count = partial ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true>(p, ctx, over)
-                                    : lane_walk<W, CANON, HASH_RC, MODE, SK, false, false>(p, ctx, over);
+                               ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi, kE8>(p, ctx, over)
+                               : lane_walk<W, CANON, HASH_RC, MODE, SK, false, kAmbi && !kTwoBodies<W>, kAmbi, kE8>(p, ctx, over);
+            else my_count = partial ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, false, kE8>(p, ctx, over)
+                                    : lane_walk<W, CANON, HASH_RC, MODE, SK, false, false, false, kE8>(p, ctx, over);
             if (over) s_overflow = 1;  // benign race: every writer stores 1
         }
     }
@@ -1126,7 +1169,11 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         // list's end get an out-of-range offset, which the bounds-checked store drops.
         if (!(p.debug & 2u)) {
             const uint32_t tid0 = (uint32_t)wave * kWave;
-            const uint8_t *rd = smem + (uint32_t)lane * kListStride + 2u * tid0;
+            const uint8_t *rd = smem + (uint32_t)lane * kStride + kEB * tid0;
+            // entry u of the eight lists L0 .. L0 + 7 in flight (one byte or one 16-bit word each)
+            auto entry = [&](int L) -> uint32_t {
+                return kE8 ? (uint32_t)rd[L] : (uint32_t)*reinterpret_cast<const uint16_t *>(rd + 2 * L);
+            };
             const uint32_t vb0 = (READS ? 0u : (uint32_t)bw0 + tid0 * S) - (MODE == 0 ? 1u : 0u);
             // Output window of this wave as a bounds-checked buffer (wave-uniform, so the
             // descriptor lives in SGPRs): stores past the caller's capacity are dropped by the
@@ -1193,7 +1240,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
                 for (int L0 = 0; L0 < kWave; L0 += kBatch) {
                     uint32_t ent[kBatch];
 #pragma unroll
-                    for (int u = 0; u < kBatch; ++u) ent[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u));
+                    for (int u = 0; u < kBatch; ++u) ent[u] = entry(L0 + u);
 #pragma unroll
                     for (int u = 0; u < kBatch; ++u) {
                         const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
@@ -1219,7 +1266,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
                 for (int L0 = 0; L0 < kWave; L0 += kBatch) {
                     uint32_t ent[kBatch];
 #pragma unroll
-                    for (int u = 0; u < kBatch; ++u) ent[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u));
+                    for (int u = 0; u < kBatch; ++u) ent[u] = entry(L0 + u);
 #pragma unroll
                     for (int u = 0; u < kBatch; ++u) {
                         const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
@@ -1268,7 +1315,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
                 for (int L0 = 0; L0 < kWave; L0 += kBatch) {
                     uint32_t ent[kBatch];
 #pragma unroll
-                    for (int u = 0; u < kBatch; ++u) ent[u] = *reinterpret_cast<const uint16_t *>(rd + 2 * (L0 + u));
+                    for (int u = 0; u < kBatch; ++u) ent[u] = entry(L0 + u);
 #pragma unroll
                     for (int u = 0; u < kBatch; ++u) {
                         const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
@@ -1292,8 +1339,8 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
                     const uint32_t n = pkl & 511u, off = pkl >> 9;
                     const uint32_t vb = READS ? vb0 : vb0 + L * S;
                     for (uint32_t c = (uint32_t)kWave + lane; c < n; c += kWave) {
-                        const uint8_t *q = rd + 2u * L + (c - lane) * kListStride;
-                        const uint32_t e1 = *reinterpret_cast<const uint16_t *>(q);
+                        const uint8_t *q = rd + kEB * L + (c - lane) * kStride;
+                        const uint32_t e1 = kE8 ? (uint32_t)*q : (uint32_t)*reinterpret_cast<const uint16_t *>(q);
                         const uint32_t iw = e1 >> kSh;
                         __builtin_amdgcn_raw_buffer_store_b32(SK ? vb + iw + (e1 & kRelMask) : vb + e1, opos,
                                                               (off + c) * 4u, 0, 0);
@@ -1311,8 +1358,8 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
             ctx.dst = o;
             bool over;
             if (act) {
-                if (kAmbi && p.wamb) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true, kAmbi>(p, ctx, over);
-                else lane_walk<W, CANON, HASH_RC, MODE, SK, true, true>(p, ctx, over);
+                if (kAmbi && p.wamb) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true, kAmbi, kE8>(p, ctx, over);
+                else lane_walk<W, CANON, HASH_RC, MODE, SK, true, true, false, kE8>(p, ctx, over);
             }
             o += (read_counts >> (16u * j)) & 0xffffu;
         }
@@ -1320,9 +1367,9 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         // some list overflowed: walk the tile again, now storing straight to the output
         ctx.dst = run0 + excl;
         bool over;
-        if (kAmbi && p.wamb) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true, kAmbi>(p, ctx, over);
-        else if (partial) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true>(p, ctx, over);
-        else lane_walk<W, CANON, HASH_RC, MODE, SK, true, false>(p, ctx, over);
+        if (kAmbi && p.wamb) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true, kAmbi, kE8>(p, ctx, over);
+        else if (partial) lane_walk<W, CANON, HASH_RC, MODE, SK, true, true, false, kE8>(p, ctx, over);
+        else lane_walk<W, CANON, HASH_RC, MODE, SK, true, false, false, kE8>(p, ctx, over);
     }
     if (p.trace) {
         __syncthreads();
