@@ -717,7 +717,7 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
     a.batch_tile_seq = ws->batch_tiles;
     a.batch_offsets = ws->batch_offsets;
     a.batch_tiles = n_tiles;
-    r = grow(ws->status, ws->status_words, n_tiles + 8, sizeof(unsigned long long));
+    r = grow(ws->status, ws->status_words, (n_tiles + 8) * mm::fused_status_stride(), sizeof(unsigned long long));
     if (r) return r;
     a.out.status = ws->status;
 

@@ -56,6 +56,13 @@ uint32_t list_capacity(uint32_t w, uint32_t mode, uint32_t S) {
 // on 2 Gbp (cap limit 76 / 62 / 51 / 44 / 38): forward w = 19: 0.99 / 0.79 / 0.74 / 0.77 / 0.76 ms,
 // w = 33: 1.45 / 1.34 / 0.95 / 0.75 / 0.71; canonical w = 11: 1.20 / 1.23 / 1.32 / 1.41,
 // w = 25: 1.26 / 1.19 / 1.17 / 1.16, w = 33 (3 workgroups per CU): 1.35 / 1.30 / 1.25 / 1.30.
+// words the host reserves and clears per tile status (kStatusStride of the prebuilt kernels; experiments
+// with run-time specialised kernels of another stride set MM_STATUS_STRIDE_HOST to at least that stride)
+uint64_t status_stride_host() {
+    static const uint64_t v = getenv("MM_STATUS_STRIDE_HOST") ? (uint64_t)atoi(getenv("MM_STATUS_STRIDE_HOST")) : kStatusStride;
+    return v < kStatusStride ? kStatusStride : v;
+}
+
 uint32_t default_cap_limit(uint32_t w, bool canonical, bool e8 = false) {
     // (forward w <= 13: 8-bit list entries, half the LDS per list - a slightly longer lane pays: round 2, 3.1 Gbp,
     // limit 51 -> 60: w = 7 1.629 -> 1.579 ms, w = 10 1.395 -> 1.343, w = 11 1.340 -> 1.318; the lane length is
@@ -212,7 +219,7 @@ bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_c
 uint64_t fused_status_words(const RunArgs &a) {
     // (x 1.2: tune_whole_rounds may shorten the lanes by 15 %; + 8: the chunked look-back variant keeps
     // per-tile counts and per-chunk bases in the same words)
-    return geometry(a).nblocks * 6 / 5 + 8;
+    return (geometry(a).nblocks * 6 / 5 + 8) * status_stride_host();
 }
 uint32_t fused_tile_windows(const RunArgs &a) { return geometry(a).NB; }
 
@@ -337,7 +344,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         const char *dbg = getenv("MM_DEBUG");
         p.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
     }
-    if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (g.nblocks + 8), stream) != hipSuccess)
+    if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (g.nblocks + 8) * status_stride_host(), stream) != hipSuccess)
         return -1;
     // (the ticket is only read in ticket mode: one stream operation less per run otherwise)
     if (a.use_ticket && hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
@@ -395,8 +402,9 @@ bool fused_reads_supported(uint32_t w, int canonical_windows, int hasher_canonic
 }
 
 uint64_t fused_reads_status_words(const ReadsArgs &a) {
-    return (a.n_reads + kFusedThreads - 1) / kFusedThreads + 8;
+    return ((a.n_reads + kFusedThreads - 1) / kFusedThreads + 8) * status_stride_host();
 }
+uint64_t fused_status_stride() { return status_stride_host(); }
 
 int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     if (a.n_reads == 0) return 0;
@@ -466,7 +474,8 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.batch_n = 0;
     p.trace = nullptr;
     p.out = a.out;
-    if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (nblocks + 8), stream) != hipSuccess) return -1;
+    if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (nblocks + 8) * status_stride_host(), stream) != hipSuccess)
+        return -1;
     // (the ticket is only read in ticket mode: one stream operation less per run otherwise)
     if (a.use_ticket && hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
     return launch_kernel(kr, (uint32_t)nblocks, lds_bytes, stream, p, a.timing_start, a.timing_stop);

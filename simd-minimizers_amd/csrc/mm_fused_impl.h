@@ -41,7 +41,19 @@
 #define MM_PREFETCH_BLOCKS 2
 #endif
 
+// 8-byte words between the look-back status words of consecutive tiles.  One word per 64 bytes: tiles that
+// finish at about the same time publish and poll neighbouring words, and with the words packed 8 bytes apart
+// those accesses contend for the same memory sector - the look-back wait of the forward kernel was mostly
+// that (round 2, 3.1 Gbp, stride 1 -> 8: forward k=21 w=11 1.293 -> 1.213 ms, canonical 1.805 -> 1.749;
+// stride 2 already gives 1.232, 16 and 32 nothing more; tools/gpu_jit_w.py).  2.5 MB of status words for
+// 3.1 Gbp, cleared per launch.
+#ifndef MM_STATUS_STRIDE
+#define MM_STATUS_STRIDE 8
+#endif
+
 namespace mm {
+
+constexpr size_t kStatusStride = MM_STATUS_STRIDE;
 
 // Byte distance between consecutive entries of one lane's list: 258 u16 slots per plane
 // (256 lanes + pad) = 129 dwords, odd, so that both the per-lane appends of phase 1 and the
@@ -726,7 +738,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
 constexpr uint32_t kMaxIdleRounds = 1u << 12;
 
 __device__ __forceinline__ void publish_aggregate(unsigned long long *status, uint32_t bid, uint32_t total) {
-    st_status(&status[bid], kFlagAgg | ((unsigned long long)total & kValMask));
+    st_status(&status[(size_t)bid * kStatusStride], kFlagAgg | ((unsigned long long)total & kValMask));
 }
 
 // Look-back of a tile run by wave 0 alone while the other waves of the workgroup may still be in
@@ -748,7 +760,7 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
         bool progress = false;
         if (!have_excl) {
             const long long idx = j - lane;
-            const unsigned long long s = idx >= 0 ? ld_status(&status[idx]) : kFlagIncl;
+            const unsigned long long s = idx >= 0 ? ld_status(&status[(size_t)idx * kStatusStride]) : kFlagIncl;
             const unsigned long long zmask = __ballot((s >> 62) == 0);
             const unsigned long long pmask = __ballot((s >> 62) == 2);
             const int first_zero = zmask ? __builtin_ctzll(zmask) : kWave;
@@ -784,7 +796,10 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
                 unsigned long long s0 = 0;
                 for (uint32_t spins = 0; spins < 64u; ++spins) {
                     __builtin_amdgcn_s_sleep(MM_LB_SLEEP);
-                    if (lane == 0) s0 = ld_status(&status[j]);
+#ifdef MM_LB_SLEEP2
+                    __builtin_amdgcn_s_sleep(MM_LB_SLEEP2);  // experiment: poll even less often than the longest sleep
+#endif
+                    if (lane == 0) s0 = ld_status(&status[(size_t)j * kStatusStride]);
                     s0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(s0 >> 32)) << 32) |
                          (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)s0);
                     if ((s0 >> 62) != 0) break;
@@ -794,7 +809,7 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
             }
         }
     }
-    if (lane == 0) st_status(&status[bid], kFlagIncl | ((excl + block_total) & kValMask));
+    if (lane == 0) st_status(&status[(size_t)bid * kStatusStride], kFlagIncl | ((excl + block_total) & kValMask));
     return excl;
 }
 

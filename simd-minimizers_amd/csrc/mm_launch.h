@@ -40,6 +40,8 @@ struct RunArgs {
 // ---- fused family (mm_fused_*.hip): one kernel, specialised per w
 bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_canonical);
 uint64_t fused_status_words(const RunArgs &a);
+// 8-byte words reserved per tile status (the look-back words of consecutive tiles are spaced apart)
+uint64_t fused_status_stride();
 // windows per tile for this plan / output flavour (what a batch's tile table is built from)
 uint32_t fused_tile_windows(const RunArgs &a);
 // blocks per lane that make a batch fill whole rounds of resident workgroups (0 = keep the default);
