@@ -1263,6 +1263,9 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
                         const uint32_t vbl = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
                         const uint32_t iw = ent[u] >> kSh;
                         const uint32_t val = SK ? vbl + iw + (ent[u] & kRelMask) : vbl + ent[u];
+                        // (round 2 experiment: storing every list as one or two full, aligned 128-byte lines
+                        // instead changed the forward kernel by -1.5 % / +3 % - the stores cost by their bytes,
+                        // not by their partial lines, so staging them into aligned runs would not pay)
                         const uint32_t end_bytes = ((off + n) * 4u) & store_mask;  // (store_mask 0: timing experiment)
                         const __amdgpu_buffer_rsrc_t dl = __builtin_amdgcn_make_buffer_rsrc(
                             const_cast<uint32_t *>(obase32), 0, (int)end_bytes, 0x00020000);
