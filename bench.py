@@ -192,14 +192,20 @@ def recorded_counters(kernel_ms):
         sclk_hz = float(c["GRBM_GUI_ACTIVE_per_xcd"]) / (float(c["counter_pass_kernel_us"]) * 1e-6)
         issue_clk = float(isa["issue_clk_per_valu"])
         busy = insts * issue_clk / (N_SIMD * sclk_hz)  # seconds of VALU-pipe time per launch
+        pass_cycles = float(c["GRBM_GUI_ACTIVE_per_xcd"])  # shader cycles of one launch IN the counter pass
         valu = {"insts_per_window": round(insts * 64.0 / windows, 2),
                 "main_loop_insts_per_window": isa["valu_per_window"],
                 "issue_clk": round(issue_clk, 3), "sclk_mhz": round(sclk_hz / 1e6, 0),
+                # upper bound: live kernel time at the (lower) clock of the counter pass
                 "frac": round(busy / (kernel_ms * 1e-3), 4),
-                "source": "SQ_INSTS_VALU and shader clock recorded (profiles/head_counters.json; the clock is that of "
-                          "the counter pass, about 2 % below an un-profiled run, so frac may read a little above 1), "
-                          "issue clocks per instruction from the main loop's census (profiles/head_isa_census.json), "
-                          "kernel time live"
+                # lower bound, cycle-exact: VALU-pipe cycles / shader cycles of the counter pass itself,
+                # which runs about 13 % slower than the live kernel (counter collection)
+                "frac_counter_pass": round(insts * issue_clk / (N_SIMD * pass_cycles), 4),
+                "source": "SQ_INSTS_VALU and GRBM_GUI_ACTIVE recorded (profiles/head_counters.json), issue clocks per "
+                          "instruction from the main loop's census (profiles/head_isa_census.json), kernel time live; "
+                          "`frac` uses the live kernel time with the counter pass's clock (the live clock is a few % "
+                          "higher, so it may read slightly above 1), `frac_counter_pass` is cycle-exact within the "
+                          "slower counter pass: the true VALU-pipe utilisation lies between the two"
                           + ("; STALE counters: kernel source changed since" if stale else "")
                           + ("; STALE census" if isa.get("kernel_source_sha") != sha else "")}
     except Exception:
