@@ -19,7 +19,9 @@ sliding min -> strand vote -> dedup/collect) over synthetic input that is alread
 With N > 1 and no launcher in the environment the script starts its N ranks itself (child processes,
 before anything in this process touches a GPU); under torchrun it uses the ranks it is given.  The
 timed region follows the driver contract: W untimed steps, barrier + synchronize, exactly K steps,
-synchronize + barrier, max over ranks.  Rank 0 prints ONE JSON line.
+synchronize + barrier, max over ranks.  Rank 0 prints ONE JSON line.  `vs_baseline` stays null: BASELINE.md
+holds no published number for this metric on this hardware (the CPU figure measured beside it is
+`cpu_baseline`, a reported baseline and not a target).
 """
 import argparse
 import hashlib
