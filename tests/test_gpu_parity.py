@@ -559,8 +559,10 @@ def test_batch_of_contigs(sm, oracle, gpu):
     d = [torch.from_numpy(x).cuda() for x in datas]
     out = torch.zeros(sum(lens) + 16, dtype=torch.int32, device="cuda")
     sk = torch.zeros_like(out)
+    # (the forward plans with w <= 13 and no super-k-mer indices run the 8-bit-list flavour of the kernel)
     for k, w, canonical, mode, use_sk in [(21, 11, True, 0, False), (21, 11, False, 0, True), (15, 17, True, 1, False),
-                                          (9, 23, False, 0, False)]:
+                                          (9, 23, False, 0, False), (15, 10, False, 0, False), (12, 9, False, 1, False),
+                                          (7, 13, False, 2, False)]:
         b = sm.Builder(k, w, canonical, mode)
         offs = sm.run_batch_device(b, d, lens, out, sk if use_sk else None)
         assert offs[0] == 0 and len(offs) == len(lens) + 1
