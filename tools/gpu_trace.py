@@ -8,7 +8,7 @@ import simd_minimizers_amd as sm
 n = 3_100_000_000
 d = sm.generate_device(n, 3)
 out = torch.zeros(int(n * 0.2), dtype=torch.int32, device="cuda")
-b = sm.canonical_minimizers(21, 11)
+b = sm.Builder(21, 11, os.environ.get("FWD") != "1", 0)
 b.run_device(d, n, out)
 for spec in sys.argv[1:] or ["0:0", "4:0"]:
     stagger, dbg = spec.split(":")
