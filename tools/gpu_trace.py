@@ -31,7 +31,9 @@ for spec in sys.argv[1:] or ["0:0", "4:0"]:
     for ts in np.linspace(0.2, 0.8, 4) * end.max():
         res = (start <= ts) & (end > ts)
         in_p2 = res & (p1 <= ts)
-        print(f"   t={ts:7.1f} us: resident={res.sum():4d} in phase 2={in_p2.sum():4d}")
+        xc = ((t[:, 4] >> 32) & 15).astype(int)
+        print(f"   t={ts:7.1f} us: resident={res.sum():4d} in phase 2={in_p2.sum():4d}; resident by XCD "
+              f"{np.bincount(xc[res], minlength=8)} walking by XCD {np.bincount(xc[res & ~in_p2], minlength=8)}")
     # one CU's slots over time
     c0 = cu[0]
     idx = np.flatnonzero(cu == c0)[40:46]
