@@ -541,7 +541,6 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
         a.out.error = reinterpret_cast<uint32_t *>(ws->total + 1);
         a.nblk = ws->nblk;
         a.use_ticket = (ws->force_ticket || getenv("MM_FORCE_TICKET")) ? 1 : 0;
-        a.xcd_speed = nullptr;
         a.scratch = nullptr;
         a.generic_round_windows = 0;
         a.timing_start = a.timing_stop = nullptr;
@@ -647,7 +646,6 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
     a.out.ticket = ws->ticket;
     a.out.error = reinterpret_cast<uint32_t *>(ws->total + 1);
     a.nblk = ws->nblk;
-    a.xcd_speed = nullptr;
     a.scratch = nullptr;
     a.generic_round_windows = 0;
     a.wamb = nullptr;

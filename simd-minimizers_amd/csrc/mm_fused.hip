@@ -225,11 +225,11 @@ bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_c
     return jit_enabled() && w >= 1 && w <= kJitMaxW;
 }
 
-// (x 1.5: tune_whole_rounds may shorten the lanes by 15 %, tiles sized by XCD are up to 25 % shorter than
-// the longest one and their grid has a few spare tiles; + 8: the chunked look-back variant keeps per-tile
-// counts and per-chunk bases in the same words)
-static uint64_t max_tiles(const RunArgs &a) { return geometry(a).nblocks * 3 / 2 + 16; }
-uint64_t fused_status_words(const RunArgs &a) { return (max_tiles(a) + 8) * status_stride_host(); }
+uint64_t fused_status_words(const RunArgs &a) {
+    // (x 1.2: tune_whole_rounds may shorten the lanes by 15 %; + 8: the chunked look-back variant keeps
+    // per-tile counts and per-chunk bases in the same words)
+    return (geometry(a).nblocks * 6 / 5 + 8) * status_stride_host();
+}
 uint32_t fused_tile_windows(const RunArgs &a) { return geometry(a).NB; }
 
 static uint32_t g_lds_pad = 0;
@@ -319,70 +319,6 @@ uint32_t fused_batch_nblk(const RunArgs &a, const uint64_t *n_windows, uint64_t 
     return nb == g.nblk ? 0u : nb;
 }
 
-// Tiles sized by XCD (XcdTiles in mm_fused_impl.h).  `speed` = relative speed of the eight XCDs; the fastest
-// one walks g.nblk blocks per lane (what the lists are sized for), the others proportionally fewer, dithered
-// over the eight rounds of a 64-tile super-period between the two neighbouring integers.  The grid covers the
-// run for every XCD rotation c the hardware may pick, so up to seven tiles at the end may be empty.
-// Returns false (uniform tiles) when the run is too short to care or the tables would not fit.
-static bool build_xcd_tiles(const RunArgs &a, const float *speed, Geometry &g, XcdTiles &xt, uint64_t tile_limit) {
-    xt.on = 0;
-    if (!speed || a.batch_tile_seq || a.use_ticket || g.nblk < 8u || g.nblk > 255u || g.nblocks < 2048u)
-        return false;
-    double mx = 0.0, mn = 1e30;
-    for (int x = 0; x < 8; ++x) {
-        if (!(speed[x] > 0.0f)) return false;
-        mx = speed[x] > mx ? speed[x] : mx;
-        mn = speed[x] < mn ? speed[x] : mn;
-    }
-    if (mn >= mx * 0.995) return false;  // nothing to balance
-    double f[8];
-    for (int x = 0; x < 8; ++x) {
-        f[x] = g.nblk * (speed[x] / mx);
-        const double lo = 0.75 * g.nblk > 6.0 ? 0.75 * g.nblk : 6.0;  // (a mis-measured XCD must not get crumbs)
-        f[x] = f[x] < lo ? lo : f[x];
-    }
-    uint32_t acc = 0;
-    for (int j = 0; j < 8; ++j)
-        for (int x = 0; x < 8; ++x) {
-            const int u = 8 * j + x;
-            const uint32_t sz = (uint32_t)((j + 1) * f[x] + 1e-9) - (uint32_t)(j * f[x] + 1e-9);
-            xt.size[u] = (uint8_t)(sz > g.nblk ? g.nblk : (sz < 1u ? 1u : sz));
-            xt.prefix[u] = (uint16_t)acc;
-            acc += xt.size[u];
-        }
-    xt.total = acc;
-    for (int c = 0; c < 8; ++c) xt.prefix[64 + c] = (uint16_t)(acc + xt.prefix[c]);
-    // tiles needed for the worst rotation
-    const uint64_t nwin = a.win_end - a.win_begin;
-    const uint64_t blk_windows = (uint64_t)kFusedThreads * a.w;
-    const uint64_t need = (nwin + blk_windows - 1) / blk_windows;  // blocks per lane over the whole run
-    uint64_t tiles = 0;
-    for (uint32_t c = 0; c < 8; ++c) {
-        const uint64_t target = need + xt.prefix[c];
-        uint64_t u = target / xt.total * 64u;  // blocks before tile u: (u / 64) * total + prefix[u % 64]
-        while ((u >> 6) * xt.total + xt.prefix[u & 63u] < target) ++u;
-        tiles = u - c > tiles ? u - c : tiles;
-    }
-    if (tiles > tile_limit || tiles >= (1ull << 31)) return false;
-    g.nblocks = tiles;
-    xt.on = 1;
-    return true;
-}
-
-// MM_XCD_W="s0,s1,...,s7" (experiments): relative XCD speeds that override the caller's
-static const float *env_xcd_speed(float *buf) {
-    const char *e = getenv("MM_XCD_W");
-    if (!e || !*e) return nullptr;
-    int n = 0;
-    for (const char *q = e; n < 8 && *q; ++n) {
-        char *end = nullptr;
-        buf[n] = strtof(q, &end);
-        if (end == q) break;
-        q = *end == ',' ? end + 1 : end;
-    }
-    return n == 8 ? buf : nullptr;
-}
-
 int launch_fused(const RunArgs &a, hipStream_t stream) {
     Geometry g = geometry(a);
     if (g.nblocks == 0) return 0;
@@ -413,14 +349,6 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.batch_n = a.batch_n;
     p.out = a.out;
     p.use_ticket = a.use_ticket ? 1u : 0u;
-    {
-        static const bool off = getenv("MM_NO_XCD_TILES") != nullptr;
-        float envbuf[8];
-        const float *speed = env_xcd_speed(envbuf);
-        if (!speed) speed = a.xcd_speed;
-        p.xt.on = 0;
-        if (!off) build_xcd_tiles(a, speed, g, p.xt, max_tiles(a));
-    }
     {
         const char *dbg = getenv("MM_DEBUG");
         p.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
@@ -555,7 +483,6 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.batch_n = 0;
     p.trace = nullptr;
     p.out = a.out;
-    p.xt.on = 0;
     if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (nblocks + 8) * status_stride_host(), stream) != hipSuccess)
         return -1;
     // (the ticket is only read in ticket mode: one stream operation less per run otherwise)

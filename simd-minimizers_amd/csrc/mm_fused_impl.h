@@ -72,20 +72,6 @@ constexpr bool kEntry8 = !READS && kEntry8Rule((uint32_t)W, CANON, SK);
 constexpr uint32_t kListStride8 = kFusedThreads + 4u;
 constexpr uint32_t list_stride(bool e8) { return e8 ? kListStride8 : kListStride; }
 
-// Tile sizes by XCD (sequence mode; see "XCD-proportional tiles" in DESIGN.md).  gfx950 hands workgroup b
-// to XCD (b + c) mod 8 with c fixed within a launch, and the XCDs of a part differ in speed by 4-20 %; with equal
-// tiles the slowest one sets the pace of the in-order look-back and of the round-robin dispatch.  Tiles are
-// therefore sized in proportion to their XCD's measured speed: tile u = b + c of the launch walks size[u % 64]
-// W-blocks per lane (the XCD is u % 8; the eight rounds of a super-period dither the size between two
-// neighbouring integers) and starts prefix[...] blocks into the run.  c is read from the hardware by every
-// workgroup; the look-back checks that all of them saw the same one (status word, kXcdShift).
-struct XcdTiles {
-    uint32_t on;            // 0: uniform tiles of FusedParams::nblk blocks
-    uint32_t total;         // blocks (per lane) of one super-period of 64 tiles
-    uint16_t prefix[64 + 8];  // blocks of tiles 0 .. u-1 of the super-period, u = 0 .. 71 (the tail serves c)
-    uint8_t size[64];       // blocks per lane of tile u of the super-period
-};
-
 struct FusedParams {
     SeqView seq;
     HashTables ht;
@@ -120,7 +106,6 @@ struct FusedParams {
     // timing experiments (MM_TRACE): 4 timestamps per tile (start, phase 1 done, look-back done, end)
     unsigned long long *trace;
     OutParams out;
-    XcdTiles xt;
 };
 
 // inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts
@@ -752,18 +737,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
 // a no-progress round of lookback_overlapped sleeps up to 64 x 3.5 us: give up after about a second
 constexpr uint32_t kMaxIdleRounds = 1u << 12;
 
-// Bits 56..59 of a status word carry the tile's XCD tag: 0 for uniform tiles, 8 | c for tiles sized by XCD
-// (XcdTiles; c = the launch's XCD rotation as THIS workgroup read it from the hardware).  Every status word a
-// look-back consumes must carry the consumer's own tag: the chain of equalities proves that all workgroups of
-// the launch used the same c, i.e. the same tile geometry; a mismatch reports error 3 and the host repeats the
-// run with uniform tiles.  Counts and prefixes stay far below 2^56.
-constexpr uint32_t kXcdShift = 56;
-constexpr unsigned long long kValLow = (1ull << kXcdShift) - 1ull;
-
-__device__ __forceinline__ void publish_aggregate(unsigned long long *status, uint32_t bid, uint32_t total,
-                                                  uint32_t xcd_tag) {
-    st_status(&status[(size_t)bid * kStatusStride],
-              kFlagAgg | ((unsigned long long)xcd_tag << kXcdShift) | (unsigned long long)total);
+__device__ __forceinline__ void publish_aggregate(unsigned long long *status, uint32_t bid, uint32_t total) {
+    st_status(&status[(size_t)bid * kStatusStride], kFlagAgg | ((unsigned long long)total & kValMask));
 }
 
 // Look-back of a tile run by wave 0 alone while the other waves of the workgroup may still be in
@@ -774,8 +749,7 @@ __device__ __forceinline__ void publish_aggregate(unsigned long long *status, ui
 // Status words and bounds as in lookback_exclusive (mm_common.h).  Returns the exclusive prefix.
 __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long long *status, uint32_t bid,
                                                                   unsigned long long carry_in, uint32_t *error,
-                                                                  uint32_t *done, const uint32_t *wave_tot,
-                                                                  uint32_t xcd_tag) {
+                                                                  uint32_t *done, const uint32_t *wave_tot) {
     const int lane = threadIdx.x & (kWave - 1);
     bool have_excl = (bid == 0);
     unsigned long long excl = (bid == 0) ? carry_in : 0ull;
@@ -792,10 +766,7 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
             const int first_zero = zmask ? __builtin_ctzll(zmask) : kWave;
             const int first_p = pmask ? __builtin_ctzll(pmask) : kWave;
             const int take = first_p < first_zero ? first_p + 1 : first_zero;  // lanes [0, take) count
-            unsigned long long v = lane < take ? (s & kValLow) : 0ull;
-            // every word consumed comes from a tile of the same geometry (see kXcdShift)
-            if (__ballot(lane < take && idx >= 0 && (uint32_t)((s >> kXcdShift) & 15u) != xcd_tag) != 0ull)
-                flag_error(error, 3u);
+            unsigned long long v = lane < take ? (s & kValMask) : 0ull;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
             excl += v;
@@ -838,9 +809,7 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
             }
         }
     }
-    if (lane == 0)
-        st_status(&status[(size_t)bid * kStatusStride],
-                  kFlagIncl | ((unsigned long long)xcd_tag << kXcdShift) | ((excl + block_total) & kValLow));
+    if (lane == 0) st_status(&status[(size_t)bid * kStatusStride], kFlagIncl | ((excl + block_total) & kValMask));
     return excl;
 }
 
@@ -1016,20 +985,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         p.trace[10 * (size_t)bid + 4] = ((unsigned long long)xcc << 32) | hw;
     }
 
-    // blocks per lane and first window of this tile: uniform tiles, or sized by XCD (XcdTiles)
-    uint32_t nblk_t = p.nblk, xcd_c = 0;
-    uint64_t xcd_w0 = 0;
-    const bool xcd_tiles = !READS && p.xt.on != 0u;
-    if (xcd_tiles) {
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        xcd_c = (xcc - bid) & 7u;
-        const uint32_t u = bid + xcd_c, r = u & 63u;
-        nblk_t = __builtin_amdgcn_readfirstlane((uint32_t)p.xt.size[r]);
-        const uint64_t blk0 = (uint64_t)(u >> 6) * p.xt.total + p.xt.prefix[r] - p.xt.prefix[xcd_c];
-        xcd_w0 = blk0 * (uint64_t)(kFusedThreads * (uint32_t)W);
-    }
-    const uint32_t S = (uint32_t)W * nblk_t;
+    const uint32_t S = (uint32_t)W * p.nblk;
     const uint32_t NB = kFusedThreads * S;
     // (one 32 x 32 -> 64-bit product: stays on the scalar unit, so everything derived from the tile
     // origin - the buffer descriptors of the sequence loads above all - lives in SGPRs)
@@ -1069,12 +1025,9 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         p.trace[10 * (size_t)bid + 8] = ((unsigned long long)win_end << 32) | local_tile;
         p.trace[10 * (size_t)bid + 9] = batch_s;
     }
-    const uint64_t bw0 = READS ? 0ull  // first window of the tile
-                               : (uint64_t)win_begin + (xcd_tiles ? xcd_w0 : (uint64_t)local_tile * NB);
-    // (tiles sized by XCD: the grid covers the run for every c, so the last few tiles may lie behind its end)
+    const uint64_t bw0 = READS ? 0ull : (uint64_t)win_begin + (uint64_t)local_tile * NB;  // first window of the tile
     const uint32_t nvalid = READS ? NB
-        : (bw0 >= (uint64_t)win_end ? 0u
-                                    : (uint32_t)(((uint64_t)win_end - bw0) < NB ? ((uint64_t)win_end - bw0) : NB));
+        : (uint32_t)(((uint64_t)win_end - bw0) < NB ? ((uint64_t)win_end - bw0) : NB);
     const bool partial = READS || nvalid < NB;
 
     LaneCtx ctx;
@@ -1082,7 +1035,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     ctx.list = smem + kEB * (uint32_t)tid;
     ctx.list_bytes = p.list_cap * kStride;
     ctx.dst = 0;
-    ctx.nblk = nblk_t;
+    ctx.nblk = p.nblk;
     ctx.seq_d = seq_d;
     ctx.seq_dwords = seq_dwords;
     bool lane_active = false;
@@ -1174,7 +1127,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
             uint32_t tot = 0;
 #pragma unroll
             for (int v = 0; v < kFusedWaves; ++v) tot += reinterpret_cast<volatile uint32_t *>(s_wave_tot)[v];
-            publish_aggregate(p.out.status, bid, tot, xcd_tiles ? (8u | xcd_c) : 0u);
+            publish_aggregate(p.out.status, bid, tot);
         }
 #else
         if (atomicAdd(&s_done, 1u) == (uint32_t)(kFusedWaves - 1) && !(p.debug & 1u)) {
@@ -1192,8 +1145,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         const unsigned long long carry = (bid == 0) ? *p.out.total : 0ull;
         const unsigned long long ex =
             (p.debug & 1u) ? (unsigned long long)bid * (NB / 6u)
-                           : lookback_overlapped(p.out.status, bid, carry, p.out.error, &s_done, s_wave_tot,
-                                                 xcd_tiles ? (8u | xcd_c) : 0u);
+                           : lookback_overlapped(p.out.status, bid, carry, p.out.error, &s_done, s_wave_tot);
 #else
         const unsigned long long carry = s_carry;  // base of chunk 0: every tile of that chunk needs it
         const unsigned long long ex =

@@ -30,9 +30,6 @@ struct RunArgs {
     uint32_t nblk;  // w-blocks per lane (0 = default)
     uint64_t work_windows;  // windows of the whole run (0 = unknown): short runs get shorter lanes (more tiles)
     int use_ticket; // tile ids from an atomic ticket instead of blockIdx.x (safe mode)
-    // relative speed of the device's eight XCDs (hardware XCC ids; any scale), or null: uniform tiles.
-    // Long single-sequence runs size their tiles in proportion (XcdTiles, mm_fused_impl.h).
-    const float *xcd_speed;
     // generic path
     void *scratch;
     uint64_t generic_round_windows;
