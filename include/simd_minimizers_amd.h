@@ -313,6 +313,26 @@ int mm_pack_ascii_device_async(mm_workspace_t *ws, const uint8_t *d_ascii, uint6
  * base (set for every character that is not ACGT / acgt), d_amb = ceil(n/8) bytes. */
 int mm_pack_ascii_n_device_async(mm_workspace_t *ws, const uint8_t *d_ascii, uint64_t n_bases,
                                  uint8_t *d_packed /* ceil(n/4) bytes */, uint8_t *d_amb);
+/* FASTA text -> PackedSeq records on the device: what the reference's loader does on the CPU with
+ * needletail::parse_fastx_file + PackedSeqVec::from_ascii per record (bench/src/lib.rs:51-82).  A record
+ * starts with '>' at the start of a line, its header runs to the end of that line, its sequence is every
+ * following line up to the next header with '\n' and '\r' removed (bytes before the first header are
+ * ignored); every sequence byte packs as (c >> 1) & 3.  ALL records go back to back into d_packed (4-byte
+ * aligned, packed_capacity_bytes a multiple of 4; n_bytes / 4 + 8 always suffices): record r = bases
+ * [d_rec_base[r], d_rec_base[r + 1]) of it - pass d_packed + base / 4 with base_offset = base % 4 to
+ * mm_run_batch_device.  d_rec_text_pos[r] (optional) = byte offset of the record's '>' in the text (the
+ * caller slices the header from there).  d_counts[0] = bases, d_counts[1] = records found; records past
+ * max_records are counted but not tabulated.  The text must be shorter than 2^32 bytes. */
+int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes,
+                               uint8_t *d_packed, uint64_t packed_capacity_bytes,
+                               uint64_t *d_rec_base /* [max_records + 1] */,
+                               uint64_t *d_rec_text_pos /* [max_records] or NULL */, uint64_t max_records,
+                               uint64_t *d_counts /* [2] */);
+/* The same, synchronous: out_counts[0..1] receive the counts; MM_ERR_CAPACITY when the bases did not fit
+ * d_packed or the records did not fit the table (the counts say what is needed). */
+int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
+                         uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
+                         uint64_t max_records, uint64_t *d_counts, uint64_t *out_counts /* [2] */);
 /* Deterministic synthetic PackedSeq generator G of BASELINE.md §4, written on the device. */
 int mm_generate_device_async(mm_workspace_t *ws, uint64_t seed, uint64_t first_base,
                              uint64_t n_bases, uint8_t *d_packed /* ceil(n/4) bytes */);

@@ -136,6 +136,26 @@ def pack_ascii(seq: bytes) -> np.ndarray:
     return out
 
 
+def fasta_records(text: bytes) -> list[tuple[int, bytes, bytes]]:
+    """FASTA reader restated (the reference's loader uses needletail::parse_fastx_file, a third-party crate that
+    is not in the tree, and keeps ``r.seq()`` of every record, bench/src/lib.rs:51-82 - parity unpinned): a record
+    starts with '>' at the start of a line; the header runs to the end of that line; the sequence is every
+    following line up to the next header line with '\\n' and '\\r' removed; bytes before the first header are
+    ignored.  Returns (byte offset of '>', header without '>' and line end, sequence) per record."""
+    recs: list[list] = []
+    i, n = 0, len(text)
+    while i < n:
+        j = text.find(b"\n", i)
+        end = n if j < 0 else j
+        line = text[i:end]
+        if line[:1] == b">":
+            recs.append([i, line[1:].rstrip(b"\r"), bytearray()])
+        elif recs:
+            recs[-1][2] += line.replace(b"\r", b"")
+        i = end + 1
+    return [(p, bytes(h), bytes(q)) for p, h, q in recs]
+
+
 def gen_packed(seed: int, n: int, first_base: int = 0) -> np.ndarray:
     out = np.zeros((n + 3) // 4 + 16, dtype=np.uint8)
     if n:

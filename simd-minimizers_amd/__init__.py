@@ -137,6 +137,9 @@ def lib():
         L.mm_host_free.restype = None
         L.mm_pack_ascii_device_async.argtypes = [vp, vp, C.c_uint64, vp]
         L.mm_generate_device_async.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+        fasta_args = [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, C.c_uint64, vp]
+        L.mm_fasta_pack_device_async.argtypes = fasta_args
+        L.mm_fasta_pack_device.argtypes = fasta_args + [u64p]
         _lib = L
     return _lib
 
@@ -155,7 +158,7 @@ EXPORTED_SYMBOLS = [
     "mm_run_skip_ambiguous_host_ascii", "mm_run_reads_skip_ambiguous_device_async",
     "mm_run_reads_skip_ambiguous_device", "mm_pack_ascii_n_device_async", "mm_pack_ascii_device_async",
     "mm_host_alloc", "mm_host_free",
-    "mm_generate_device_async",
+    "mm_generate_device_async", "mm_fasta_pack_device_async", "mm_fasta_pack_device",
 ]
 
 
@@ -712,6 +715,74 @@ def minimizer_positions(seq, k, w):  # src/lib.rs:639
 
 def canonical_minimizer_positions(seq, k, w):  # src/lib.rs:652
     return canonical_minimizers(k, w).run_once(seq)
+
+
+class FastaRecords:
+    """Records of a FASTA text packed on the device (``fasta_pack_device``): ``packed`` = one 2-bit buffer holding
+    all sequences back to back, ``base`` = the n + 1 base offsets delimiting them, ``text_pos`` = byte offset of
+    every record's '>' in the text."""
+
+    def __init__(self, packed, base, text_pos):
+        self.packed, self.base, self.text_pos = packed, base, text_pos
+
+    def __len__(self):
+        return len(self.base) - 1
+
+    def lengths(self):
+        return [int(self.base[i + 1] - self.base[i]) for i in range(len(self))]
+
+    def views(self):
+        """(tensor, base_offset, n_bases) per record, as ``run_batch_device`` takes them."""
+        out = []
+        for i in range(len(self)):
+            b, e = int(self.base[i]), int(self.base[i + 1])
+            out.append((self.packed[b // 4:], b % 4, e - b))
+        return out
+
+    def header(self, text: bytes, i: int) -> bytes:
+        """The header line of record i (without '>' and line end), sliced from the host copy of the text."""
+        p = int(self.text_pos[i]) + 1
+        q = text.find(b"\n", p)
+        return text[p:len(text) if q < 0 else q].rstrip(b"\r")
+
+
+def fasta_pack_device(text, max_records: int = 1 << 16, device: int = 0) -> FastaRecords:
+    """needletail::parse_fastx_file + PackedSeqVec::from_ascii of every record (bench/src/lib.rs:51-82) on the
+    device: ``text`` = the FASTA file's bytes (bytes / numpy uint8 / torch uint8 CUDA tensor)."""
+    import torch
+
+    dev = f"cuda:{device}"
+    if isinstance(text, (bytes, bytearray)):
+        text = np.frombuffer(bytes(text), dtype=np.uint8).copy()
+    if isinstance(text, np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(text)).to(dev) if text.size else torch.zeros(0, dtype=torch.uint8, device=dev)
+    else:
+        t = text
+    n = int(t.numel())
+    ws = default_workspace(device)
+    packed = torch.empty((n // 4 + 8 + 3) // 4 * 4 + 64, dtype=torch.uint8, device=dev)
+    rec_base = torch.zeros(max_records + 1, dtype=torch.int64, device=dev)
+    rec_pos = torch.zeros(max(max_records, 1), dtype=torch.int64, device=dev)
+    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize(device)
+    out = (C.c_uint64 * 2)()
+    code = lib().mm_fasta_pack_device(ws.h, C.c_void_p(t.data_ptr()) if n else None, n, C.c_void_p(packed.data_ptr()),
+                                      packed.numel() // 4 * 4, C.c_void_p(rec_base.data_ptr()),
+                                      C.c_void_p(rec_pos.data_ptr()), max_records, C.c_void_p(counts.data_ptr()), out)
+    if code == ERR["CAPACITY"]:
+        raise MinimizerError(code, f"{out[1]} records > max_records {max_records}")
+    _check(code)
+    n_rec = int(out[1])
+    return FastaRecords(packed, rec_base[: n_rec + 1].cpu().numpy().astype(np.uint64),
+                        rec_pos[:n_rec].cpu().numpy().astype(np.uint64))
+
+
+def run_fasta_device(builder: "Builder", records: FastaRecords, out_pos, out_sk=None):
+    """All records of a packed FASTA (``fasta_pack_device``) with one plan in one launch (``mm_run_batch_device``);
+    record-local positions back to back in ``out_pos``; returns the n + 1 offsets."""
+    v = records.views()
+    return run_batch_device(builder, [t for t, _, _ in v], [m for _, _, m in v], out_pos, out_sk,
+                            base_offsets=[o for _, o, _ in v])
 
 
 def generate_device(n_bases: int, seed: int, device: int = 0, first_base: int = 0):

@@ -96,6 +96,11 @@ int launch_pack_ascii_n(const uint8_t *d_ascii, uint64_t n, uint8_t *d_packed, u
 // bit i of d_out = window i (bases [i, i+l)) holds an ambiguous base; windows [win_begin-1, win_end)
 int launch_window_ambiguity(const uint32_t *d_amb, uint32_t amb_dwords, uint64_t bit0, uint32_t l,
                             uint64_t win_begin, uint64_t win_end, uint32_t *d_out, hipStream_t stream);
+// ---- FASTA text -> packed records (mm_fasta.hip)
+uint64_t fasta_scratch_bytes(uint64_t n_bytes);
+int launch_fasta_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed, uint64_t packed_capacity_bytes,
+                      unsigned long long *d_rec_base, unsigned long long *d_rec_pos, uint64_t max_records,
+                      unsigned long long *d_counts, void *scratch, hipStream_t stream);
 int launch_generate(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d_packed,
                     hipStream_t stream);
 

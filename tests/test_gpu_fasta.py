@@ -1,0 +1,153 @@
+"""FASTA text -> PackedSeq records on the device (mm_fasta_pack_device, the loader step in front of the path:
+needletail::parse_fastx_file + PackedSeqVec::from_ascii per record in the reference's harness,
+bench/src/lib.rs:51-82), bit-exact against the oracle's restatement of that reader, and end to end through
+mm_run_batch_device."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def expect(oracle, text):
+    recs = oracle.fasta_records(text)
+    seq = b"".join(s for _, _, s in recs)
+    base = np.cumsum([0] + [len(s) for _, _, s in recs]).astype(np.uint64)
+    return recs, seq, base, oracle.pack_ascii(seq)[: (len(seq) + 3) // 4]
+
+
+def check(sm, oracle, text, **kw):
+    recs, seq, base, packed = expect(oracle, text)
+    got = sm.fasta_pack_device(text, **kw)
+    assert len(got) == len(recs), (len(got), len(recs))
+    assert np.array_equal(got.base, base)
+    assert [int(p) for p in got.text_pos] == [p for p, _, _ in recs]
+    assert np.array_equal(got.packed[: len(packed)].cpu().numpy(), packed)
+    for i, (_, h, _) in enumerate(recs):
+        assert got.header(bytes(text), i) == h
+    return got
+
+
+def test_fasta_known_cases(sm, oracle, gpu):
+    for text in [
+        b">chr1 test\nACGT\nAC\n",
+        b">a\r\nACGT\r\nGG\r\n>b\r\nTT",            # CRLF, no newline at the end
+        b"junk before\n>chr1\nACGTNNNN\n\n\nacgt\n>c2\n>c3\nGG>T\nA",  # blank lines, empty record, '>' inside a line
+        b"",
+        b"\n",
+        b"ACGT\nACGT\n",                            # no header at all: nothing
+        b">only a header",
+        b">h\n",
+        b">\n>\n>\nA",
+        b">x\n" + b"ACGT" * 5000,                   # one long line
+        b">" + b"h" * 40000 + b"\nACGT\n",          # a header longer than two chunks
+        b">x\n" + b"\n".join(b"ACGTTGCA"[: 1 + i % 8] for i in range(9000)) + b"\n>y\nGATTACA\n",
+    ]:
+        check(sm, oracle, text)
+
+
+def random_fasta(rng, n_target):
+    out = bytearray()
+    if rng.random() < 0.2:
+        out += b"preamble\n"
+    while len(out) < n_target:
+        out += b">" + bytes(rng.choice(list(b"abc XYZ>09|"), size=int(rng.integers(0, 40))).astype(np.uint8)) + (
+            b"\r\n" if rng.random() < 0.2 else b"\n")
+        m = int(rng.choice([0, 1, 5, 70, 4000, 20000, 70000]))
+        m = int(rng.integers(0, m + 1))
+        seq = rng.choice(list(b"ACGTacgtN"), size=m).astype(np.uint8).tobytes()
+        width = int(rng.choice([1, 7, 60, 61, 80, 1000, 10 ** 6]))
+        nl = b"\r\n" if rng.random() < 0.2 else b"\n"
+        lines = [seq[i:i + width] for i in range(0, m, width)]
+        out += nl.join(lines)
+        if rng.random() < 0.9:
+            out += nl
+        if rng.random() < 0.1:
+            out += b"\n\n"
+    return bytes(out)
+
+
+def test_fasta_random(sm, oracle, gpu):
+    rng = np.random.default_rng(2024)
+    sizes = [1, 15, 16, 17, 4095, 4096, 4097, 16383, 16384, 16385, 32768, 65536 + 3, 200_000, 1_000_000]
+    for i in range(60):
+        text = random_fasta(rng, sizes[i % len(sizes)])
+        cut = int(rng.integers(0, 3))
+        if cut == 1 and len(text) > 8:  # end somewhere inside
+            text = text[: int(rng.integers(1, len(text)))]
+        check(sm, oracle, text)
+
+
+def test_fasta_unaligned_text_and_limits(sm, oracle, gpu):
+    import torch
+    rng = np.random.default_rng(7)
+    text = random_fasta(rng, 100_000)
+    buf = torch.zeros(len(text) + 64, dtype=torch.uint8, device="cuda")
+    recs, seq, base, packed = expect(oracle, text)
+    for off in (1, 3, 8, 15):
+        buf[off: off + len(text)] = torch.from_numpy(np.frombuffer(text, dtype=np.uint8).copy()).cuda()
+        got = sm.fasta_pack_device(buf[off: off + len(text)])
+        assert np.array_equal(got.base, base)
+        assert np.array_equal(got.packed[: len(packed)].cpu().numpy(), packed)
+    with pytest.raises(sm.MinimizerError):
+        sm.fasta_pack_device(b">a\nA\n>b\nC\n>c\nG\n", max_records=2)
+
+
+def test_fasta_to_minimizers(sm, oracle, gpu):
+    """FASTA -> packed records -> one batch launch: record-local canonical minimizers == the oracle per record."""
+    import torch
+    rng = np.random.default_rng(11)
+    lens = [250_000, 0, 1, 40, 41, 99_999, 1_000_003, 7]
+    parts = []
+    for i, m in enumerate(lens):
+        seq = rng.choice(list(b"ACGT"), size=m).astype(np.uint8).tobytes()
+        parts.append(b">contig%d some text\n" % i + b"\n".join(seq[j:j + 60] for j in range(0, m, 60)) + b"\n")
+    text = b"".join(parts)
+    recs = sm.fasta_pack_device(text)
+    assert recs.lengths() == lens
+    k, w = 21, 11
+    b = sm.canonical_minimizers(k, w)
+    out = torch.zeros(sum(lens) // 4 + 1024, dtype=torch.int32, device="cuda")
+    offs = sm.run_fasta_device(b, recs, out)
+    host = out.cpu().numpy().view(np.uint32)
+    for i, (_, _, seq) in enumerate(oracle.fasta_records(text)):
+        exp = oracle.run(oracle.pack_ascii(seq), len(seq), k, w, canonical=True)
+        assert np.array_equal(host[offs[i]: offs[i + 1]], exp), i
+
+
+def test_fasta_large_against_ascii_pack(sm, oracle, gpu):
+    """300 MB of text (18 000 chunks: the chunk scans run over many groups per wave): the packed records equal
+    mm_pack_ascii of the sequence bytes selected on the device with torch, and the record table matches the
+    construction."""
+    import ctypes as C
+    import torch
+    n, width, n_rec = 300_000_000, 70, 24
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    t = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")[torch.randint(0, 4, (n,), device="cuda", generator=g)]
+    i = torch.arange(n, device="cuda")
+    t[i % (width + 1) == width] = 10
+    del i
+    keep = t != 10
+    starts = []
+    for r in range(n_rec):
+        p = (n // n_rec) * r + (r * 7919) % 50
+        hdr = b">record %d\n" % r
+        if p:
+            t[p - 1] = 10
+            keep[p - 1] = False
+        t[p: p + len(hdr)] = torch.tensor(list(hdr), dtype=torch.uint8, device="cuda")
+        keep[p: p + len(hdr)] = False
+        starts.append(p)
+    keep &= t != 10
+    seq = t[keep]
+    m = int(seq.numel())
+    exp = torch.zeros((m + 3) // 4 + 64, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    sm._check(sm.lib().mm_pack_ascii_device_async(gpu.h, C.c_void_p(seq.data_ptr()), m, C.c_void_p(exp.data_ptr())))
+    gpu.sync()
+    got = sm.fasta_pack_device(t)
+    assert len(got) == n_rec and int(got.base[-1]) == m
+    assert [int(p) for p in got.text_pos] == starts
+    before = torch.cumsum(keep.to(torch.int64), 0)
+    assert [int(b) for b in got.base[:-1]] == [int(before[p].item()) for p in starts]
+    assert torch.equal(got.packed[: (m + 3) // 4], exp[: (m + 3) // 4])

@@ -282,3 +282,11 @@ def test_alternative_hashers_naive_equals_streaming(oracle):
         for j in range(k):
             v = (v << 2) | (codes[i + j] ^ (3 if j == 0 else 0))
         assert int(hv[i]) == v << (32 - 2 * k)
+
+
+def test_fasta_reader_restatement(oracle):
+    """The FASTA reader the device packer is checked against (needletail is not in the tree: parity unpinned)."""
+    recs = oracle.fasta_records(b"junk\n>chr1 test\r\nACGT\r\nAC\n\n>c2\n>c3\nGG>T\nA")
+    assert recs == [(5, b"chr1 test", b"ACGTAC"), (27, b"c2", b""), (31, b"c3", b"GG>TA")]
+    assert oracle.fasta_records(b"") == [] and oracle.fasta_records(b"ACGT\n") == []
+    assert oracle.fasta_records(b">x") == [(0, b"x", b"")]
