@@ -7,7 +7,7 @@
 //
 // All records are packed back to back into ONE 2-bit buffer (record r = bases [rec_base[r], rec_base[r+1]) of it,
 // any base offset - what mm_run_batch_device takes), so the job is a stream compaction of the text:
-//   K1  per 16 KB chunk: position of its last '\n' and of its last record start (context-free: a '>' right after
+//   K1  per 32 KB chunk: position of its last '\n' and of its last record start (context-free: a '>' right after
 //       a '\n' starts a record whatever came before)
 //   S1  exclusive max-scan of both over the chunks (one workgroup) -> the line / record context at every chunk start
 //   K2  per chunk, now with its context: number of sequence bytes and of record starts
@@ -23,7 +23,7 @@ namespace mm {
 namespace {
 
 constexpr uint32_t kIterBytes = 16u * kBlockThreads;  // 4096: one 16-byte piece per thread
-constexpr uint32_t kIters = 4;                        // pieces a workgroup walks one after the other
+constexpr uint32_t kIters = 8;                        // pieces a workgroup walks one after the other (all loaded up front)
 constexpr uint32_t kChunkBytes = kIterBytes * kIters;
 constexpr int kScanThreads = 1024;
 
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kBlockThreads) void fasta_marks_kernel(const uint8_
     }
 }
 
-// S1 / S2: exclusive scans of TWO arrays of `n` values by ONE workgroup (n <= 2^18 chunks for a 4 GB text);
+// S1 / S2: exclusive scans of TWO arrays of `n` values by ONE workgroup (n <= 2^17 chunks for a 4 GB text);
 // out[n] = total.  Every wave owns a contiguous slab: it reduces it (coalesced groups of 64, loads independent),
 // the sixteen slab totals are combined through LDS, then the wave scans its slab group by group.
 template <class Op>
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kBlockThreads) void fasta_walk_kernel(
     }
     if (!PACK) {
         uint32_t tot;
-        block_sum_excl((my_recs << 16) | my_bases, s, tot);  // (at most 64 x 256 bases: the low half holds 16384)
+        block_sum_excl((my_recs << 16) | my_bases, s, tot);  // (a chunk holds at most 32768 bases: they fit the low half)
         if (tid == 0) {
             cnt_bases[blockIdx.x] = tot & 0xffffu;
             cnt_recs[blockIdx.x] = tot >> 16;

@@ -39,7 +39,7 @@ def test_fasta_known_cases(sm, oracle, gpu):
         b">h\n",
         b">\n>\n>\nA",
         b">x\n" + b"ACGT" * 5000,                   # one long line
-        b">" + b"h" * 40000 + b"\nACGT\n",          # a header longer than two chunks
+        b">" + b"h" * 100000 + b"\nACGT\n",         # a header longer than three chunks
         b">x\n" + b"\n".join(b"ACGTTGCA"[: 1 + i % 8] for i in range(9000)) + b"\n>y\nGATTACA\n",
     ]:
         check(sm, oracle, text)
@@ -68,8 +68,8 @@ def random_fasta(rng, n_target):
 
 def test_fasta_random(sm, oracle, gpu):
     rng = np.random.default_rng(2024)
-    sizes = [1, 15, 16, 17, 4095, 4096, 4097, 16383, 16384, 16385, 32768, 65536 + 3, 200_000, 1_000_000]
-    for i in range(60):
+    sizes = [1, 15, 16, 17, 4095, 4096, 4097, 16383, 16384, 16385, 32767, 32768, 32769, 65536 + 3, 200_000, 1_000_000]
+    for i in range(64):
         text = random_fasta(rng, sizes[i % len(sizes)])
         cut = int(rng.integers(0, 3))
         if cut == 1 and len(text) > 8:  # end somewhere inside
@@ -115,7 +115,7 @@ def test_fasta_to_minimizers(sm, oracle, gpu):
 
 
 def test_fasta_large_against_ascii_pack(sm, oracle, gpu):
-    """300 MB of text (18 000 chunks: the chunk scans run over many groups per wave): the packed records equal
+    """300 MB of text (9 000 chunks: the chunk scans run over many groups per wave): the packed records equal
     mm_pack_ascii of the sequence bytes selected on the device with torch, and the record table matches the
     construction."""
     import ctypes as C
