@@ -48,8 +48,9 @@ typedef enum mm_hasher_kind { MM_HASHER_NT = 0, MM_HASHER_MUL = 1, MM_HASHER_ANT
 /* Builder<_, _, _, SYNCMER> (src/lib.rs:221-225): 0 minimizers, 1 closed, 2 open syncmers */
 typedef enum mm_mode { MM_MINIMIZERS = 0, MM_CLOSED_SYNCMERS = 1, MM_OPEN_SYNCMERS = 2 } mm_mode_t;
 
-/* Which kernel family a run used (diagnostics; both are HIP kernels). */
-typedef enum mm_path { MM_PATH_FUSED = 1, MM_PATH_GENERIC = 2 } mm_path_t;
+/* Which kernel family a run used (diagnostics; all are HIP kernels).  MM_PATH_SPLIT is the fused family's
+ * two-stream form: the same walk, its lists expanded to positions by a second, concurrent kernel. */
+typedef enum mm_path { MM_PATH_FUSED = 1, MM_PATH_GENERIC = 2, MM_PATH_SPLIT = 3 } mm_path_t;
 
 typedef struct mm_plan mm_plan_t;           /* immutable (k, w, hasher, mode): the Builder     */
 typedef struct mm_workspace mm_workspace_t; /* per-stream device scratch: the thread-local CACHE
@@ -69,6 +70,7 @@ enum {
     MM_ERR_BAD_MODE = -9,             /* src/lib.rs:437; super-k-mers with syncmers, src/lib.rs:339 */
     MM_ERR_NULL = -10,
     MM_ERR_VALUE_LEN = -11,           /* values_u64 needs len <= 32, values_u128 len <= 64 */
+    MM_ERR_FORMAT = -12,              /* mm_fasta_pack_device: the text is FASTQ ('@' first), not FASTA */
     MM_ERR_NO_DEVICE = -20,           /* no HIP device: the engine has no CPU fallback */
     MM_ERR_HIP = -21,                 /* a HIP call failed; see mm_last_error() */
     MM_ERR_ALLOC = -22,
@@ -329,7 +331,10 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
                                uint64_t *d_rec_text_pos /* [max_records] or NULL */, uint64_t max_records,
                                uint64_t *d_counts /* [2] */);
 /* The same, synchronous: out_counts[0..1] receive the counts; MM_ERR_CAPACITY when the bases did not fit
- * d_packed or the records did not fit the table (the counts say what is needed). */
+ * d_packed or the records did not fit the table (the counts say what is needed: out_counts[0] against
+ * 4 * packed_capacity_bytes, out_counts[1] against max_records).  A text whose first non-blank byte is '@'
+ * is FASTQ, which the reference's loader also reads and this packer does not: MM_ERR_FORMAT, nothing is
+ * packed (the asynchronous entry point does not look and would pack no record from it). */
 int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
                          uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
                          uint64_t max_records, uint64_t *d_counts, uint64_t *out_counts /* [2] */);

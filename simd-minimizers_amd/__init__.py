@@ -18,13 +18,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsimd_minimizers_amd.so")
 
 MM_MINIMIZERS, MM_CLOSED_SYNCMERS, MM_OPEN_SYNCMERS = 0, 1, 2
-PATH_FUSED, PATH_GENERIC = 1, 2
+PATH_FUSED, PATH_GENERIC, PATH_SPLIT = 1, 2, 3
 U64_MAX = (1 << 64) - 1
 
 ERR = {
     "W_ZERO": -1, "W_TOO_LARGE": -2, "LEN_TOO_LARGE": -3, "EVEN_L": -4,
     "HASHER_NOT_CANONICAL": -5, "OPEN_EVEN_W": -6, "K_ZERO": -7, "CAPACITY": -8, "BAD_MODE": -9,
-    "NULL": -10, "VALUE_LEN": -11, "NO_DEVICE": -20, "HIP": -21, "ALLOC": -22, "ORDER": -23,
+    "NULL": -10, "VALUE_LEN": -11, "FORMAT": -12, "NO_DEVICE": -20, "HIP": -21, "ALLOC": -22, "ORDER": -23,
 }
 
 
@@ -770,7 +770,9 @@ def fasta_pack_device(text, max_records: int = 1 << 16, device: int = 0) -> Fast
                                       packed.numel() // 4 * 4, C.c_void_p(rec_base.data_ptr()),
                                       C.c_void_p(rec_pos.data_ptr()), max_records, C.c_void_p(counts.data_ptr()), out)
     if code == ERR["CAPACITY"]:
-        raise MinimizerError(code, f"{out[1]} records > max_records {max_records}")
+        if out[1] > max_records:
+            raise MinimizerError(code, f"{out[1]} records > max_records {max_records}")
+        raise MinimizerError(code, f"{out[0]} bases do not fit the packed buffer of {packed.numel() // 4 * 4} bytes")
     _check(code)
     n_rec = int(out[1])
     return FastaRecords(packed, rec_base[: n_rec + 1].cpu().numpy().astype(np.uint64),

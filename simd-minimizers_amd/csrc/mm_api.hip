@@ -108,6 +108,10 @@ struct mm_workspace {
                                             // [2] low word = sticky error flag (mm_workspace_check)
     unsigned long long *h_total = nullptr;  // pinned copy of both words
     bool force_ticket = false;
+    bool async_unchecked = false;  // an *_async run was issued since the last mm_workspace_check
+    // split path (walk + expander on a second stream): dump slots, tile status, redo list, fork / join events
+    mm::SplitBuffers split;
+    bool no_split = false;  // the split path failed once on this workspace: fused kernel from then on
     // generic-path scratch
     void *scratch = nullptr;
     uint64_t scratch_bytes = 0;
@@ -168,6 +172,52 @@ int grow(T *&ptr, uint64_t &have, uint64_t need, size_t elem) {
     return MM_OK;
 }
 
+// The tile status words.  MM_STATUS_TIGHT=1 (tests) allocates exactly what the launcher asked for, without
+// the slack of grow(), so that an under-sized request cannot hide behind it.
+int grow_status(mm_workspace *ws, uint64_t need) {
+    static const bool tight = getenv("MM_STATUS_TIGHT") != nullptr;
+    if (!tight) return grow(ws->status, ws->status_words, need, sizeof(unsigned long long));
+    if (ws->status && ws->status_words == need) return MM_OK;
+    if (ws->status) MM_HIP(hipFree(ws->status));
+    ws->status = nullptr;
+    ws->status_words = 0;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, need * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return MM_ERR_ALLOC;
+    }
+    ws->status = reinterpret_cast<unsigned long long *>(p);
+    ws->status_words = need;
+    return MM_OK;
+}
+
+// Buffers, second stream and events of the split path, grown to what the run needs.
+int prepare_split(mm_workspace *ws, uint64_t tiles, uint64_t dump_bytes) {
+    mm::SplitBuffers &b = ws->split;
+    if (!b.aux) {
+        int lo = 0, hi = 0;
+        MM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        MM_HIP(hipStreamCreateWithPriority(&b.aux, hipStreamNonBlocking, hi));
+        MM_HIP(hipEventCreateWithFlags(&b.ev_fork, hipEventDisableTiming));
+        MM_HIP(hipEventCreateWithFlags(&b.ev_join, hipEventDisableTiming));
+        void *p = nullptr;
+        MM_HIP(hipMalloc(&p, 64));
+        b.redo_n = reinterpret_cast<uint32_t *>(p);
+        b.carry = reinterpret_cast<unsigned long long *>(p) + 1;
+    }
+    int r = grow(b.dump, b.dump_bytes, dump_bytes, 1);
+    if (r) return r;
+    r = grow(b.tile_status, b.status_words, tiles, sizeof(unsigned long long));
+    if (r) return r;
+    uint8_t *rl = reinterpret_cast<uint8_t *>(b.redo_list);
+    uint64_t have = b.redo_entries;
+    r = grow(rl, have, tiles, 16);
+    b.redo_list = rl;
+    b.redo_entries = have;
+    return r;
+}
+
 int make_view(const void *d_packed, uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
               mm::SeqView *v) {
     uintptr_t a = reinterpret_cast<uintptr_t>(d_packed);
@@ -204,7 +254,17 @@ int collect_timing(mm_workspace *ws) {
 int judge_run_error(mm_workspace *ws) {
     const uint32_t code = (uint32_t)ws->h_total[1];
     if (code == 0) return 0;
+    // The synchronous caller learns of this error right here (it repeats the run or returns the code), so the
+    // sticky word the kernel raised with it (flag_error) is not news for mm_workspace_check - unless an
+    // asynchronous run that has not been checked yet may have raised it too (then the check reports it: at
+    // worst valid work is repeated).
+    if (!ws->async_unchecked) (void)hipMemsetAsync(ws->total + 2, 0, sizeof(unsigned long long), ws->stream);
     if (code == 1u) {
+        if (ws->last_path == MM_PATH_SPLIT && !ws->no_split) {
+            // the expander gave up waiting for a tile of the walk: this workspace keeps to the fused kernel
+            ws->no_split = true;
+            return 1;
+        }
         if (ws->force_ticket) {
             g_last_error = "look-back scan timed out in ticket mode";
             return MM_ERR_HIP;
@@ -237,6 +297,7 @@ const char *mm_strerror(int code) {
         case MM_ERR_BAD_MODE: return "bad mode (or super-k-mers requested with syncmers)";
         case MM_ERR_NULL: return "null argument";
         case MM_ERR_VALUE_LEN: return "values_u64 needs 1 <= len <= 32";
+        case MM_ERR_FORMAT: return "FASTQ text (first record starts with '@'): only FASTA is packed on the device";
         case MM_ERR_NO_DEVICE: return "no HIP device (this engine has no CPU fallback)";
         case MM_ERR_HIP: return "HIP call failed";
         case MM_ERR_ALLOC: return "device allocation failed";
@@ -380,6 +441,13 @@ void mm_workspace_destroy(mm_workspace_t *ws) {
         hipEventDestroy(ev.second);
     }
     if (ws->status) hipFree(ws->status);
+    if (ws->split.dump) hipFree(ws->split.dump);
+    if (ws->split.tile_status) hipFree(ws->split.tile_status);
+    if (ws->split.redo_list) hipFree(ws->split.redo_list);
+    if (ws->split.redo_n) hipFree(ws->split.redo_n);  // (redo_n and carry share one allocation)
+    if (ws->split.ev_fork) hipEventDestroy(ws->split.ev_fork);
+    if (ws->split.ev_join) hipEventDestroy(ws->split.ev_join);
+    if (ws->split.aux) hipStreamDestroy(ws->split.aux);
     if (ws->ticket) hipFree(ws->ticket);
     if (ws->total) hipFree(ws->total);
     if (ws->h_total) hipHostFree(ws->h_total);
@@ -418,12 +486,14 @@ int mm_workspace_check(mm_workspace_t *ws) {
                           ws->stream));
     MM_HIP(hipStreamSynchronize(ws->stream));
     const uint32_t code = (uint32_t)ws->h_total[2];
+    ws->async_unchecked = false;
     if (code == 0) return MM_OK;
     MM_HIP(hipMemsetAsync(ws->total + 2, 0, sizeof(unsigned long long), ws->stream));
     if (code == 1u) {
         // workgroups were not dispatched in index order: every later run on this workspace takes its
         // tile ids from an atomic ticket; the caller repeats the runs since the last check
         ws->force_ticket = true;
+        ws->no_split = true;
         g_last_error = "a look-back scan timed out in an asynchronous run: its output is invalid";
         return MM_ERR_ORDER;
     }
@@ -569,10 +639,25 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
             a.timing_stop = e1;
         }
         int lr = 0;
-        if (fused) {
-            r = grow(ws->status, ws->status_words, mm::fused_status_words(a), sizeof(unsigned long long));
+        bool split = false;
+        if (fused && !ws->no_split && mm::split_wanted(a)) {
+            // split path: the walk dumps its lists, expander workgroups on a second stream write the positions
+            uint64_t tiles = 0, dump_bytes = 0;
+            mm::split_requirements(a, &tiles, &dump_bytes);
+            if (tiles) {
+                r = prepare_split(ws, tiles, dump_bytes);
+                if (r) return r;
+                a.out.status = nullptr;
+                lr = mm::launch_split(a, ws->split, ws->stream);
+                split = lr == 0;
+                if (lr == -2) lr = 0;  // no walk kernel for this plan: the fused kernel below
+            }
+        }
+        if (fused && !split && lr == 0) {
+            r = grow_status(ws, mm::fused_status_words(a));
             if (r) return r;
             a.out.status = ws->status;
+            a.status_avail = ws->status_words;
             lr = mm::launch_fused(a, ws->stream);
             if (lr == -2) {
                 // no prebuilt instance and the run-time specialisation is unavailable: generic family
@@ -590,8 +675,7 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
             ws->scratch = sp;
             if (r) return r;
             a.scratch = ws->scratch;
-            r = grow(ws->status, ws->status_words, mm::generic_status_words(a.generic_round_windows),
-                     sizeof(unsigned long long));
+            r = grow_status(ws, mm::generic_status_words(a.generic_round_windows));
             if (r) return r;
             a.out.status = ws->status;
             lr = mm::launch_generic(a, ws->stream);
@@ -600,7 +684,7 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
             g_last_error = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
             return MM_ERR_HIP;
         }
-        ws->last_path = fused ? MM_PATH_FUSED : MM_PATH_GENERIC;
+        ws->last_path = fused ? (split ? MM_PATH_SPLIT : MM_PATH_FUSED) : MM_PATH_GENERIC;
     }
     if (d_count)
         MM_HIP(hipMemcpyAsync(d_count, ws->total, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
@@ -612,6 +696,7 @@ int mm_run_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d
                         uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
                         uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
                         uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_count) {
+    if (ws) ws->async_unchecked = true;
     return run_device_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin,
                                  win_end, d_out_pos, d_out_sk, capacity, d_count, false);
 }
@@ -717,9 +802,10 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
     a.batch_tile_seq = ws->batch_tiles;
     a.batch_offsets = ws->batch_offsets;
     a.batch_tiles = n_tiles;
-    r = grow(ws->status, ws->status_words, (n_tiles + 8) * mm::fused_status_stride(), sizeof(unsigned long long));
+    r = grow_status(ws, (n_tiles + 8) * mm::fused_status_stride());
     if (r) return r;
     a.out.status = ws->status;
+    a.status_avail = ws->status_words;
 
     std::vector<unsigned long long> offs(n_seqs + 1);
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -875,7 +961,7 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
             if (r) return r;
             a.wamb = ws->wamb;
         }
-        r = grow(ws->status, ws->status_words, mm::fused_reads_status_words(a), sizeof(unsigned long long));
+        r = grow_status(ws, mm::fused_reads_status_words(a));
         if (r) return r;
         a.out.status = ws->status;
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -933,6 +1019,7 @@ int mm_run_reads_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const v
                               uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
                               uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
                               uint64_t *d_count) {
+    if (ws) ws->async_unchecked = true;
     return run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride,
                                 read_len, d_read_lens, d_out_pos, capacity, d_out_offsets, d_count);
 }
@@ -974,6 +1061,7 @@ int mm_run_reads_superkmers_device_async(const mm_plan_t *plan, mm_workspace_t *
                                          uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
                                          uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
                                          uint64_t *d_out_offsets, uint64_t *d_count) {
+    if (ws) ws->async_unchecked = true;
     if (!d_out_sk) return MM_ERR_NULL;
     return run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride,
                                 read_len, d_read_lens, d_out_pos, capacity, d_out_offsets, d_count, nullptr,
@@ -997,6 +1085,7 @@ int mm_run_reads_skip_ambiguous_device_async(const mm_plan_t *plan, mm_workspace
                                              uint32_t read_len, const uint32_t *d_read_lens,
                                              uint32_t *d_out_pos, uint64_t capacity,
                                              uint64_t *d_out_offsets, uint64_t *d_count) {
+    if (ws) ws->async_unchecked = true;
     const AmbArgs amb{d_amb, amb_bytes, amb_offset};
     return run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride,
                                 read_len, d_read_lens, d_out_pos, capacity, d_out_offsets, d_count, &amb);
@@ -1019,6 +1108,7 @@ int mm_run_skip_ambiguous_device_async(const mm_plan_t *plan, mm_workspace_t *ws
                                        uint64_t amb_bytes, uint64_t amb_offset, uint64_t n_bases,
                                        uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
                                        uint64_t capacity, uint64_t *d_count) {
+    if (ws) ws->async_unchecked = true;
     const AmbArgs amb{d_amb, amb_bytes, amb_offset};
     return run_device_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin,
                                  win_end, d_out_pos, nullptr, capacity, d_count, false, &amb);
@@ -1462,6 +1552,20 @@ int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_b
                          uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
                          uint64_t max_records, uint64_t *d_counts, uint64_t *out_counts) {
     if (!out_counts) return MM_ERR_NULL;
+    if (ws && d_text && n_bytes) {
+        // FASTQ starts with '@' where FASTA starts with '>' (needletail tells them apart the same way)
+        unsigned char head[256];
+        const size_t nh = n_bytes < sizeof head ? (size_t)n_bytes : sizeof head;
+        MM_HIP(hipSetDevice(ws->device));
+        MM_HIP(hipMemcpyAsync(head, d_text, nh, hipMemcpyDeviceToHost, ws->stream));
+        MM_HIP(hipStreamSynchronize(ws->stream));
+        size_t i = 0;
+        while (i < nh && (head[i] == ' ' || head[i] == '\t' || head[i] == '\r' || head[i] == '\n')) ++i;
+        if (i < nh && head[i] == '@') {
+            g_last_error = "mm_fasta_pack_device: the text starts with '@' (FASTQ)";
+            return MM_ERR_FORMAT;
+        }
+    }
     const int r = mm_fasta_pack_device_async(ws, d_text, n_bytes, d_packed, packed_capacity_bytes, d_rec_base,
                                              d_rec_text_pos, max_records, d_counts);
     if (r) return r;

@@ -6,6 +6,7 @@
 #include "mm_fused_impl.h"
 #include "mm_fused_inst.h"
 #include "mm_launch.h"
+#include "mm_split.h"
 
 #include <cstdlib>
 #include <cstdio>
@@ -225,10 +226,26 @@ bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_c
     return jit_enabled() && w >= 1 && w <= kJitMaxW;
 }
 
+// lower end of the lane lengths tune_whole_rounds may choose from (blocks per lane)
+static uint32_t whole_rounds_lo(uint32_t nblk) { return nblk * 85u / 100u > 6u ? nblk * 85u / 100u : 6u; }
+
 uint64_t fused_status_words(const RunArgs &a) {
-    // (x 1.2: tune_whole_rounds may shorten the lanes by 15 %; + 8: the chunked look-back variant keeps
-    // per-tile counts and per-chunk bases in the same words)
-    return (geometry(a).nblocks * 6 / 5 + 8) * status_stride_host();
+    // Sized for the shortest lanes tune_whole_rounds can pick (it may shorten them to 85 % of the default,
+    // floor, but not below 6 blocks: 8 -> 6 blocks are 1.33 x the tiles), with the same integer arithmetic;
+    // + 8: the chunked look-back variant keeps per-tile counts and per-chunk bases in the same words.
+    // launch_fused checks the tuned grid against RunArgs::status_avail and keeps the default lanes if a
+    // caller reserved less.
+    const Geometry g = geometry(a);
+    uint64_t tiles = g.nblocks;
+    if (!a.batch_tile_seq && a.nblk == 0) {
+        const uint32_t lo = whole_rounds_lo(g.nblk);
+        if (lo < g.nblk) {
+            const uint64_t nwin = a.win_end - a.win_begin, nb = (uint64_t)kFusedThreads * a.w * lo;
+            const uint64_t t = (nwin + nb - 1) / nb;
+            if (t > tiles) tiles = t;
+        }
+    }
+    return (tiles + 8) * status_stride_host();
 }
 uint32_t fused_tile_windows(const RunArgs &a) { return geometry(a).NB; }
 
@@ -269,7 +286,7 @@ static uint32_t whole_rounds_nblk(const RunArgs &a, const KernelRef &kr, const G
         for (sh = 1; (1u << sh) <= a.w;) ++sh;
     double best = 0.0;
     uint32_t best_nb = g.nblk;
-    const uint32_t lo = g.nblk * 85u / 100u > 6u ? g.nblk * 85u / 100u : 6u, hi = g.nblk * 115u / 100u;
+    const uint32_t lo = whole_rounds_lo(g.nblk), hi = g.nblk * 115u / 100u;
     for (uint32_t nb = lo; nb <= hi; ++nb) {
         const uint64_t S = (uint64_t)a.w * nb;
         if (S > 60000u || (sh && (S << sh) > 65536u)) continue;
@@ -326,7 +343,17 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     const KernelRef kr = resolve_kernel(a.w, a.canonical_windows, (int)a.ht.canonical, a.mode,
                                         a.out.sk != nullptr);
     if (!kr) return -2;
-    tune_whole_rounds(a, kr, g);
+    {
+        const Geometry untuned = g;
+        tune_whole_rounds(a, kr, g);
+        // never launch (or clear) more tile status words than the caller allocated: keep the default lanes
+        static const bool strict = getenv("MM_STATUS_STRICT") != nullptr;  // tests: an under-sized request fails
+        if (a.status_avail && (g.nblocks + 8) * status_stride_host() > a.status_avail) {
+            if (strict) return -1;
+            g = untuned;
+        }
+        if (a.status_avail && (g.nblocks + 8) * status_stride_host() > a.status_avail) return -1;
+    }
 
     FusedParams p;
     p.seq = a.seq;
@@ -348,6 +375,11 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.batch_offsets = a.batch_offsets;
     p.batch_n = a.batch_n;
     p.out = a.out;
+    p.dump = nullptr;
+    p.dump_stride = 0;
+    p.tile_status = nullptr;
+    p.redo_list = nullptr;
+    p.redo_n = nullptr;
     p.use_ticket = a.use_ticket ? 1u : 0u;
     {
         const char *dbg = getenv("MM_DEBUG");
@@ -383,6 +415,152 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         return r;
     }
     return launch_kernel(kr, (uint32_t)g.nblocks, lds_bytes + g_lds_pad, stream, p, a.timing_start, a.timing_stop);
+}
+
+// ------------------------------------------------------------------ split path (walk + expander)
+namespace {
+
+// prebuilt walk kernels (mm_walk_inst.hip); everything else is specialised at first use
+}  // namespace
+
+namespace {
+KernelRef resolve_walk_kernel(uint32_t w, int canonical_windows, int hasher_canonical, uint32_t mode, bool sk) {
+    KernelRef kr;
+    if (mode > 2) return kr;
+    const bool force_jit = getenv("MM_JIT_FORCE") != nullptr;
+    int n = 0;
+    const WalkInstance *inst = walk_instances(&n);
+    for (int i = 0; i < n && !force_jit; ++i)
+        if (inst[i].w == w && inst[i].canon == (canonical_windows != 0) && inst[i].hash_rc == (hasher_canonical != 0) &&
+            inst[i].mode == mode && inst[i].sk == (mode == 0 && sk)) {
+            kr.host = inst[i].fn;
+            return kr;
+        }
+    kr.mod = jit_fused_kernel(w, canonical_windows != 0, hasher_canonical != 0, (int)mode, mode == 0 && sk, false,
+                              &t_jit_error, true);
+    return kr;
+}
+
+uint32_t split_dump_stride(const Geometry &g) { return (kSplitHeader + g.lds_bytes + 255u) & ~255u; }
+
+// expander workgroups: enough to keep up with the walk (measured, tools/ubench/concurrent_kernels.hip: 256
+// workgroups move 2.3 TB/s, 512 move 3.6)
+uint32_t split_expanders(const RunArgs &a, uint64_t tiles) {
+    uint32_t e = a.canonical_windows ? 256u : 512u;
+    if (const char *v = getenv("MM_SPLIT_E")) e = (uint32_t)atoi(v);
+    if (e < 1u) e = 1u;
+    if (e > tiles) e = (uint32_t)tiles;
+    return e;
+}
+}  // namespace
+
+void split_requirements(const RunArgs &a, uint64_t *tiles, uint64_t *dump_bytes) {
+    const Geometry g = geometry(a);
+    *tiles = g.nblocks;
+    *dump_bytes = g.nblocks * (uint64_t)split_dump_stride(g);
+    if (g.lds_bytes > kMaxLdsBytes || g.nblocks >= (1ull << 31) || a.batch_tile_seq) *tiles = 0;
+}
+
+bool split_wanted(const RunArgs &a) {
+    if (const char *v = getenv("MM_SPLIT")) return v[0] == '1';
+    return false;
+}
+
+int launch_split(const RunArgs &a, const SplitBuffers &b, hipStream_t stream) {
+    const Geometry g = geometry(a);
+    if (g.nblocks == 0) return 0;
+    if (g.lds_bytes > kMaxLdsBytes || a.batch_tile_seq) return -2;
+    const bool sk = a.out.sk != nullptr && a.mode == 0;
+    const KernelRef kr = resolve_walk_kernel(a.w, a.canonical_windows, (int)a.ht.canonical, a.mode, sk);
+    if (!kr) return -2;
+    const KernelRef redo_kr = resolve_kernel(a.w, a.canonical_windows, (int)a.ht.canonical, a.mode, a.out.sk != nullptr);
+    if (!redo_kr) return -2;
+    const uint32_t stride = split_dump_stride(g);
+    if (g.nblocks * (uint64_t)stride > b.dump_bytes || g.nblocks > b.status_words || g.nblocks > b.redo_entries) return -1;
+
+    FusedParams p;
+    p.seq = a.seq;
+    p.ht = a.ht;
+    p.k = a.k;
+    p.nblk = g.nblk;
+    p.win_begin = (uint32_t)a.win_begin;
+    p.win_end = (uint32_t)a.win_end;
+    p.list_cap = g.list_cap;
+    p.n_reads = 0;
+    p.reads_per_lane = 1;
+    p.read_stride = p.read_len = 0;
+    p.read_lens = nullptr;
+    p.read_offsets = nullptr;
+    p.wamb = a.wamb;
+    p.wamb_dwords = a.wamb_dwords;
+    p.batch_seqs = a.batch_seqs;
+    p.batch_tile_seq = a.batch_tile_seq;
+    p.batch_offsets = a.batch_offsets;
+    p.batch_n = a.batch_n;
+    p.out = a.out;
+    p.use_ticket = 0;
+    {
+        const char *dbg = getenv("MM_DEBUG");
+        p.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
+    }
+    p.trace = nullptr;
+    p.dump = b.dump;
+    p.dump_stride = stride;
+    p.tile_status = b.tile_status;
+    p.redo_list = nullptr;
+    p.redo_n = b.redo_n;
+
+    ExpandParams e;
+    e.dump = b.dump;
+    e.dump_stride = stride;
+    e.tile_status = b.tile_status;
+    e.n_tiles = (uint32_t)g.nblocks;
+    e.S = g.S;
+    e.NB = g.NB;
+    e.list_cap = g.list_cap;
+    e.mode_sub = a.mode == 0 ? 1u : 0u;
+    e.sk_shift = 1;
+    while ((1u << e.sk_shift) <= a.w && e.sk_shift < 8u) ++e.sk_shift;  // kSkShift<W>
+    e.win_begin = (uint32_t)a.win_begin;
+    e.redo_list = reinterpret_cast<RedoEntry *>(b.redo_list);
+    e.redo_n = b.redo_n;
+    e.carry = b.carry;
+    e.debug = p.debug;
+    e.out = a.out;
+
+    // stream `stream`: clear, walk ........................ join, redo
+    // stream `aux`   :        fork -> expander (persistent) -^
+    if (hipMemsetAsync(b.tile_status, 0, sizeof(unsigned long long) * g.nblocks, stream) != hipSuccess) return -1;
+    if (hipMemsetAsync(b.redo_n, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
+    if (hipMemcpyAsync(b.carry, a.out.total, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream) != hipSuccess)
+        return -1;
+    if (a.timing_start) hipEventRecord(a.timing_start, stream);
+    if (hipEventRecord(b.ev_fork, stream) != hipSuccess) return -1;
+    if (hipStreamWaitEvent(b.aux, b.ev_fork, 0) != hipSuccess) return -1;
+    // the walk first: it never waits for anything, so the pair cannot deadlock whatever the hardware does
+    // with the two queues (if they were serialised the expander would simply run after the walk)
+    int r = launch_kernel(kr, (uint32_t)g.nblocks, g.lds_bytes + g_lds_pad, stream, p, nullptr, nullptr);
+    if (r) return r;
+    // timing experiments: MM_SPLIT_SERIAL=1 starts the expander only when the walk has finished (each kernel
+    // alone on the chip), MM_SPLIT_NO_EXPAND=1 leaves it out (wrong results: the walk and its dump alone)
+    static const bool serial = getenv("MM_SPLIT_SERIAL") != nullptr, no_expand = getenv("MM_SPLIT_NO_EXPAND") != nullptr;
+    if (serial) {
+        if (hipEventRecord(b.ev_fork, stream) != hipSuccess) return -1;
+        if (hipStreamWaitEvent(b.aux, b.ev_fork, 0) != hipSuccess) return -1;
+    }
+    if (!no_expand && launch_expand(e, entry8(a), sk, split_expanders(a, g.nblocks), g.lds_bytes, b.aux)) return -1;
+    if (hipEventRecord(b.ev_join, b.aux) != hipSuccess) return -1;
+    if (hipStreamWaitEvent(stream, b.ev_join, 0) != hipSuccess) return -1;
+    // tiles whose lists overflowed (low-complexity sequence): walked again by the fused kernel in redo mode,
+    // one workgroup per entry of the redo list (the grid covers the worst case; the others exit at once)
+    static const bool no_redo = getenv("MM_SPLIT_NO_REDO") != nullptr;  // timing experiment
+    if (!no_redo) {
+        p.redo_list = reinterpret_cast<const RedoEntry *>(b.redo_list);
+        r = launch_kernel(redo_kr, (uint32_t)g.nblocks, g.lds_bytes, stream, p, nullptr, nullptr);
+        if (r) return r;
+    }
+    if (a.timing_stop) hipEventRecord(a.timing_stop, stream);
+    return 0;
 }
 
 // ------------------------------------------------------------------ reads mode
@@ -482,6 +660,11 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.batch_offsets = nullptr;
     p.batch_n = 0;
     p.trace = nullptr;
+    p.dump = nullptr;
+    p.dump_stride = 0;
+    p.tile_status = nullptr;
+    p.redo_list = nullptr;
+    p.redo_n = nullptr;
     p.out = a.out;
     if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (nblocks + 8) * status_stride_host(), stream) != hipSuccess)
         return -1;

@@ -105,7 +105,21 @@ struct FusedParams {
     uint32_t batch_n;
     // timing experiments (MM_TRACE): 4 timestamps per tile (start, phase 1 done, look-back done, end)
     unsigned long long *trace;
+    // split path (walk_kernel + mm_split.hip): the walk dumps its lists and publishes the tile's count
+    uint8_t *dump;                      // n_tiles x dump_stride bytes: 512 bytes of lane counts, then the list rows
+    uint32_t dump_stride;
+    unsigned long long *tile_status;    // one word per tile: kSplitValid | kSplitOverflow | rows << 32 | count
+    const struct RedoEntry *redo_list;  // redo pass (tiles whose lists overflowed): null for the walk itself
+    const uint32_t *redo_n;
     OutParams out;
+};
+
+// split path: status word of a tile and the redo list the expander writes
+constexpr unsigned long long kSplitValid = 1ull << 63, kSplitOverflow = 1ull << 62;
+constexpr uint32_t kSplitHeader = 2u * kFusedThreads;  // bytes: one u16 count per lane in front of the list rows
+struct RedoEntry {
+    uint32_t tile, pad;
+    unsigned long long prefix;  // first output slot of the tile
 };
 
 // inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts
@@ -903,6 +917,214 @@ __device__ __forceinline__ unsigned long long lookback_chunked(unsigned long lon
     return excl;
 }
 
+// Phase 2, the copy-out of one wave: the 64 lists of its lanes (LDS, entry c of lane t at c * stride + eb * t)
+// go to the output in lane order (= window order) from slot run0 on.  `vbt` = value of list entry 0 of the
+// tile's lane 0 (first window of the tile, minus one for minimizer positions; 0 in reads mode), `S` = windows
+// per lane, `kSh` = kSkShift of the window size (super-k-mer entries), `my_count` / `excl` = length of the
+// lane's list and its first slot relative to run0, `wave_total` = sum of the wave's lengths.  Shared by the
+// fused kernel and by the expander of the split path (mm_split.hip).
+template <bool E8, bool SK, bool READS>
+__device__ __forceinline__ void copy_out_wave(const uint8_t *smem, const OutParams &out, const uint32_t debug,
+                                              const int wave, const int lane, const uint32_t vbt, const uint32_t S,
+                                              const uint32_t kSh, const unsigned long long run0,
+                                              const uint32_t wave_total, const uint32_t my_count,
+                                              const uint32_t excl) {
+    constexpr uint32_t kStride = list_stride(E8), kEB = E8 ? 1u : 2u;
+    {
+    // Copy the 64 lists of this wave's lanes, in lane order (= window order).  Entry c of
+    // lane t sits at smem + c * kListStride + 2 * t, so lane `c` of the copying wave reads
+    // entry c of list L: conflict-free, and the stores of one list are contiguous.
+    // Eight lists are in flight at a time (LDS reads first, then the stores); lanes past a
+    // list's end get an out-of-range offset, which the bounds-checked store drops.
+    if (!(debug & 2u)) {
+        const uint32_t tid0 = (uint32_t)wave * kWave;
+        const uint8_t *rd = smem + (uint32_t)lane * kStride + kEB * tid0;
+        // entry u of the eight lists L0 .. L0 + 7 in flight (one byte or one 16-bit word each)
+        auto entry = [&](int L) -> uint32_t {
+            return E8 ? (uint32_t)rd[L] : (uint32_t)*reinterpret_cast<const uint16_t *>(rd + 2 * L);
+        };
+        const uint32_t vb0 = vbt + (READS ? 0u : tid0 * S);
+        // Output window of this wave as a bounds-checked buffer (wave-uniform, so the
+        // descriptor lives in SGPRs): stores past the caller's capacity are dropped by the
+        // hardware, offsets stay 32-bit.
+        const uint32_t r_lo = __builtin_amdgcn_readfirstlane((uint32_t)run0);
+        const uint32_t r_hi = __builtin_amdgcn_readfirstlane((uint32_t)(run0 >> 32));
+        const unsigned long long run0_u = ((unsigned long long)r_hi << 32) | r_lo;
+        const unsigned long long room = out.cap > run0_u ? out.cap - run0_u : 0ull;
+        // (64-bit compares run on the vector unit; pin the result to an SGPR so that the per-list
+        // descriptor arithmetic below stays on the scalar unit)
+        const uint32_t room32 = __builtin_amdgcn_readfirstlane(room > 0x3fffffffull ? 0x3fffffffu : (uint32_t)room);
+        const uint32_t room_bytes = room32 * 4u;
+        const __amdgpu_buffer_rsrc_t opos =
+            __builtin_amdgcn_make_buffer_rsrc(out.pos + run0_u, 0, (int)room_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t osk = __builtin_amdgcn_make_buffer_rsrc(
+            SK ? out.sk + run0_u : out.pos + run0_u, 0, (int)room_bytes, 0x00020000);
+#ifndef MM_COPY_BATCH
+#define MM_COPY_BATCH 8
+#endif
+        constexpr int kBatch = MM_COPY_BATCH;
+        const uint32_t store_mask =
+            __builtin_amdgcn_readfirstlane((debug & 8u) ? 0u : 0xffffffffu);  // timing experiment: no store
+        // Fast path (the whole wave fits the caller's capacity, no SK): the lane mask "entry <
+        // length of the list" and the list's byte offset are made on the scalar unit (s_bfm ->
+        // exec, soffset), so a list costs 2 v_readlane + 1 v_add; of lists with more than 64 entries
+        // the first 64 are stored here, the rest by the loop below.
+#ifdef MM_NO_FAST
+        const bool fast = false;
+#else
+        const bool fast = room32 >= wave_total;
+#endif
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const unsigned long long obase = (unsigned long long)reinterpret_cast<uintptr_t>(out.pos + run0_u);
+        u32x4 odesc;
+        odesc.x = __builtin_amdgcn_readfirstlane((uint32_t)obase);
+        odesc.y = __builtin_amdgcn_readfirstlane((uint32_t)(obase >> 32) & 0xffffu);
+        odesc.z = 0x7fffffffu;  // the capacity was checked for the whole wave
+        odesc.w = 0x00020000u;
+        const unsigned long long sbase =
+            (unsigned long long)reinterpret_cast<uintptr_t>((SK ? out.sk : out.pos) + run0_u);
+        u32x4 sdesc = odesc;  // super-k-mer indices: same slots of the second output array
+        sdesc.x = __builtin_amdgcn_readfirstlane((uint32_t)sbase);
+        sdesc.y = __builtin_amdgcn_readfirstlane((uint32_t)(sbase >> 32) & 0xffffu);
+        // an SK entry packs (window << shift) + offset-in-window (see kSkShift)
+        const uint32_t kRelMask = (1u << kSh) - 1u;
+        const uint32_t lane4 = (uint32_t)lane * 4u;
+        // length and first slot of a lane's list in one word (one v_readlane per list instead of two;
+        // a list that is copied holds at most 315 entries - 159 KB of LDS - and a wave's lists at most
+        // 64 times that many)
+        const uint32_t pk = (excl << 9) | (my_count & 511u);
+        // (Tried in round 2: a lane-owned copy-out - every lane streams its own list with 16-byte stores,
+        // a third of the instructions - ran the whole kernel 2.8 x slower, 5.2 ms: a wave's 64 scattered
+        // segments per store defeat the memory pipeline.  The stores have to stay coalesced.)
+        {
+#ifndef MM_COPY_EXEC
+        if (fast) {
+            // The lanes of a list are selected by the bounds check of its store: a descriptor whose
+            // num_records ends behind the list's last entry drops the lanes past it.  No EXEC write, so
+            // consecutive lists do not serialise on the mask (a wave's time off the walk is what the
+            // copy-out costs: the walk runs where VALU issue and per-wave latency both bind).
+            const uint32_t *obase32 = out.pos + run0_u;
+            const uint32_t *sbase32 = (SK ? out.sk : out.pos) + run0_u;
+#pragma unroll
+            for (int L0 = 0; L0 < kWave; L0 += kBatch) {
+                uint32_t ent[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) ent[u] = entry(L0 + u);
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
+                    const uint32_t n = pkl & 511u, off = pkl >> 9;
+                    const uint32_t vbl = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
+                    const uint32_t iw = ent[u] >> kSh;
+                    const uint32_t val = SK ? vbl + iw + (ent[u] & kRelMask) : vbl + ent[u];
+                    // (round 2 experiment: storing every list as one or two full, aligned 128-byte lines
+                    // instead changed the forward kernel by -1.5 % / +3 % - the stores cost by their bytes,
+                    // not by their partial lines, so staging them into aligned runs would not pay)
+                    const uint32_t end_bytes = ((off + n) * 4u) & store_mask;  // (store_mask 0: timing experiment)
+                    const __amdgpu_buffer_rsrc_t dl = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<uint32_t *>(obase32), 0, (int)end_bytes, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b32(val, dl, lane4, off * 4u, MM_STORE_AUX);
+                    if (SK) {
+                        const __amdgpu_buffer_rsrc_t dl2 = __builtin_amdgcn_make_buffer_rsrc(
+                            const_cast<uint32_t *>(sbase32), 0, (int)end_bytes, 0x00020000);
+                        __builtin_amdgcn_raw_buffer_store_b32(vbl + 1u + iw, dl2, lane4, off * 4u, MM_STORE_AUX);
+                    }
+                }
+            }
+        } else
+#endif
+        if (fast) {
+#pragma unroll
+            for (int L0 = 0; L0 < kWave; L0 += kBatch) {
+                uint32_t ent[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) ent[u] = entry(L0 + u);
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
+                    const uint32_t n = pkl & 511u, off = pkl >> 9;
+                    const uint32_t vbl = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
+                    const uint32_t iw = ent[u] >> kSh;
+                    const uint32_t val = SK ? vbl + iw + (ent[u] & kRelMask) : vbl + ent[u];
+                    const uint32_t val2 = vbl + 1u + iw;
+                    uint32_t t0;
+                    unsigned long long sv;
+                    if (SK)
+                        asm volatile(
+                            "s_and_b32 %[t0], %[n], %[sm]\n\t"
+                            "s_mov_b64 %[sv], exec\n\t"
+                            "s_bfm_b64 exec, %[t0], 0\n\t"
+                            "s_cmp_lt_u32 %[t0], 64\n\t"
+                            "s_cselect_b64 exec, exec, -1\n\t"
+                            "s_lshl_b32 %[t0], %[off], 2\n\t"
+                            "buffer_store_dword %[val], %[lane4], %[desc], %[t0] offen " MM_STORE_MOD "\n\t"
+                            "buffer_store_dword %[val2], %[lane4], %[desc2], %[t0] offen " MM_STORE_MOD "\n\t"
+                            "s_mov_b64 exec, %[sv]"
+                            : [t0] "=&s"(t0), [sv] "=&s"(sv)
+                            : [n] "s"(n), [off] "s"(off), [val] "v"(val), [val2] "v"(val2), [lane4] "v"(lane4),
+                              [desc] "s"(odesc), [desc2] "s"(sdesc), [sm] "s"(store_mask)
+                            : "scc", "memory");
+                    else
+                    asm volatile(
+                        "s_and_b32 %[t0], %[n], %[sm]\n\t"
+                        "s_mov_b64 %[sv], exec\n\t"
+                        "s_bfm_b64 exec, %[t0], 0\n\t"
+                        "s_cmp_lt_u32 %[t0], 64\n\t"
+                        "s_cselect_b64 exec, exec, -1\n\t"
+                        "s_lshl_b32 %[t0], %[off], 2\n\t"
+                        "buffer_store_dword %[val], %[lane4], %[desc], %[t0] offen " MM_STORE_MOD "\n\t"
+                        "s_mov_b64 exec, %[sv]"
+                        : [t0] "=&s"(t0), [sv] "=&s"(sv)
+                        : [n] "s"(n), [off] "s"(off), [val] "v"(val), [lane4] "v"(lane4), [desc] "s"(odesc),
+                          [sm] "s"(store_mask)
+                        : "scc", "memory");
+                }
+            }
+        } else {
+            // (capacity-checked offsets; also the super-k-mer flavour.  Kept rolled: eight lists
+            // per iteration are enough to cover the LDS latency and the code stays small)
+#pragma unroll 1
+            for (int L0 = 0; L0 < kWave; L0 += kBatch) {
+                uint32_t ent[kBatch];
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) ent[u] = entry(L0 + u);
+#pragma unroll
+                for (int u = 0; u < kBatch; ++u) {
+                    const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
+                    const uint32_t n = pkl & 511u, off = pkl >> 9;
+                    const uint32_t vb = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
+                    uint32_t voff = (uint32_t)lane < n ? (off + (uint32_t)lane) * 4u : 0xffffffffu;
+                    voff |= ~store_mask;
+                    const uint32_t iw = ent[u] >> kSh;
+                    __builtin_amdgcn_raw_buffer_store_b32(SK ? vb + iw + (ent[u] & kRelMask) : vb + ent[u], opos,
+                                                          voff, 0, MM_STORE_AUX);
+                    if (SK) __builtin_amdgcn_raw_buffer_store_b32(vb + 1u + iw, osk, voff, 0, MM_STORE_AUX);
+                }
+            }
+        }
+        // lists longer than one wave: the entries from the 65th on, list by list (both paths above
+        // have stored the first 64)
+        for (unsigned long long longer = __ballot(my_count > (uint32_t)kWave); longer; longer &= longer - 1ull) {
+            {
+                const uint32_t L = (uint32_t)__builtin_ctzll(longer);
+                const uint32_t pkl = __builtin_amdgcn_readlane(pk, L);
+                const uint32_t n = pkl & 511u, off = pkl >> 9;
+                const uint32_t vb = READS ? vb0 : vb0 + L * S;
+                for (uint32_t c = (uint32_t)kWave + lane; c < n; c += kWave) {
+                    const uint8_t *q = rd + kEB * L + (c - lane) * kStride;
+                    const uint32_t e1 = E8 ? (uint32_t)*q : (uint32_t)*reinterpret_cast<const uint16_t *>(q);
+                    const uint32_t iw = e1 >> kSh;
+                    __builtin_amdgcn_raw_buffer_store_b32(SK ? vb + iw + (e1 & kRelMask) : vb + e1, opos,
+                                                          (off + c) * 4u, 0, 0);
+                    if (SK) __builtin_amdgcn_raw_buffer_store_b32(vb + 1u + iw, osk, (off + c) * 4u, 0, 0);
+                }
+            }
+        }
+        }
+    }
+    }
+}
+
 // READS = false: one sequence (range of windows), lane t walks windows [t*S, (t+1)*S) of the tile.
 // READS = true : a batch of short reads at a fixed stride, lane t walks read (tile*256 + t) alone;
 //                positions are read-local and read_offsets[] delimits the reads in the output.
@@ -920,6 +1142,9 @@ template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool READS>
 #ifndef MM_MIN_BLOCKS
 #define MM_MIN_BLOCKS \
     (W <= 12 ? 4 : (CANON && !READS ? (W >= 19 && W <= 37 ? 4 : (W >= 38 && W <= 54 ? 3 : (W >= 55 && W <= 64 ? 2 : 1))) : 1))
+#endif
+#ifndef MM_MIN_BLOCKS_WALK
+#define MM_MIN_BLOCKS_WALK MM_MIN_BLOCKS
 #endif
 __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(const FusedParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // lane lists
@@ -963,9 +1188,14 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     // Tile id.  Default: blockIdx.x (workgroups are dispatched in index order on gfx950, which
     // the look-back needs for forward progress; its spins are bounded and report a violation,
     // upon which the host re-runs in ticket mode where an atomic counter defines the order).
+    // Redo mode (split path, mm_split.hip): workgroup b walks tile redo_list[b].tile - one whose lists
+    // overflowed in walk_kernel - again and stores directly from redo_list[b].prefix on; the lane counts come
+    // from the tile's dump slot.  No look-back, nothing is published.
+    const bool redo = !READS && p.redo_list != nullptr;
+    if (redo && blockIdx.x >= *p.redo_n) return;
     if (tid == 0) {
-        s_bid = p.use_ticket ? atomicAdd(p.out.ticket, 1u) : blockIdx.x;
-        s_overflow = 0;
+        s_bid = redo ? p.redo_list[blockIdx.x].tile : (p.use_ticket ? atomicAdd(p.out.ticket, 1u) : blockIdx.x);
+        s_overflow = redo ? 1u : 0u;
         s_done = 0;
         s_carry = *p.out.total;
     }
@@ -1099,7 +1329,9 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         ctx.rem_valid = (int)nvalid - (int)lw;
         ctx.abase = (uint32_t)bw0 + lw;
         set_min_rem(lane_active);
-        if (lane_active && !(p.debug & 4u)) {
+        if (redo) {
+            my_count = reinterpret_cast<const uint16_t *>(p.dump + (size_t)bid * p.dump_stride)[tid];
+        } else if (lane_active && !(p.debug & 4u)) {
             bool over = false;
             if (kAmbi && p.wamb)
                 my_count = (partial || !kTwoBodies<W>)
@@ -1123,7 +1355,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         // LDS, in order behind the store above.  The wave that finishes phase 1 last publishes the
         // tile's aggregate at once (successors wait for that, never for this tile's look-back).
 #ifndef MM_LB_CHUNKED
-        if (atomicAdd(&s_done, 1u) == (uint32_t)(kFusedWaves - 1) && bid != 0 && !(p.debug & 1u)) {
+        if (atomicAdd(&s_done, 1u) == (uint32_t)(kFusedWaves - 1) && bid != 0 && !(p.debug & 1u) && !redo) {
             uint32_t tot = 0;
 #pragma unroll
             for (int v = 0; v < kFusedWaves; ++v) tot += reinterpret_cast<volatile uint32_t *>(s_wave_tot)[v];
@@ -1144,8 +1376,9 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
 #ifndef MM_LB_CHUNKED
         const unsigned long long carry = (bid == 0) ? *p.out.total : 0ull;
         const unsigned long long ex =
-            (p.debug & 1u) ? (unsigned long long)bid * (NB / 6u)
-                           : lookback_overlapped(p.out.status, bid, carry, p.out.error, &s_done, s_wave_tot);
+            redo ? p.redo_list[blockIdx.x].prefix
+                 : ((p.debug & 1u) ? (unsigned long long)bid * (NB / 6u)
+                                   : lookback_overlapped(p.out.status, bid, carry, p.out.error, &s_done, s_wave_tot));
 #else
         const unsigned long long carry = s_carry;  // base of chunk 0: every tile of that chunk needs it
         const unsigned long long ex =
@@ -1174,200 +1407,12 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
             o += (read_counts >> (16u * j)) & 0xffffu;
         }
     }
-    if (batch && tid == 0 && local_tile == 0) p.batch_offsets[batch_s] = s_excl;
+    if (batch && tid == 0 && local_tile == 0 && !redo) p.batch_offsets[batch_s] = s_excl;
 
     if (!overflow) {
-        // Copy the 64 lists of this wave's lanes, in lane order (= window order).  Entry c of
-        // lane t sits at smem + c * kListStride + 2 * t, so lane `c` of the copying wave reads
-        // entry c of list L: conflict-free, and the stores of one list are contiguous.
-        // Eight lists are in flight at a time (LDS reads first, then the stores); lanes past a
-        // list's end get an out-of-range offset, which the bounds-checked store drops.
-        if (!(p.debug & 2u)) {
-            const uint32_t tid0 = (uint32_t)wave * kWave;
-            const uint8_t *rd = smem + (uint32_t)lane * kStride + kEB * tid0;
-            // entry u of the eight lists L0 .. L0 + 7 in flight (one byte or one 16-bit word each)
-            auto entry = [&](int L) -> uint32_t {
-                return kE8 ? (uint32_t)rd[L] : (uint32_t)*reinterpret_cast<const uint16_t *>(rd + 2 * L);
-            };
-            const uint32_t vb0 = (READS ? 0u : (uint32_t)bw0 + tid0 * S) - (MODE == 0 ? 1u : 0u);
-            // Output window of this wave as a bounds-checked buffer (wave-uniform, so the
-            // descriptor lives in SGPRs): stores past the caller's capacity are dropped by the
-            // hardware, offsets stay 32-bit.
-            const uint32_t r_lo = __builtin_amdgcn_readfirstlane((uint32_t)run0);
-            const uint32_t r_hi = __builtin_amdgcn_readfirstlane((uint32_t)(run0 >> 32));
-            const unsigned long long run0_u = ((unsigned long long)r_hi << 32) | r_lo;
-            const unsigned long long room = p.out.cap > run0_u ? p.out.cap - run0_u : 0ull;
-            // (64-bit compares run on the vector unit; pin the result to an SGPR so that the per-list
-            // descriptor arithmetic below stays on the scalar unit)
-            const uint32_t room32 = __builtin_amdgcn_readfirstlane(room > 0x3fffffffull ? 0x3fffffffu : (uint32_t)room);
-            const uint32_t room_bytes = room32 * 4u;
-            const __amdgpu_buffer_rsrc_t opos =
-                __builtin_amdgcn_make_buffer_rsrc(p.out.pos + run0_u, 0, (int)room_bytes, 0x00020000);
-            const __amdgpu_buffer_rsrc_t osk = __builtin_amdgcn_make_buffer_rsrc(
-                SK ? p.out.sk + run0_u : p.out.pos + run0_u, 0, (int)room_bytes, 0x00020000);
-#ifndef MM_COPY_BATCH
-#define MM_COPY_BATCH 8
-#endif
-            constexpr int kBatch = MM_COPY_BATCH;
-            const uint32_t store_mask =
-                __builtin_amdgcn_readfirstlane((p.debug & 8u) ? 0u : 0xffffffffu);  // timing experiment: no store
-            // Fast path (the whole wave fits the caller's capacity, no SK): the lane mask "entry <
-            // length of the list" and the list's byte offset are made on the scalar unit (s_bfm ->
-            // exec, soffset), so a list costs 2 v_readlane + 1 v_add; of lists with more than 64 entries
-            // the first 64 are stored here, the rest by the loop below.
-#ifdef MM_NO_FAST
-            const bool fast = false;
-#else
-            const bool fast = room32 >= wave_total;
-#endif
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const unsigned long long obase = (unsigned long long)reinterpret_cast<uintptr_t>(p.out.pos + run0_u);
-            u32x4 odesc;
-            odesc.x = __builtin_amdgcn_readfirstlane((uint32_t)obase);
-            odesc.y = __builtin_amdgcn_readfirstlane((uint32_t)(obase >> 32) & 0xffffu);
-            odesc.z = 0x7fffffffu;  // the capacity was checked for the whole wave
-            odesc.w = 0x00020000u;
-            const unsigned long long sbase =
-                (unsigned long long)reinterpret_cast<uintptr_t>((SK ? p.out.sk : p.out.pos) + run0_u);
-            u32x4 sdesc = odesc;  // super-k-mer indices: same slots of the second output array
-            sdesc.x = __builtin_amdgcn_readfirstlane((uint32_t)sbase);
-            sdesc.y = __builtin_amdgcn_readfirstlane((uint32_t)(sbase >> 32) & 0xffffu);
-            // an SK entry packs (window << shift) + offset-in-window (see kSkShift)
-            constexpr uint32_t kSh = (uint32_t)kSkShift<W>, kRelMask = (1u << kSh) - 1u;
-            const uint32_t lane4 = (uint32_t)lane * 4u;
-            // length and first slot of a lane's list in one word (one v_readlane per list instead of two;
-            // a list that is copied holds at most 315 entries - 159 KB of LDS - and a wave's lists at most
-            // 64 times that many)
-            const uint32_t pk = (excl << 9) | (my_count & 511u);
-            // (Tried in round 2: a lane-owned copy-out - every lane streams its own list with 16-byte stores,
-            // a third of the instructions - ran the whole kernel 2.8 x slower, 5.2 ms: a wave's 64 scattered
-            // segments per store defeat the memory pipeline.  The stores have to stay coalesced.)
-            {
-#ifndef MM_COPY_EXEC
-            if (fast) {
-                // The lanes of a list are selected by the bounds check of its store: a descriptor whose
-                // num_records ends behind the list's last entry drops the lanes past it.  No EXEC write, so
-                // consecutive lists do not serialise on the mask (a wave's time off the walk is what the
-                // copy-out costs: the walk runs where VALU issue and per-wave latency both bind).
-                const uint32_t *obase32 = p.out.pos + run0_u;
-                const uint32_t *sbase32 = (SK ? p.out.sk : p.out.pos) + run0_u;
-#pragma unroll
-                for (int L0 = 0; L0 < kWave; L0 += kBatch) {
-                    uint32_t ent[kBatch];
-#pragma unroll
-                    for (int u = 0; u < kBatch; ++u) ent[u] = entry(L0 + u);
-#pragma unroll
-                    for (int u = 0; u < kBatch; ++u) {
-                        const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
-                        const uint32_t n = pkl & 511u, off = pkl >> 9;
-                        const uint32_t vbl = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
-                        const uint32_t iw = ent[u] >> kSh;
-                        const uint32_t val = SK ? vbl + iw + (ent[u] & kRelMask) : vbl + ent[u];
-                        // (round 2 experiment: storing every list as one or two full, aligned 128-byte lines
-                        // instead changed the forward kernel by -1.5 % / +3 % - the stores cost by their bytes,
-                        // not by their partial lines, so staging them into aligned runs would not pay)
-                        const uint32_t end_bytes = ((off + n) * 4u) & store_mask;  // (store_mask 0: timing experiment)
-                        const __amdgpu_buffer_rsrc_t dl = __builtin_amdgcn_make_buffer_rsrc(
-                            const_cast<uint32_t *>(obase32), 0, (int)end_bytes, 0x00020000);
-                        __builtin_amdgcn_raw_buffer_store_b32(val, dl, lane4, off * 4u, MM_STORE_AUX);
-                        if (SK) {
-                            const __amdgpu_buffer_rsrc_t dl2 = __builtin_amdgcn_make_buffer_rsrc(
-                                const_cast<uint32_t *>(sbase32), 0, (int)end_bytes, 0x00020000);
-                            __builtin_amdgcn_raw_buffer_store_b32(vbl + 1u + iw, dl2, lane4, off * 4u, MM_STORE_AUX);
-                        }
-                    }
-                }
-            } else
-#endif
-            if (fast) {
-#pragma unroll
-                for (int L0 = 0; L0 < kWave; L0 += kBatch) {
-                    uint32_t ent[kBatch];
-#pragma unroll
-                    for (int u = 0; u < kBatch; ++u) ent[u] = entry(L0 + u);
-#pragma unroll
-                    for (int u = 0; u < kBatch; ++u) {
-                        const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
-                        const uint32_t n = pkl & 511u, off = pkl >> 9;
-                        const uint32_t vbl = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
-                        const uint32_t iw = ent[u] >> kSh;
-                        const uint32_t val = SK ? vbl + iw + (ent[u] & kRelMask) : vbl + ent[u];
-                        const uint32_t val2 = vbl + 1u + iw;
-                        uint32_t t0;
-                        unsigned long long sv;
-                        if (SK)
-                            asm volatile(
-                                "s_and_b32 %[t0], %[n], %[sm]\n\t"
-                                "s_mov_b64 %[sv], exec\n\t"
-                                "s_bfm_b64 exec, %[t0], 0\n\t"
-                                "s_cmp_lt_u32 %[t0], 64\n\t"
-                                "s_cselect_b64 exec, exec, -1\n\t"
-                                "s_lshl_b32 %[t0], %[off], 2\n\t"
-                                "buffer_store_dword %[val], %[lane4], %[desc], %[t0] offen " MM_STORE_MOD "\n\t"
-                                "buffer_store_dword %[val2], %[lane4], %[desc2], %[t0] offen " MM_STORE_MOD "\n\t"
-                                "s_mov_b64 exec, %[sv]"
-                                : [t0] "=&s"(t0), [sv] "=&s"(sv)
-                                : [n] "s"(n), [off] "s"(off), [val] "v"(val), [val2] "v"(val2), [lane4] "v"(lane4),
-                                  [desc] "s"(odesc), [desc2] "s"(sdesc), [sm] "s"(store_mask)
-                                : "scc", "memory");
-                        else
-                        asm volatile(
-                            "s_and_b32 %[t0], %[n], %[sm]\n\t"
-                            "s_mov_b64 %[sv], exec\n\t"
-                            "s_bfm_b64 exec, %[t0], 0\n\t"
-                            "s_cmp_lt_u32 %[t0], 64\n\t"
-                            "s_cselect_b64 exec, exec, -1\n\t"
-                            "s_lshl_b32 %[t0], %[off], 2\n\t"
-                            "buffer_store_dword %[val], %[lane4], %[desc], %[t0] offen " MM_STORE_MOD "\n\t"
-                            "s_mov_b64 exec, %[sv]"
-                            : [t0] "=&s"(t0), [sv] "=&s"(sv)
-                            : [n] "s"(n), [off] "s"(off), [val] "v"(val), [lane4] "v"(lane4), [desc] "s"(odesc),
-                              [sm] "s"(store_mask)
-                            : "scc", "memory");
-                    }
-                }
-            } else {
-                // (capacity-checked offsets; also the super-k-mer flavour.  Kept rolled: eight lists
-                // per iteration are enough to cover the LDS latency and the code stays small)
-#pragma unroll 1
-                for (int L0 = 0; L0 < kWave; L0 += kBatch) {
-                    uint32_t ent[kBatch];
-#pragma unroll
-                    for (int u = 0; u < kBatch; ++u) ent[u] = entry(L0 + u);
-#pragma unroll
-                    for (int u = 0; u < kBatch; ++u) {
-                        const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
-                        const uint32_t n = pkl & 511u, off = pkl >> 9;
-                        const uint32_t vb = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
-                        uint32_t voff = (uint32_t)lane < n ? (off + (uint32_t)lane) * 4u : 0xffffffffu;
-                        voff |= ~store_mask;
-                        const uint32_t iw = ent[u] >> kSh;
-                        __builtin_amdgcn_raw_buffer_store_b32(SK ? vb + iw + (ent[u] & kRelMask) : vb + ent[u], opos,
-                                                              voff, 0, MM_STORE_AUX);
-                        if (SK) __builtin_amdgcn_raw_buffer_store_b32(vb + 1u + iw, osk, voff, 0, MM_STORE_AUX);
-                    }
-                }
-            }
-            // lists longer than one wave: the entries from the 65th on, list by list (both paths above
-            // have stored the first 64)
-            for (unsigned long long longer = __ballot(my_count > (uint32_t)kWave); longer; longer &= longer - 1ull) {
-                {
-                    const uint32_t L = (uint32_t)__builtin_ctzll(longer);
-                    const uint32_t pkl = __builtin_amdgcn_readlane(pk, L);
-                    const uint32_t n = pkl & 511u, off = pkl >> 9;
-                    const uint32_t vb = READS ? vb0 : vb0 + L * S;
-                    for (uint32_t c = (uint32_t)kWave + lane; c < n; c += kWave) {
-                        const uint8_t *q = rd + kEB * L + (c - lane) * kStride;
-                        const uint32_t e1 = kE8 ? (uint32_t)*q : (uint32_t)*reinterpret_cast<const uint16_t *>(q);
-                        const uint32_t iw = e1 >> kSh;
-                        __builtin_amdgcn_raw_buffer_store_b32(SK ? vb + iw + (e1 & kRelMask) : vb + e1, opos,
-                                                              (off + c) * 4u, 0, 0);
-                        if (SK) __builtin_amdgcn_raw_buffer_store_b32(vb + 1u + iw, osk, (off + c) * 4u, 0, 0);
-                    }
-                }
-            }
-            }
-        }
+        copy_out_wave<kE8, SK, READS>(smem, p.out, p.debug, wave, lane,
+                                      (READS ? 0u : (uint32_t)bw0) - (MODE == 0 ? 1u : 0u), S, (uint32_t)kSkShift<W>,
+                                      run0, wave_total, my_count, excl);
     } else if (READS) {
         // some list overflowed: walk the lane's reads again, now storing straight to the output
         unsigned long long o = run0 + excl;
@@ -1393,10 +1438,144 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         __syncthreads();
         if (tid == 0) p.trace[10 * (size_t)bid + 3] = wall_clock64();
     }
-    if (tid == 0 && bid == gridDim.x - 1) {
+    if (tid == 0 && bid == gridDim.x - 1 && !redo) {
         *p.out.total = s_excl + block_total;
         if (READS) p.read_offsets[p.n_reads] = s_excl + block_total;
         if (batch) p.batch_offsets[p.batch_n] = s_excl + block_total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ split path
+// (round 3) The walk without phase 2.  In the fused kernel a tile that has finished walking keeps its
+// registers and its lists while it waits for the counts of all earlier tiles and while it copies its lists
+// out - a third of the forward run.  Here the workgroup stores the raw list rows and the lane counts to a
+// per-tile slot in HBM (write-through 16-byte stores), publishes the tile's count in ONE status word and
+// exits: it never waits for another tile, needs no dispatch order and no ticket.  Persistent expander
+// workgroups on a second stream (mm_split.hip) sum the published counts, load the rows back and run the
+// same copy-out (copy_out_wave).  A tile whose list overflowed publishes its count with kSplitOverflow; the
+// expander notes its first output slot in the redo list and a launch of fused_kernel in redo mode
+// (FusedParams::redo_list) walks those tiles again, storing directly.
+// One sequence (or a window range of it) per launch; reads and batches of sequences keep the fused kernel.
+template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool READS = false>
+__global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS_WALK) void walk_kernel(const FusedParams p) {
+    static_assert(!READS, "the split path has no reads mode");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // lane lists
+    __shared__ uint2 s_tab[36];
+    __shared__ uint32_t s_overflow, s_total, s_maxrows;
+    __shared__ __attribute__((aligned(16))) uint16_t s_cnt[kFusedThreads];
+    constexpr bool kAmbi = CANON && !SK;
+    constexpr bool kE8 = kEntry8<W, CANON, SK, false>;
+    constexpr uint32_t kStride = list_stride(kE8), kEB = kE8 ? 1u : 2u;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    {  // layout contract of the list overflow, as in fused_kernel
+        auto lds_end = [](const void *q, size_t bytes) {
+            return (uint32_t)reinterpret_cast<uintptr_t>(q) + (uint32_t)bytes;
+        };
+        uint32_t st_end = lds_end(s_tab, sizeof(s_tab));
+        st_end = max(st_end, lds_end(&s_overflow, sizeof(s_overflow)));
+        st_end = max(st_end, lds_end(&s_total, sizeof(s_total)));
+        st_end = max(st_end, lds_end(&s_maxrows, sizeof(s_maxrows)));
+        st_end = max(st_end, lds_end(s_cnt, sizeof(s_cnt)));
+        if ((uint32_t)reinterpret_cast<uintptr_t>(smem) < st_end) {
+            if (tid == 0) flag_error(p.out.error, 2u);
+            return;
+        }
+    }
+    if (tid < 16) s_tab[tid] = p.ht.t_in_out[tid];
+    else if (tid < 20) s_tab[tid] = p.ht.t_in[tid - 16];
+    else if (tid < 36) s_tab[tid] = p.ht.t_in2[tid - 20];
+    const uint32_t S = (uint32_t)W * p.nblk;
+    const uint32_t NB = kFusedThreads * S;
+    {
+        // (one tile per workgroup and no loop around it: a loop here - the redo pass was one at first - costs
+        // the walk 17 to 24 registers)
+        const uint32_t bid = blockIdx.x;
+        if (tid == 0) {
+            s_overflow = 0;
+            s_total = 0;
+            s_maxrows = 0;
+        }
+        __syncthreads();
+        // (one sequence or one window range of it; batches of sequences keep the fused kernel)
+        const uint32_t *seq_d = p.seq.d;
+        const uint32_t seq_dwords = p.seq.n_dwords, seq_base0 = p.seq.base0;
+        const uint32_t win_begin = p.win_begin, win_end = p.win_end, local_tile = bid;
+        const uint64_t bw0 = (uint64_t)win_begin + (uint64_t)local_tile * NB;  // first window of the tile
+        const uint32_t nvalid = (uint32_t)(((uint64_t)win_end - bw0) < NB ? ((uint64_t)win_end - bw0) : NB);
+        const bool partial = nvalid < NB;
+
+        LaneCtx ctx;
+        ctx.tab = s_tab;
+        ctx.list = smem + kEB * (uint32_t)tid;
+        ctx.list_bytes = p.list_cap * kStride;
+        ctx.list_used = 0;
+        ctx.dst = 0;
+        ctx.nblk = p.nblk;
+        ctx.seq_d = seq_d;
+        ctx.seq_dwords = seq_dwords;
+        const uint32_t lw = (uint32_t)tid * S;  // first window of the lane, tile-relative
+        const bool lane_active = lw < nvalid;
+        ctx.p0 = (long long)seq_base0 + (long long)bw0 - 1;
+        ctx.lane_bases = lw;
+        ctx.wbase = (uint32_t)bw0 + lw;
+        ctx.no_prev = (bw0 + lw == 0);
+        ctx.rem_valid = (int)nvalid - (int)lw;
+        ctx.abase = (uint32_t)bw0 + lw;
+        {
+            int m = lane_active ? ctx.rem_valid : 0x7fffffff;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) m = min(m, __shfl_xor(m, d, kWave));
+            ctx.min_rem = __builtin_amdgcn_readfirstlane(m);
+        }
+        uint8_t *slot = p.dump + (size_t)bid * p.dump_stride;
+        {
+            // ------------------------------------------------------------ the walk, into the lane lists
+            uint32_t my_count = 0;
+            if (lane_active && !(p.debug & 4u)) {
+                bool over = false;
+                if (kAmbi && p.wamb)
+                    my_count = (partial || !kTwoBodies<W>)
+                                   ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi, kE8>(p, ctx, over)
+                                   : lane_walk<W, CANON, HASH_RC, MODE, SK, false, kAmbi && !kTwoBodies<W>, kAmbi, kE8>(p, ctx, over);
+                else my_count = partial ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, false, kE8>(p, ctx, over)
+                                        : lane_walk<W, CANON, HASH_RC, MODE, SK, false, false, false, kE8>(p, ctx, over);
+                if (over) s_overflow = 1;  // benign race: every writer stores 1
+            }
+            // ------------------------------------------------------------ dump and publish
+            uint32_t tot = my_count, mx = my_count;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                tot += __shfl_xor(tot, d, kWave);
+                mx = max(mx, __shfl_xor(mx, d, kWave));
+            }
+            s_cnt[tid] = (uint16_t)my_count;
+            if (lane == 0) {
+                atomicAdd(&s_total, tot);
+                atomicMax(&s_maxrows, mx);
+            }
+            __syncthreads();
+            const uint32_t total = s_total, overflow = s_overflow;
+            const uint32_t rows = s_maxrows < p.list_cap ? s_maxrows : p.list_cap;
+            const __amdgpu_buffer_rsrc_t dr =
+                __builtin_amdgcn_make_buffer_rsrc(slot, 0, (int)p.dump_stride, 0x00020000);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            // aux 16 = sc1: write-through, so that no release fence (a write-back of the XCD's whole L2) is
+            // needed before the status word
+            if (tid < (int)(kSplitHeader / 16u))
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint8_t *>(s_cnt) + 16 * tid),
+                                                       dr, 16u * (uint32_t)tid, 0, 16);
+            if (!overflow) {
+                const uint32_t pieces = (rows * kStride + 15u) / 16u;
+                for (uint32_t i = (uint32_t)tid; i < pieces; i += kFusedThreads)
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4 *>(smem + 16u * i), dr,
+                                                           kSplitHeader + 16u * i, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its own stores ...
+            __syncthreads();                                    // ... before one lane publishes
+            if (tid == 0)
+                st_status(&p.tile_status[bid], kSplitValid | (overflow ? kSplitOverflow : 0ull) |
+                                                   ((unsigned long long)rows << 32) | (unsigned long long)total);
+        }
     }
 }
 

@@ -45,4 +45,16 @@ const FusedReadsInstance *fused_reads_instances_b(int *count);
 const FusedReadsInstance *fused_reads_instances_c(int *count);
 const FusedReadsInstance *fused_reads_instances_d(int *count);
 
+// walk kernels of the split path (walk_kernel), mm_walk_inst.hip
+struct WalkInstance {
+    uint32_t w;
+    bool canon, hash_rc;
+    uint32_t mode;
+    bool sk;
+    FusedKernelFn fn;
+};
+#define MM_WALK_INST(W, C, R, MODE, SK) \
+    { W, C, R, MODE, SK, &walk_kernel<W, C, R, MODE, SK> }
+const WalkInstance *walk_instances(int *count);
+
 }  // namespace mm

@@ -5,6 +5,7 @@
 // window sizes (the reference is generic over w at full speed; so is this).
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -61,24 +62,34 @@ std::string cache_dir() {
     return base + "/simd_minimizers_amd";
 }
 
-bool read_file(const std::string &path, std::vector<char> &out) {
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    fseek(f, 0, SEEK_END);
-    long n = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    out.resize(n > 0 ? (size_t)n : 0);
-    bool ok = n > 0 && fread(out.data(), 1, (size_t)n, f) == (size_t)n;
-    fclose(f);
-    return ok;
+// The cache holds code this process will load and run.  An entry is read only from a directory that is a
+// real directory (no symlink) owned by this user and writable by nobody else, and only if the entry itself
+// is a regular file owned by this user that nobody else can write; the checks run on the descriptor the
+// bytes are then read from (O_NOFOLLOW + fstat), so nothing can be swapped between check and read.
+bool trusted_dir(const std::string &dir) {
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0) return false;
+    return S_ISDIR(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
 }
 
-// The cache holds code this process will load and run: the directory is private to the user (0700)
-// and an entry is only trusted if it is a regular file owned by this user that nobody else can write.
-bool trusted_file(const std::string &path) {
+bool read_trusted_file(const std::string &path, std::vector<char> &out) {
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return false;
     struct stat st;
-    if (lstat(path.c_str(), &st) != 0) return false;
-    return S_ISREG(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+    bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid() &&
+              (st.st_mode & (S_IWGRP | S_IWOTH)) == 0 && st.st_size > 0 && st.st_size < (off_t)(1ll << 30);
+    if (ok) {
+        out.resize((size_t)st.st_size);
+        size_t got = 0;
+        while (got < out.size()) {
+            const ssize_t n = read(fd, out.data() + got, out.size() - got);
+            if (n <= 0) break;
+            got += (size_t)n;
+        }
+        ok = got == out.size();
+    }
+    close(fd);
+    return ok;
 }
 
 void write_file_atomic(const std::string &dir, const std::string &path, const std::vector<char> &data) {
@@ -167,15 +178,15 @@ bool jit_enabled() {
     return !(e && e[0] == '0');
 }
 
-std::string fused_kernel_name(uint32_t w, bool canon, bool hash_rc, int mode, bool sk, bool reads) {
+std::string fused_kernel_name(uint32_t w, bool canon, bool hash_rc, int mode, bool sk, bool reads, bool walk) {
     auto b = [](bool x) { return x ? "true" : "false"; };
-    return "mm::fused_kernel<" + std::to_string(w) + ", " + b(canon) + ", " + b(hash_rc) + ", " +
+    return std::string(walk ? "mm::walk_kernel<" : "mm::fused_kernel<") + std::to_string(w) + ", " + b(canon) + ", " + b(hash_rc) + ", " +
            std::to_string(mode) + ", " + b(sk) + ", " + b(reads) + ">";
 }
 
 // Compiled-and-loaded kernel for the current device, or nullptr (then *err says why).
 hipFunction_t jit_fused_kernel(uint32_t w, bool canon, bool hash_rc, int mode, bool sk, bool reads,
-                               std::string *err) {
+                               std::string *err, bool walk) {
     std::string local_err;
     if (!err) err = &local_err;
     if (!jit_enabled() || w == 0 || w > kJitMaxW) {
@@ -187,7 +198,7 @@ hipFunction_t jit_fused_kernel(uint32_t w, bool canon, bool hash_rc, int mode, b
         *err = "hipGetDevice failed";
         return nullptr;
     }
-    const std::string name = fused_kernel_name(w, canon, hash_rc, mode, sk, reads);
+    const std::string name = fused_kernel_name(w, canon, hash_rc, mode, sk, reads, walk);
     const char *defs = getenv("MM_JIT_DEFS");
     const std::string key = std::to_string(device) + ":" + name + "|" + (defs ? defs : "");
     std::lock_guard<std::mutex> lock(g_mu);
@@ -211,8 +222,8 @@ hipFunction_t jit_fused_kernel(uint32_t w, bool canon, bool hash_rc, int mode, b
     std::vector<char> code, lowered_buf;
     std::string lowered;
     bool from_disk = false;
-    if (!path.empty() && trusted_file(path) && trusted_file(path + ".name") && read_file(path, code) &&
-        read_file(path + ".name", lowered_buf)) {
+    if (!path.empty() && trusted_dir(dir) && read_trusted_file(path, code) &&
+        read_trusted_file(path + ".name", lowered_buf)) {
         lowered.assign(lowered_buf.begin(), lowered_buf.end());
         from_disk = true;
     }

@@ -30,6 +30,7 @@ struct RunArgs {
     uint32_t nblk;  // w-blocks per lane (0 = default)
     uint64_t work_windows;  // windows of the whole run (0 = unknown): short runs get shorter lanes (more tiles)
     int use_ticket; // tile ids from an atomic ticket instead of blockIdx.x (safe mode)
+    uint64_t status_avail = 0;  // 8-byte words allocated behind out.status (0 = not known to the launcher)
     // generic path
     void *scratch;
     uint64_t generic_round_windows;
@@ -51,6 +52,27 @@ uint32_t fused_batch_nblk(const RunArgs &a, const uint64_t *n_windows, uint64_t 
 // fused_unavailable_reason() says why)
 int launch_fused(const RunArgs &a, hipStream_t stream);
 const char *fused_unavailable_reason();
+
+// ---- split path of the fused family (walk_kernel in mm_fused_impl.h + mm_split.hip): the walk dumps its lists
+// and exits, persistent expander workgroups on a second stream turn them into positions
+struct SplitBuffers {
+    uint8_t *dump = nullptr;                     // tiles x dump slot
+    uint64_t dump_bytes = 0;
+    unsigned long long *tile_status = nullptr;   // one word per tile
+    uint64_t status_words = 0;
+    void *redo_list = nullptr;                   // one 16-byte entry per tile
+    uint64_t redo_entries = 0;
+    uint32_t *redo_n = nullptr;
+    unsigned long long *carry = nullptr;         // outputs before the run (append mode)
+    hipStream_t aux = nullptr;                   // the expander's stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+};
+// what a run needs (tiles of the run and bytes of its dump area); tiles == 0: the plan has no split path
+void split_requirements(const RunArgs &a, uint64_t *tiles, uint64_t *dump_bytes);
+// default policy + MM_SPLIT (0 / 1) override: whether this run should take the split path
+bool split_wanted(const RunArgs &a);
+// returns 0, -1 (HIP failure) or -2 (no walk kernel for this plan: take the fused kernel)
+int launch_split(const RunArgs &a, const SplitBuffers &b, hipStream_t stream);
 
 // ---- reads mode of the fused family: a batch of short reads at a fixed stride, one lane per read
 struct ReadsArgs {
@@ -77,8 +99,9 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream);
 // ---- run-time specialisation (mm_jit.hip): window sizes without a prebuilt instance
 constexpr uint32_t kJitMaxW = 128;  // ring registers: 256 VGPRs + AGPRs still hold W = 128 without scratch
 bool jit_enabled();                 // MM_JIT=0 switches it off (then such w take the generic family)
+// walk = true: mm::walk_kernel (the split path's walk) instead of mm::fused_kernel
 hipFunction_t jit_fused_kernel(uint32_t w, bool canon, bool hash_rc, int mode, bool sk, bool reads,
-                               std::string *err);
+                               std::string *err, bool walk = false);
 
 // ---- generic family (mm_generic.hip): any k / w
 uint64_t generic_scratch_bytes(uint64_t round_windows, uint32_t w);
