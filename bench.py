@@ -167,7 +167,7 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def recorded_counters(kernel_ms):
+def recorded_counters(kernel_ms, live_clock_ghz=None):
     """HBM traffic and SQ counters cannot be collected from inside this process: rocprofv3 gathers them
     in separate passes around the same command (tools/prof_head.py), and the condensed result is
     committed as profiles/head_counters.json together with the hash of the kernel source it was
@@ -176,9 +176,12 @@ def recorded_counters(kernel_ms):
     valu dict or None, provenance text).
 
     roofline.valu - the bound that actually binds: VALU-pipe time of one launch / kernel time, where
-    VALU-pipe time = (wave-instructions issued, PMC SQ_INSTS_VALU) x (issue clocks per instruction, from
-    the census of the main loop at the issue rates measured on MI355X) / (1024 SIMDs x shader clock, PMC
-    GRBM_GUI_ACTIVE / kernel time of the counter pass)."""
+    VALU-pipe time = (wave-instructions issued, PMC SQ_INSTS_VALU: a property of the kernel and its input, not of
+    the run) x (shader cycles per instruction: the census of the main loop priced at the issue rates
+    tools/ubench/valu_rate.hip measures in shader cycles, profiles/r03_valu_issue_rates.txt) / (1024 SIMDs x the
+    shader clock sampled LIVE around the timed loop, mm_clock_probe_*).  `frac` cannot exceed 1 but for noise:
+    a pure stream of one instruction class is what defines the rate.  `frac_ideal` prices the same instructions
+    at the architectural 2 / 4 cycles."""
     sha = kernel_source_sha()
     try:
         c = json.load(open(os.path.join(ROOT, "profiles", "head_counters.json")))
@@ -191,23 +194,24 @@ def recorded_counters(kernel_ms):
         isa = json.load(open(os.path.join(ROOT, "profiles", "head_isa_census.json")))
         insts = float(c["SQ_INSTS_VALU"])
         windows = float(c["windows_per_launch"])
-        sclk_hz = float(c["GRBM_GUI_ACTIVE_per_xcd"]) / (float(c["counter_pass_kernel_us"]) * 1e-6)
-        issue_clk = float(isa["issue_clk_per_valu"])
-        busy = insts * issue_clk / (N_SIMD * sclk_hz)  # seconds of VALU-pipe time per launch
-        pass_cycles = float(c["GRBM_GUI_ACTIVE_per_xcd"])  # shader cycles of one launch IN the counter pass
+        pass_clk_hz = float(c["GRBM_GUI_ACTIVE_per_xcd"]) / (float(c["counter_pass_kernel_us"]) * 1e-6)
+        clk_hz = live_clock_ghz * 1e9 if live_clock_ghz else pass_clk_hz
+        cyc = float(isa["issue_clk_per_valu"])
+        ideal = float(isa.get("ideal_clk_per_valu", cyc))
+        cycles_per_simd = N_SIMD * clk_hz * kernel_ms * 1e-3  # SIMD cycles the kernel had
         valu = {"insts_per_window": round(insts * 64.0 / windows, 2),
                 "main_loop_insts_per_window": isa["valu_per_window"],
-                "issue_clk": round(issue_clk, 3), "sclk_mhz": round(sclk_hz / 1e6, 0),
-                # upper bound: live kernel time at the (lower) clock of the counter pass
-                "frac": round(busy / (kernel_ms * 1e-3), 4),
-                # lower bound, cycle-exact: VALU-pipe cycles / shader cycles of the counter pass itself,
-                # which runs about 13 % slower than the live kernel (counter collection)
-                "frac_counter_pass": round(insts * issue_clk / (N_SIMD * pass_cycles), 4),
-                "source": "SQ_INSTS_VALU and GRBM_GUI_ACTIVE recorded (profiles/head_counters.json), issue clocks per "
-                          "instruction from the main loop's census (profiles/head_isa_census.json), kernel time live; "
-                          "`frac` uses the live kernel time with the counter pass's clock (the live clock is a few % "
-                          "higher, so it may read slightly above 1), `frac_counter_pass` is cycle-exact within the "
-                          "slower counter pass: the true VALU-pipe utilisation lies between the two"
+                "cycles_per_inst": round(cyc, 3), "cycles_per_inst_ideal": round(ideal, 3),
+                "sclk_mhz": round(clk_hz / 1e6, 0),
+                "clock_source": ("live: shader cycle counter against the 100 MHz real-time counter, sampled by sleeping "
+                                 "waves beside the timed loop (mm_clock_probe_*)") if live_clock_ghz else
+                                "GRBM_GUI_ACTIVE / kernel time of the recorded counter pass (no live probe in this run)",
+                "frac": round(insts * cyc / cycles_per_simd, 4),
+                "frac_ideal": round(insts * ideal / cycles_per_simd, 4),
+                "source": "SQ_INSTS_VALU recorded (profiles/head_counters.json), shader cycles per instruction from the "
+                          "main loop's census (profiles/head_isa_census.json) at the measured issue rates "
+                          "(profiles/r03_valu_issue_rates.txt: 2.31 / 4.14 cycles per full- / half-rate wave64 "
+                          "instruction), kernel time and shader clock live; frac_ideal: the same at 2 / 4 cycles"
                           + ("; STALE counters: kernel source changed since" if stale else "")
                           + ("; STALE census" if isa.get("kernel_source_sha") != sha else "")}
     except Exception:
@@ -333,6 +337,14 @@ def main():
                   sm.canonical_minimizers(31, 51), 0, 0, 2 / 52, contigs=sharding.CHM13_CONTIG_LENGTHS)
         secondary("C5 canonical closed syncmers k=15 w=17, 3.1 Gbp (G seed 3)", sm.canonical_closed_syncmers(15, 17),
                   N_BASES, SEED, 2 / 17)
+        # The rows either side of the path: whole-call device time (torch events on the workspace's
+        # stream, median of 5 after 3 warm-up calls), algorithmic bytes and their fraction of the HBM peak
+        from simd_minimizers_amd import workloads
+        for comp in workloads.COMPONENTS:
+            try:
+                extras.append(workloads.measure(comp, ws, dev))
+            except Exception as e:  # a component must never take the headline down
+                extras.append({"component": comp, "error": str(e)[:200]})
 
     # ---------------------------------------------------------------- workload set-up
     n = args.bases
@@ -413,6 +425,15 @@ def main():
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    # shader clock during the timed loop (16 sleeping waves on a stream of their own; they end by themselves
+    # after about the span of the loop: a step takes ~2 ms)
+    live_clock = None
+    probe = rank == 0 and world == 1 and hasattr(ws, "clock_probe_begin")
+    if probe:
+        try:
+            ws.clock_probe_begin(max(2000, int(args.steps * 1800)))
+        except Exception:
+            probe = False
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -423,6 +444,11 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms, launches = ws.kernel_time(True)
     ws.enable_timing(False)
+    if probe:
+        try:
+            live_clock = ws.clock_probe_end()
+        except Exception:
+            live_clock = None
     ws.check()  # no asynchronous run of the timed loop reported a look-back time-out / kernel error
 
     if distributed:
@@ -497,7 +523,7 @@ def main():
         achieved = alg_bytes / kern_s / 1e9
         traffic, valu, prov = (None, None, "not recorded for this workload")
         if args.workload == "headline" and n == N_BASES:
-            traffic, valu, prov = recorded_counters(kern_s * 1e3)
+            traffic, valu, prov = recorded_counters(kern_s * 1e3, live_clock)
         config = {"workload": workload, "k": k, "w": w, "bases_per_gpu": my_bases, "outputs_per_gpu": n_out,
                   "kernel": kernel_name, "parallelism": f"shard{world}"}
         if gather_ms is not None:

@@ -338,6 +338,12 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
 int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
                          uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
                          uint64_t max_records, uint64_t *d_counts, uint64_t *out_counts /* [2] */);
+/* Diagnostics: the shader clock while other work runs on the device.  _begin starts a handful of sleeping
+ * single-wave workgroups on a stream of the workspace's own that sample the shader cycle counter against the
+ * 100 MHz real-time counter for duration_us; _end waits for them and returns the mean clock in GHz (bench.py
+ * brackets its timed loop with the pair: the VALU bound of roofline.valu is priced at THIS clock). */
+int mm_clock_probe_begin(mm_workspace_t *ws, uint64_t duration_us);
+int mm_clock_probe_end(mm_workspace_t *ws, double *ghz);
 /* Deterministic synthetic PackedSeq generator G of BASELINE.md §4, written on the device. */
 int mm_generate_device_async(mm_workspace_t *ws, uint64_t seed, uint64_t first_base,
                              uint64_t n_bases, uint8_t *d_packed /* ceil(n/4) bytes */);

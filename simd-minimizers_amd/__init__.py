@@ -91,6 +91,8 @@ def lib():
         L.mm_workspace_destroy.restype = None
         L.mm_workspace_sync.argtypes = [vp]
         L.mm_workspace_check.argtypes = [vp]
+        L.mm_clock_probe_begin.argtypes = [vp, C.c_uint64]
+        L.mm_clock_probe_end.argtypes = [vp, C.POINTER(C.c_double)]
         L.mm_workspace_force_generic.argtypes = [vp, C.c_int]
         L.mm_workspace_set_blocks_per_lane.argtypes = [vp, C.c_uint32]
         L.mm_workspace_enable_timing.argtypes = [vp, C.c_int]
@@ -159,6 +161,7 @@ EXPORTED_SYMBOLS = [
     "mm_run_reads_skip_ambiguous_device", "mm_pack_ascii_n_device_async", "mm_pack_ascii_device_async",
     "mm_host_alloc", "mm_host_free",
     "mm_generate_device_async", "mm_fasta_pack_device_async", "mm_fasta_pack_device",
+    "mm_clock_probe_begin", "mm_clock_probe_end",
 ]
 
 
@@ -303,6 +306,16 @@ class Workspace:
         """Completion status of the asynchronous runs since the last check (mm_workspace_check):
         raises MinimizerError(ORDER) if one of them has to be repeated."""
         _check(lib().mm_workspace_check(self.h))
+
+    def clock_probe_begin(self, duration_us: int):
+        """Start sampling the shader clock for ``duration_us`` on a stream of the workspace's own (diagnostics)."""
+        _check(lib().mm_clock_probe_begin(self.h, int(duration_us)))
+
+    def clock_probe_end(self) -> float:
+        """Mean shader clock in GHz over the sampled span."""
+        g = C.c_double()
+        _check(lib().mm_clock_probe_end(self.h, C.byref(g)))
+        return g.value
 
     def force_generic(self, on: bool):
         _check(lib().mm_workspace_force_generic(self.h, int(on)))

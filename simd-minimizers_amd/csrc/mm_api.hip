@@ -112,6 +112,9 @@ struct mm_workspace {
     // split path (walk + expander on a second stream): dump slots, tile status, redo list, fork / join events
     mm::SplitBuffers split;
     bool no_split = false;  // the split path failed once on this workspace: fused kernel from then on
+    // diagnostics: shader-clock probe on a stream of its own (mm_clock_probe_*)
+    hipStream_t probe_stream = nullptr;
+    unsigned long long *probe_out = nullptr;
     // generic-path scratch
     void *scratch = nullptr;
     uint64_t scratch_bytes = 0;
@@ -448,6 +451,11 @@ void mm_workspace_destroy(mm_workspace_t *ws) {
     if (ws->split.ev_fork) hipEventDestroy(ws->split.ev_fork);
     if (ws->split.ev_join) hipEventDestroy(ws->split.ev_join);
     if (ws->split.aux) hipStreamDestroy(ws->split.aux);
+    if (ws->probe_stream) {
+        hipStreamSynchronize(ws->probe_stream);
+        hipStreamDestroy(ws->probe_stream);
+    }
+    if (ws->probe_out) hipFree(ws->probe_out);
     if (ws->ticket) hipFree(ws->ticket);
     if (ws->total) hipFree(ws->total);
     if (ws->h_total) hipHostFree(ws->h_total);
@@ -1572,6 +1580,36 @@ int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_b
     MM_HIP(hipMemcpyAsync(out_counts, d_counts, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ws->stream));
     MM_HIP(hipStreamSynchronize(ws->stream));
     if (out_counts[0] > (packed_capacity_bytes & ~3ull) * 4 || out_counts[1] > max_records) return MM_ERR_CAPACITY;
+    return MM_OK;
+}
+
+static const uint32_t kProbeGroups = 16;
+
+int mm_clock_probe_begin(mm_workspace_t *ws, uint64_t duration_us) {
+    if (!ws) return MM_ERR_NULL;
+    MM_HIP(hipSetDevice(ws->device));
+    if (!ws->probe_stream) {
+        MM_HIP(hipStreamCreateWithFlags(&ws->probe_stream, hipStreamNonBlocking));
+        MM_HIP(hipMalloc(reinterpret_cast<void **>(&ws->probe_out), kProbeGroups * 2 * sizeof(unsigned long long)));
+    }
+    MM_HIP(hipMemsetAsync(ws->probe_out, 0, kProbeGroups * 2 * sizeof(unsigned long long), ws->probe_stream));
+    if (mm::launch_clock_probe(ws->probe_out, kProbeGroups, duration_us * 100ull, ws->probe_stream))
+        return hip_fail(hipGetLastError(), "clock_probe");
+    return MM_OK;
+}
+
+int mm_clock_probe_end(mm_workspace_t *ws, double *ghz) {
+    if (!ws || !ghz || !ws->probe_stream) return MM_ERR_NULL;
+    MM_HIP(hipSetDevice(ws->device));
+    unsigned long long h[kProbeGroups * 2];
+    MM_HIP(hipMemcpyAsync(h, ws->probe_out, sizeof h, hipMemcpyDeviceToHost, ws->probe_stream));
+    MM_HIP(hipStreamSynchronize(ws->probe_stream));
+    double cyc = 0, real = 0;
+    for (uint32_t b = 0; b < kProbeGroups; ++b) {
+        cyc += (double)h[2 * b];
+        real += (double)h[2 * b + 1];
+    }
+    *ghz = real > 0 ? cyc / real * 0.1 : 0.0;  // the real-time counter ticks at 100 MHz
     return MM_OK;
 }
 

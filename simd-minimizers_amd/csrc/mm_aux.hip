@@ -338,4 +338,25 @@ int launch_generate(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d_p
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// Shader clock under load (diagnostics, mm_clock_probe_*): a few single-wave workgroups that do nothing but sleep
+// sample the shader cycle counter (s_memtime) against the 100 MHz real-time counter (s_memrealtime) for `ticks`
+// real-time ticks while whatever else runs on the chip; out[2b] = shader cycles, out[2b + 1] = real-time ticks.
+__global__ __launch_bounds__(kWave) void clock_probe_kernel(unsigned long long *out, unsigned long long ticks) {
+    unsigned long long c0, r0, c1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0));
+    do {
+        __builtin_amdgcn_s_sleep(127);
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1));
+    } while (r1 - r0 < ticks);
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = c1 - c0;
+        out[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+
+int launch_clock_probe(unsigned long long *d_out, uint32_t workgroups, uint64_t ticks, hipStream_t stream) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(workgroups), dim3(kWave), 0, stream, d_out, (unsigned long long)ticks);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 }  // namespace mm

@@ -124,6 +124,8 @@ uint64_t fasta_scratch_bytes(uint64_t n_bytes);
 int launch_fasta_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed, uint64_t packed_capacity_bytes,
                       unsigned long long *d_rec_base, unsigned long long *d_rec_pos, uint64_t max_records,
                       unsigned long long *d_counts, void *scratch, hipStream_t stream);
+// diagnostics: shader clock while other kernels run (out: 2 words per workgroup)
+int launch_clock_probe(unsigned long long *d_out, uint32_t workgroups, uint64_t ticks, hipStream_t stream);
 int launch_generate(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d_packed,
                     hipStream_t stream);
 

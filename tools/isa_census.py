@@ -2,8 +2,9 @@
 """Static census of the dominant kernel's main loop (runs on the build box, no GPU): compiles
 mm::fused_kernel<W, CANON, ...> to gfx950 assembly with hipcc -S, finds the W-block loop of the plain
 walk (fast emit, no range / ambiguity checks) and counts its VALU instructions by issue rate
-(full / half rate as measured on MI355X, profiles/r01_valu_issue_rates.txt: 2.5 / 4.3 clocks per wave64
-instruction; any SGPR source operand makes an instruction half rate).  Writes profiles/head_isa_census.json,
+(full / half rate as measured on MI355X in SHADER CYCLES, profiles/r03_valu_issue_rates.txt: 2.31 / 4.14 cycles
+per wave64 instruction - tools/ubench/valu_rate.hip reads the shader clock under every loop since round 3, the
+round-1 table assumed 2.4 GHz and read 2.5 / 4.3; any SGPR source operand makes an instruction half rate).  Writes profiles/head_isa_census.json,
 which bench.py reads for roofline.valu.issue_clk.  usage: isa_census.py [W] [canon 0|1]"""
 import collections
 import hashlib
@@ -49,7 +50,7 @@ for i, s in enumerate(insts):
         continue
     body = insts[labels[m.group(1)]:i + 1]
     ops = collections.Counter(b.split()[0] for b in body)
-    if ops["v_cmp_ne_u32_sdwa"] + ops["v_cmpx_ne_u32_sdwa"] != W or ops["ds_write_b16"] != W:
+    if ops["v_cmp_ne_u32_sdwa"] + ops["v_cmpx_ne_u32_sdwa"] != W or ops["ds_write_b16"] + ops["ds_write_b8"] != W:
         continue
     if sum(v for o, v in ops.items() if o.startswith("ds_read")) != W or not any(o.startswith("buffer_load") for o in ops):
         continue  # (the block loop proper: W table look-ups, W list appends, the sequence loads of a later block)
@@ -68,13 +69,19 @@ h = hashlib.sha256()
 for f in ("mm_fused_impl.h", "mm_common.h"):
     h.update(open(os.path.join(csrc, f), "rb").read())
 full, half = cls["valu_full"], cls["valu_half"]
+# shader cycles per wave64 instruction (means over the instructions of each class in profiles/r03_valu_issue_rates.txt,
+# "by wall time at that clock"); the architectural figures are 2 and 4 (MI355X_MICROARCH.md)
+FULL, HALF = 2.31, 4.14
 rec = {"kernel": f"mm::fused_kernel<{W}, {c}, {c}, 0, false, false>", "kernel_source_sha": h.hexdigest()[:16],
        "main_loop_windows": W, "main_loop_instructions": len(best), "valu_full_rate": full, "valu_half_rate": half,
        "salu": cls["salu"], "lds": cls["lds"], "vmem": cls["vmem"],
        "valu_per_window": round((full + half) / W, 2),
-       "issue_clk_per_valu": round((2.5 * full + 4.3 * half) / (full + half), 3),
-       "issue_clk_per_window": round((2.5 * full + 4.3 * half) / W, 1),
-       "rates": "2.5 / 4.3 clocks per full- / half-rate wave64 VALU instruction (profiles/r01_valu_issue_rates.txt)",
+       "issue_clk_per_valu": round((FULL * full + HALF * half) / (full + half), 3),
+       "issue_clk_per_window": round((FULL * full + HALF * half) / W, 1),
+       "ideal_clk_per_valu": round((2.0 * full + 4.0 * half) / (full + half), 3),
+       "rates": f"{FULL} / {HALF} shader cycles per full- / half-rate wave64 VALU instruction, measured with the shader "
+                "clock read under each loop (profiles/r03_valu_issue_rates.txt); ideal_clk_per_valu uses the "
+                "architectural 2 / 4",
        **meta}
 out = os.path.join(ROOT, "profiles", "head_isa_census.json" if (W, CANON) == (11, True) else f"isa_census_w{W}_{'canon' if CANON else 'fwd'}.json")
 json.dump(rec, open(out, "w"), indent=1)

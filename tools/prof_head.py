@@ -147,11 +147,53 @@ def config(tag, cfg):
     open(os.path.join(OUT, f"{tag}_{cfg}.txt"), "w").writelines(lines)
 
 
+def component(tag, cfg):
+    """One of the rows either side of the path (simd_minimizers_amd.workloads): kernel trace of `run_config.py cfg 5 3`
+    and FETCH_SIZE / WRITE_SIZE summed over the kernels of one step."""
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wl", os.path.join(ROOT, "simd-minimizers_amd", "workloads.py"))
+    likes = {"READS": ["fused_kernel"], "READS_SK": ["fused_kernel"], "SKIP": ["window_ambiguity_kernel", "fused_kernel"],
+             "VALUES": ["values_u64_kernel"], "PACK": ["pack_ascii"], "FASTA": ["fasta"]}[cfg]
+    lines = []
+    db = rocprof(f"{tag}_{cfg}_stats", None, ["python3", "tools/run_config.py", cfg, "5", "3"])
+    lines.append(f"== rocprofv3 --kernel-trace --stats -- python3 tools/run_config.py {cfg} 5 3\n")
+    for r in top_kernels(db)[:8]:
+        lines.append(f"{r[0][:90]:90s} calls={r[1]:4d} total_us={r[2]:12.1f} avg_us={r[3]:10.2f} pct={r[4]:5.1f}\n")
+    try:
+        log = open(os.path.join(OUT, f"{tag}_{cfg}_stats.log")).read().strip().split("\n")
+        lines.append("-- run_config line (torch events, under the profiler): " + [x for x in log if x.startswith("{")][-1] + "\n")
+    except Exception:
+        pass
+    steps = 3 + 2
+    tot = {}
+    for name, pmc in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])):
+        db = rocprof(f"{tag}_{cfg}_{name}", pmc, ["python3", "tools/run_config.py", cfg, "3", "2"])
+        if not db:
+            continue
+        cur = sqlite3.connect(db).cursor()
+        acc = collections.defaultdict(float)
+        n = collections.defaultdict(int)
+        for k, c, v in cur.execute("select kernel_name,counter_name,value from counters_collection"):
+            if any(l in k for l in likes):
+                acc[c] += v
+                n[c] += 1
+        for c in acc:
+            tot[c] = acc[c] / steps
+            lines.append(f"{c:14s} {n[c]} dispatches of {likes} over {steps} steps: {tot[c]:.1f} KB per step\n")
+    if len(tot) == 2:
+        lines.append(f"-- HBM bytes per step = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = {int((2 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024)}"
+                     "  (FETCH_SIZE doubled: the gfx950 correction for coalesced streams; compare with algorithmic_bytes above)\n")
+    open(os.path.join(OUT, f"{tag}_{cfg}.txt"), "w").writelines(lines)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     tag = sys.argv[1]
     for what in sys.argv[2:]:
         if what == "headline":
             headline(tag)
+        elif what in ("READS", "READS_SK", "SKIP", "VALUES", "PACK", "FASTA"):
+            component(tag, what)
         else:
             config(tag, what)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs ONE secondary configuration a few times (the command rocprofv3 wraps for the per-configuration
-profiles under profiles/): tools/run_config.py <C2|FWD|C4|C5|READS|C3> [steps] [warmup].
+profiles under profiles/): tools/run_config.py <C2|FWD|C4|C5|READS|C3|READS_SK|SKIP|VALUES|PACK|FASTA> [steps] [warmup].
 Prints kernel time by HIP events (median) as one JSON line.  Measurement aid, not part of the product."""
 import json
 import os
@@ -26,6 +26,12 @@ def gen(n, seed):
     sm._check(sm.lib().mm_generate_device_async(ws.h, seed, 0, n, t.data_ptr()))
     return t
 
+
+from simd_minimizers_amd import workloads  # noqa: E402
+
+if cfg in workloads.COMPONENTS:  # the rows either side of the path
+    print(json.dumps(workloads.measure(cfg, ws, dev, warm=warm, reps=steps)))
+    sys.exit(0)
 
 N = 3_100_000_000
 if cfg in ("C2", "FWD", "C3", "C5"):

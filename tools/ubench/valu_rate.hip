@@ -1,15 +1,21 @@
 // Micro-benchmark: issue rate of the VALU ops the minimizer kernel is made of (gfx950).
 // Each kernel runs a long unrolled chain mix of ONE instruction on 8 independent registers.
+// Round 3: the rate is reported in SHADER CYCLES, not at an assumed clock: lane 0 of every workgroup reads
+// s_memtime (the shader clock counter) and s_memrealtime (100 MHz) around its loop; eight workgroups per CU are
+// resident together (2048 in all), so a SIMD issues 8 x iters x REP wave-instructions during one workgroup's
+// span.  The shader clock under each loop is printed beside it (d s_memtime / d s_memrealtime x 100 MHz).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 
 #define REP 256
 template <int OP>
-__global__ __launch_bounds__(256) void k(unsigned *out, unsigned seed, int iters) {
+__global__ __launch_bounds__(256) void k(unsigned *out, unsigned seed, int iters, unsigned long long *ts) {
     unsigned a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
     unsigned b = seed * 2654435761u + threadIdx.x, c = b ^ 0x55aa55aa;
     unsigned long long m64 = 0x5555aaaa5555aaaaull * seed;
+    unsigned long long c0, r0, c1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0));
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int r = 0; r < REP / 8; ++r) {
@@ -70,25 +76,40 @@ __global__ __launch_bounds__(256) void k(unsigned *out, unsigned seed, int iters
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1));
+    if (threadIdx.x == 0 && ts) {
+        ts[2 * blockIdx.x] = c1 - c0;
+        ts[2 * blockIdx.x + 1] = r1 - r0;
+    }
 }
+
+static unsigned long long *g_ts;
 
 template <int OP>
 void run(const char *name, unsigned *d) {
     const int blocks = 256 * 8, iters = 200;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1u, 2);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 1u, 2, (unsigned long long *)nullptr);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 7u, iters);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 7u, iters, g_ts);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    double winst = (double)blocks * 4 * iters * REP;       // wave-instructions
-    double per_simd_per_clk = winst / (ms * 1e-3) / (1024.0 * 2.4e9);
-    printf("%-28s %8.3f ms  %.3f wave-instr/clk/SIMD (@2.4GHz)  -> %.2f clk per wave-instr\n", name, ms, per_simd_per_clk, 1.0 / per_simd_per_clk);
+    std::vector<unsigned long long> h(2 * blocks);
+    hipMemcpy(h.data(), g_ts, h.size() * 8, hipMemcpyDeviceToHost);
+    double cyc = 0, real = 0;
+    for (int b = 0; b < blocks; ++b) { cyc += (double)h[2 * b]; real += (double)h[2 * b + 1]; }
+    cyc /= blocks; real /= blocks;
+    const double per_simd = 8.0 * iters * REP;  // wave-instructions a SIMD issues during one workgroup's span
+    const double ghz = cyc / real * 0.1;          // s_memrealtime ticks at 100 MHz
+    double winst = (double)blocks * 4 * iters * REP;
+    printf("%-28s %8.3f ms  %6.3f shader cycles per wave-instr  (shader clock %.3f GHz; by wall time at that clock: %.3f)\n",
+           name, ms, cyc / per_simd, ghz, (ms * 1e-3) * ghz * 1e9 * 1024.0 / winst);
 }
 
 int main() {
     unsigned *d; hipMalloc(&d, 256 * 8 * 256 * 4);
+    hipMalloc(&g_ts, 256 * 8 * 16);
     run<0>("v_xor_b32", d); run<5>("v_add_u32", d); run<6>("v_min_u32", d); run<12>("v_lshrrev_b32 imm", d);
     run<7>("v_bfe_u32 imm", d); run<1>("v_alignbit_b32 imm", d); run<10>("v_alignbit_b32 sgpr", d);
     run<2>("v_min3_u32", d); run<3>("v_and_or_b32 vvv", d); run<11>("v_and_or_b32 vvs", d);
