@@ -221,6 +221,50 @@ def recorded_counters(kernel_ms, live_clock_ghz=None):
     return traffic, valu, prov
 
 
+# --------------------------------------------------------------------------- one process, several devices
+def single_process(args):
+    """`--single-process --gpus N`: the several-device entry point a C / Rust caller uses."""
+    import numpy as np
+    import torch
+
+    import simd_minimizers_amd as sm
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        sys.exit("bench.py --single-process: no GPU")
+    # fewer devices than --gpus: entries share devices (a functional check, labelled as such)
+    devices = [i % n_dev for i in range(args.gpus)]
+    n = min(args.bases, 1 << 30)  # host buffers: 256 MB packed in, ~0.7 GB of positions out
+    ws = sm.default_workspace(0)
+    d = sm.generate_device(n, SEED)
+    torch.cuda.synchronize()
+    hp, hp_owner = sm.pinned_array(((n + 3) // 4 + 64,), np.uint8)
+    hp[:] = d.cpu().numpy()
+    del d
+    g = sm.DeviceGroup(devices)
+    b = sm.canonical_minimizers(K, W)
+    cap = int(n * 2.3 / (W + 1)) + 4096
+    for _ in range(max(1, args.warmup // 4)):
+        pos, _ = g.run(b, hp, n, capacity=cap)
+    t0 = time.perf_counter()
+    steps = max(1, args.steps // 4)
+    for _ in range(steps):
+        pos, _ = g.run(b, hp, n, capacity=cap)
+    dt = time.perf_counter() - t0
+    one, _ = sm.DeviceGroup([0]).run(b, hp, n, capacity=cap)
+    assert np.array_equal(pos, one), "sharded result differs from the one-device result"
+    print(json.dumps({
+        "metric": "Gbases/s, canonical minimizers k=21 w=11 through mm_run_sharded_host (host buffers, PCIe-inclusive)",
+        "value": round(n * steps / dt / 1e9, 3), "unit": "Gbases/s", "n_gpus": args.gpus, "steps": steps,
+        "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"ONE {n} bp PackedSeq in host memory cut into {args.gpus} window ranges by "
+                               "mm_run_sharded_host (one host thread and one workspace per entry, exact seam, one dense "
+                               "host result); H2D + kernel + D2H per shard: PCIe-bound",
+                   "devices": devices, "distinct_devices": len(set(devices)), "outputs": int(len(pos)),
+                   "parallelism": f"device_group{args.gpus}"}}), flush=True)
+    return 0
+
+
 # --------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -233,7 +277,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the untimed secondary configurations, the median-of-5 and the end-to-end figure")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N devices driven from THIS process through the C ABI's device group (mm_run_sharded_host: "
+                         "host buffers in, one dense host result out, one host thread per device, no torch.distributed). "
+                         "PCIe-inclusive by construction: a separate line, never the headline `value`")
     args = ap.parse_args()
+    if args.single_process:
+        sys.exit(single_process(args))
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not launched:
@@ -425,15 +475,6 @@ def main():
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    # shader clock during the timed loop (16 sleeping waves on a stream of their own; they end by themselves
-    # after about the span of the loop: a step takes ~2 ms)
-    live_clock = None
-    probe = rank == 0 and world == 1 and hasattr(ws, "clock_probe_begin")
-    if probe:
-        try:
-            ws.clock_probe_begin(max(2000, int(args.steps * 1800)))
-        except Exception:
-            probe = False
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -444,8 +485,18 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms, launches = ws.kernel_time(True)
     ws.enable_timing(False)
-    if probe:
+    # Shader clock under this kernel, sampled OUTSIDE the timed region over a few more identical steps: 16 sleeping
+    # waves on a stream of their own read the shader cycle counter against the 100 MHz real-time counter
+    # (mm_clock_probe_*).  Not inside the timed loop: a second active queue alone slows the steps by ~7 %
+    # (measured: 1.96 against 1.82 ms), whatever runs on it.
+    live_clock = None
+    if rank == 0 and world == 1 and hasattr(ws, "clock_probe_begin"):
         try:
+            probe_steps = max(4, args.steps // 2)
+            ws.clock_probe_begin(int(probe_steps * kern_ms / max(1, launches) * 1000 * 0.9))
+            for _ in range(probe_steps):
+                step()
+            torch.cuda.synchronize(dev)
             live_clock = ws.clock_probe_end()
         except Exception:
             live_clock = None

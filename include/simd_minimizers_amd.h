@@ -52,6 +52,7 @@ typedef enum mm_mode { MM_MINIMIZERS = 0, MM_CLOSED_SYNCMERS = 1, MM_OPEN_SYNCME
  * two-stream form: the same walk, its lists expanded to positions by a second, concurrent kernel. */
 typedef enum mm_path { MM_PATH_FUSED = 1, MM_PATH_GENERIC = 2, MM_PATH_SPLIT = 3 } mm_path_t;
 
+typedef struct mm_device_group mm_device_group_t; /* one workspace per listed device (several-device calls) */
 typedef struct mm_plan mm_plan_t;           /* immutable (k, w, hasher, mode): the Builder     */
 typedef struct mm_workspace mm_workspace_t; /* per-stream device scratch: the thread-local CACHE
                                                of src/lib.rs:217-219, src/collect.rs:124-126   */
@@ -338,6 +339,28 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
 int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
                          uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
                          uint64_t max_records, uint64_t *d_counts, uint64_t *out_counts /* [2] */);
+/* ------------------------------------------------------------------ several devices from one call
+ * The reference's parallel driver is host code: rayon over the contigs, one Builder::run each
+ * (bench/src/bin/paper.rs:442-459).  A device group holds one workspace (stream, scratch) per listed device; a
+ * device may be listed more than once.  Both calls run one host thread per entry, keep the count exchange on
+ * the host (nothing crosses between the devices) and deliver ONE dense result in the caller's host buffers. */
+int mm_device_group_create(mm_device_group_t **out, const int *devices, int n_devices);
+void mm_device_group_destroy(mm_device_group_t *group);
+int mm_device_group_size(const mm_device_group_t *group);
+/* One sequence cut into n equal window ranges, one per entry of the group: absolute positions, exact seam (a
+ * range's first position equal to the last one before it is dropped, src/collect.rs:265-271; syncmers have no
+ * such rule).  Same result as mm_run_host.  MM_ERR_CAPACITY: *out_count holds the need (before seam drops). */
+int mm_run_sharded_host(const mm_plan_t *plan, mm_device_group_t *group, const uint8_t *packed,
+                        uint64_t base_offset, uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk /* or NULL */,
+                        uint64_t capacity, uint64_t *out_count);
+/* n_seqs independent sequences (contigs) placed greedily, longest first, on the entries of the group; every
+ * entry runs its sequences in one batch launch.  Positions are sequence-local and lie in input order:
+ * sequence s = out_pos[out_offsets[s] .. out_offsets[s + 1]).  Same result as mm_run_batch_device. */
+int mm_run_batch_sharded_host(const mm_plan_t *plan, mm_device_group_t *group, uint64_t n_seqs,
+                              const uint8_t *const *packed, const uint64_t *base_offsets /* or NULL */,
+                              const uint64_t *n_bases, uint32_t *out_pos, uint32_t *out_sk /* or NULL */,
+                              uint64_t capacity, uint64_t *out_offsets /* [n_seqs + 1] */);
+
 /* Diagnostics: the shader clock while other work runs on the device.  _begin starts a handful of sleeping
  * single-wave workgroups on a stream of the workspace's own that sample the shader cycle counter against the
  * 100 MHz real-time counter for duration_us; _end waits for them and returns the mean clock in GHz (bench.py

@@ -238,6 +238,15 @@ class Builder {  // src/lib.rs:225-230
         return pos;
     }
 
+    // the immutable plan of this builder (caller destroys it); k and w
+    mm_plan_t *make_plan() const {
+        mm_plan_t *plan = nullptr;
+        check(mm_plan_create(&plan, k_, w_, CANONICAL, (mm_mode_t)SYNCMER, has_hasher_ ? &hasher_ : nullptr));
+        return plan;
+    }
+    uint32_t k() const { return k_; }
+    uint32_t w() const { return w_; }
+
   private:
     // one pass of the hot path over `seq` on the device; fills pos (and sk), returns the count
     uint64_t compute(PackedSeq seq, Workspace &ws, std::vector<uint32_t> &pos, std::vector<uint32_t> &sk) const {
@@ -260,6 +269,64 @@ class Builder {  // src/lib.rs:225-230
     bool has_hasher_ = false;
     std::vector<uint32_t> *sk_ = nullptr;
     Workspace *ws_ = nullptr;
+};
+
+// Several devices from one call: the reference's rayon loop over contigs (bench/src/bin/paper.rs:442-459) behind
+// the C ABI.  A group holds one workspace per listed device (a device may be listed more than once).
+class DeviceGroup {
+  public:
+    explicit DeviceGroup(const std::vector<int> &devices) {
+        check(mm_device_group_create(&g_, devices.data(), (int)devices.size()));
+    }
+    ~DeviceGroup() { mm_device_group_destroy(g_); }
+    DeviceGroup(const DeviceGroup &) = delete;
+    DeviceGroup &operator=(const DeviceGroup &) = delete;
+    mm_device_group_t *get() const { return g_; }
+    int size() const { return mm_device_group_size(g_); }
+
+    // Builder::run over all devices of the group: one sequence cut into window ranges (absolute positions,
+    // exact seam); positions are APPENDED to min_pos with the last() rule like run()
+    template <bool CANONICAL, int SYNCMER>
+    void run(const Builder<CANONICAL, SYNCMER> &b, PackedSeq seq, std::vector<uint32_t> &min_pos) const {
+        mm_plan_t *plan = b.make_plan();
+        const uint64_t l = (uint64_t)b.k() + b.w() - 1;
+        const uint64_t cap = seq.len >= l ? seq.len - l + 1 : 0;
+        std::vector<uint32_t> pos(cap ? cap : 1);
+        uint64_t n = 0;
+        const int r = mm_run_sharded_host(plan, g_, seq.data, seq.offset, seq.len, pos.data(), nullptr, cap, &n);
+        mm_plan_destroy(plan);
+        check(r);
+        size_t first = 0;
+        if (SYNCMER == 0)
+            while (first < n && !min_pos.empty() && pos[first] == min_pos.back()) ++first;
+        min_pos.insert(min_pos.end(), pos.begin() + first, pos.begin() + n);
+    }
+    // one Builder::run per sequence (paper.rs:425-431), the sequences placed greedily on the devices: positions
+    // are sequence-local, sequence s = pos[offsets[s] .. offsets[s + 1])
+    template <bool CANONICAL, int SYNCMER>
+    void run_batch(const Builder<CANONICAL, SYNCMER> &b, const std::vector<PackedSeq> &seqs, std::vector<uint32_t> &pos,
+                   std::vector<uint64_t> &offsets) const {
+        mm_plan_t *plan = b.make_plan();
+        std::vector<const uint8_t *> ptr;
+        std::vector<uint64_t> off, len;
+        uint64_t cap = 1;
+        for (const PackedSeq &s : seqs) {
+            ptr.push_back(s.data);
+            off.push_back(s.offset);
+            len.push_back(s.len);
+            cap += s.len;
+        }
+        pos.assign(cap, 0);
+        offsets.assign(seqs.size() + 1, 0);
+        const int r = mm_run_batch_sharded_host(plan, g_, seqs.size(), ptr.data(), off.data(), len.data(), pos.data(),
+                                                nullptr, cap, offsets.data());
+        mm_plan_destroy(plan);
+        check(r);
+        pos.resize(offsets.back());
+    }
+
+  private:
+    mm_device_group_t *g_ = nullptr;
 };
 
 // constructors, src/lib.rs:240-321

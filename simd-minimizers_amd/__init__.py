@@ -91,6 +91,12 @@ def lib():
         L.mm_workspace_destroy.restype = None
         L.mm_workspace_sync.argtypes = [vp]
         L.mm_workspace_check.argtypes = [vp]
+        L.mm_device_group_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
+        L.mm_device_group_destroy.argtypes = [vp]
+        L.mm_device_group_destroy.restype = None
+        L.mm_device_group_size.argtypes = [vp]
+        L.mm_run_sharded_host.argtypes = [vp, vp, u8p, C.c_uint64, C.c_uint64, u32p, u32p, C.c_uint64, u64p]
+        L.mm_run_batch_sharded_host.argtypes = [vp, vp, C.c_uint64, C.POINTER(u8p), u64p, u64p, u32p, u32p, C.c_uint64, u64p]
         L.mm_clock_probe_begin.argtypes = [vp, C.c_uint64]
         L.mm_clock_probe_end.argtypes = [vp, C.POINTER(C.c_double)]
         L.mm_workspace_force_generic.argtypes = [vp, C.c_int]
@@ -162,6 +168,8 @@ EXPORTED_SYMBOLS = [
     "mm_host_alloc", "mm_host_free",
     "mm_generate_device_async", "mm_fasta_pack_device_async", "mm_fasta_pack_device",
     "mm_clock_probe_begin", "mm_clock_probe_end",
+    "mm_device_group_create", "mm_device_group_destroy", "mm_device_group_size", "mm_run_sharded_host",
+    "mm_run_batch_sharded_host",
 ]
 
 
@@ -333,6 +341,71 @@ class Workspace:
 
     def last_path(self) -> int:
         return lib().mm_workspace_last_path(self.h)
+
+
+class DeviceGroup:
+    """``mm_device_group_t``: one workspace per listed device (a device may be listed more than once); the
+    several-device calls fan one sequence (window ranges, exact seam) or a set of sequences (greedy placement)
+    over them - the reference's rayon loop over contigs (bench/src/bin/paper.rs:442-459) behind the C ABI."""
+
+    def __init__(self, devices):
+        self.h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        _check(lib().mm_device_group_create(C.byref(self.h), arr, len(devices)))
+
+    def __len__(self):
+        return lib().mm_device_group_size(self.h)
+
+    def close(self):
+        if self.h:
+            lib().mm_device_group_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, builder: "Builder", packed: np.ndarray, n_bases: int, base_offset: int = 0, capacity=None):
+        """One host PackedSeq over all entries (``mm_run_sharded_host``): (positions, super-k-mer indices or None)."""
+        plan = builder.plan()
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        l = builder.k + builder.w - 1
+        cap = max(1, n_bases - l + 1) if capacity is None else capacity
+        pos = np.empty(cap, dtype=np.uint32)
+        sk = np.empty(cap, dtype=np.uint32) if builder._sk is not None else None
+        cnt = C.c_uint64()
+        code = lib().mm_run_sharded_host(plan.h, self.h, packed.ctypes.data_as(C.POINTER(C.c_uint8)), base_offset, n_bases,
+                                         pos.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                         sk.ctypes.data_as(C.POINTER(C.c_uint32)) if sk is not None else None, cap,
+                                         C.byref(cnt))
+        if code == ERR["CAPACITY"]:
+            raise MinimizerError(code, f"output capacity {cap} < {cnt.value}")
+        _check(code)
+        return pos[:cnt.value], (sk[:cnt.value] if sk is not None else None)
+
+    def run_batch(self, builder: "Builder", seqs, n_bases, base_offsets=None, capacity=None):
+        """Independent host sequences placed greedily on the entries (``mm_run_batch_sharded_host``): (positions,
+        super-k-mer indices or None, n + 1 offsets); sequence-local positions in input order."""
+        plan = builder.plan()
+        n = len(seqs)
+        keep = [np.ascontiguousarray(a, dtype=np.uint8) for a in seqs]
+        ptrs = (C.POINTER(C.c_uint8) * max(n, 1))(*[a.ctypes.data_as(C.POINTER(C.c_uint8)) for a in keep])
+        lens = (C.c_uint64 * max(n, 1))(*n_bases)
+        offs = (C.c_uint64 * max(n, 1))(*(base_offsets or [0] * n))
+        cap = max(1, sum(n_bases)) if capacity is None else capacity
+        pos = np.empty(cap, dtype=np.uint32)
+        sk = np.empty(cap, dtype=np.uint32) if builder._sk is not None else None
+        out_offsets = (C.c_uint64 * (n + 1))()
+        code = lib().mm_run_batch_sharded_host(plan.h, self.h, n, ptrs, offs, lens, pos.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                               sk.ctypes.data_as(C.POINTER(C.c_uint32)) if sk is not None else None, cap,
+                                               out_offsets)
+        if code == ERR["CAPACITY"]:
+            raise MinimizerError(code, f"output capacity {cap} < {out_offsets[n]}")
+        _check(code)
+        o = [int(x) for x in out_offsets]
+        return pos[:o[-1]], (sk[:o[-1]] if sk is not None else None), o
 
 
 _default_ws: dict[int, Workspace] = {}

@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -1621,6 +1623,306 @@ int mm_generate_device_async(mm_workspace_t *ws, uint64_t seed, uint64_t first_b
     MM_HIP(hipSetDevice(ws->device));
     if (mm::launch_generate(seed, first_base, n_bases, d_packed, ws->stream))
         return hip_fail(hipGetLastError(), "generate");
+    return MM_OK;
+}
+
+// ------------------------------------------------------------------ several devices from one call
+// The reference's parallel driver is ordinary host code: rayon over the contigs of a genome, one Builder::run
+// per contig (bench/src/bin/paper.rs:442-459).  Here the same call shape for a C / Rust caller: a device group
+// holds one workspace per listed device (a device may be listed more than once), and one call fans a sequence
+// (window ranges, exact seam) or a set of sequences (greedy longest-first placement) over them - one host
+// thread per entry, every shard's positions copied to its place in the caller's single buffer.  The count
+// exchange is host-side, so nothing crosses between the devices (no RCCL): results go to host memory.
+struct mm_device_group {
+    std::vector<mm_workspace_t *> ws;
+};
+
+namespace {
+
+struct ShardResult {
+    int rc = MM_OK;
+    std::string err;
+    uint64_t count = 0;
+    uint32_t first = 0, last = 0;
+};
+
+// Positions [from, from + n) of the workspace's staging buffers to the caller's arrays at `to`.
+int copy_shard_out(mm_workspace *ws, uint64_t from, uint64_t n, uint32_t *out_pos, uint32_t *out_sk, uint64_t to) {
+    if (n == 0) return MM_OK;
+    MM_HIP(hipMemcpyAsync(out_pos + to, ws->d_out + from, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ws->stream));
+    if (out_sk)
+        MM_HIP(hipMemcpyAsync(out_sk + to, ws->d_sk + from, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ws->stream));
+    return MM_OK;
+}
+
+}  // namespace
+
+int mm_device_group_create(mm_device_group_t **out, const int *devices, int n_devices) {
+    if (!out) return MM_ERR_NULL;
+    *out = nullptr;
+    if (!devices || n_devices <= 0) return MM_ERR_NULL;
+    mm_device_group *g = new (std::nothrow) mm_device_group;
+    if (!g) return MM_ERR_ALLOC;
+    for (int i = 0; i < n_devices; ++i) {
+        mm_workspace_t *ws = nullptr;
+        const int r = mm_workspace_create(&ws, devices[i], nullptr);
+        if (r) {
+            mm_device_group_destroy(g);
+            return r;
+        }
+        g->ws.push_back(ws);
+    }
+    *out = g;
+    return MM_OK;
+}
+
+void mm_device_group_destroy(mm_device_group_t *g) {
+    if (!g) return;
+    for (mm_workspace_t *ws : g->ws) mm_workspace_destroy(ws);
+    delete g;
+}
+
+int mm_device_group_size(const mm_device_group_t *g) { return g ? (int)g->ws.size() : 0; }
+
+int mm_run_sharded_host(const mm_plan_t *plan, mm_device_group_t *g, const uint8_t *packed, uint64_t base_offset,
+                        uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk, uint64_t capacity,
+                        uint64_t *out_count) {
+    if (!plan || !g || g->ws.empty()) return MM_ERR_NULL;
+    if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    if (out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;
+    if (out_count) *out_count = 0;
+    const uint64_t l = (uint64_t)plan->k + plan->w - 1;
+    const uint64_t n_w = n_bases >= l ? n_bases - l + 1 : 0;
+    if (n_w == 0) return MM_OK;
+    if (!packed) return MM_ERR_NULL;
+    const uint64_t N = g->ws.size();
+    const uint64_t bytes = (base_offset + n_bases + 3) / 4;
+    std::vector<ShardResult> res(N);
+    std::vector<uint64_t> wb(N + 1);
+    for (uint64_t i = 0; i <= N; ++i) wb[i] = n_w / N * i + (n_w % N) * i / N;  // equal window ranges
+    wb[N] = n_w;
+    // ---- phase 1: every shard uploads the bytes its windows read, runs, reports count / first / last
+    auto phase1 = [&](uint64_t i) {
+        ShardResult &r = res[i];
+        mm_workspace *ws = g->ws[i];
+        const uint64_t a = wb[i], e = wb[i + 1];
+        if (a >= e) return;
+        auto fail = [&](int rc) {
+            r.rc = rc;
+            r.err = g_last_error;
+        };
+        if (hipSetDevice(ws->device) != hipSuccess) return fail(MM_ERR_HIP);
+        uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
+        int rc = grow(din, ws->d_in_bytes, bytes + 16, 1);  // (the whole extent, so that positions stay absolute;
+        ws->d_in = din;                                     // only this shard's slice of it is filled)
+        if (rc) return fail(rc);
+        // element 0 of the first lane is the k-mer before window a; the walk's loads run a few dwords ahead
+        const uint64_t b0 = a ? ((base_offset + a - 1) / 4) & ~15ull : 0;
+        uint64_t b1 = (base_offset + e + l - 2) / 4 + 1 + 64 + plan->w / 2;
+        if (b1 > bytes) b1 = bytes;
+        if (hipMemcpyAsync(din + b0, packed + b0, b1 - b0, hipMemcpyHostToDevice, ws->stream) != hipSuccess)
+            return fail(MM_ERR_HIP);
+        const uint64_t cap = (e - a) < capacity ? (e - a) : capacity;
+        rc = grow(ws->d_out, ws->d_out_elems, cap ? cap : 1, sizeof(uint32_t));
+        if (rc == MM_OK && out_sk) rc = grow(ws->d_sk, ws->d_sk_elems, cap ? cap : 1, sizeof(uint32_t));
+        if (rc) return fail(rc);
+        uint64_t count = 0;
+        rc = run_device_sync(plan, ws, ws->d_in, bytes + 16, base_offset, n_bases, a, e, out_pos ? ws->d_out : nullptr,
+                             (out_sk && out_pos) ? ws->d_sk : nullptr, out_pos ? cap : 0, &count, nullptr);
+        r.count = count;
+        if (rc && rc != MM_ERR_CAPACITY) return fail(rc);
+        if (rc == MM_ERR_CAPACITY) r.rc = rc;
+        if (out_pos && count && rc == MM_OK) {
+            uint32_t fl[2] = {0, 0};
+            if (hipMemcpy(&fl[0], ws->d_out, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(&fl[1], ws->d_out + (count - 1), sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(MM_ERR_HIP);
+            r.first = fl[0];
+            r.last = fl[1];
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint64_t i = 1; i < N; ++i) th.emplace_back(phase1, i);
+        phase1(0);
+        for (std::thread &t : th) t.join();
+    }
+    for (uint64_t i = 0; i < N; ++i)
+        if (res[i].rc && res[i].rc != MM_ERR_CAPACITY) {
+            g_last_error = res[i].err;
+            return res[i].rc;
+        }
+    // ---- seam rule between consecutive shards (src/collect.rs:265-271): a shard's first position equal to the
+    // last one before it is the same minimizer seen again; syncmers have no such rule (src/syncmers.rs:166-169)
+    std::vector<uint64_t> drop(N, 0), off(N + 1, 0);
+    bool over = false;
+    {
+        bool have_last = false;
+        uint32_t last = 0;
+        for (uint64_t i = 0; i < N; ++i) {
+            if (res[i].rc == MM_ERR_CAPACITY) over = true;
+            if (res[i].count && !over && out_pos) {
+                if (plan->mode == MM_MINIMIZERS && have_last && res[i].first == last) drop[i] = 1;
+                last = res[i].last;
+                have_last = true;
+            }
+            off[i + 1] = off[i] + res[i].count - drop[i];
+        }
+    }
+    if (out_count) *out_count = off[N];
+    if (over || (out_pos && off[N] > capacity)) return MM_ERR_CAPACITY;  // (the count may miss seam drops then)
+    if (!out_pos) return MM_OK;
+    // ---- phase 2: every shard's positions to their place in the caller's buffer
+    auto phase2 = [&](uint64_t i) {
+        mm_workspace *ws = g->ws[i];
+        if (res[i].count <= drop[i]) return;
+        if (hipSetDevice(ws->device) != hipSuccess ||
+            copy_shard_out(ws, drop[i], res[i].count - drop[i], out_pos, out_sk, off[i]) != MM_OK ||
+            hipStreamSynchronize(ws->stream) != hipSuccess) {
+            res[i].rc = MM_ERR_HIP;
+            res[i].err = g_last_error;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint64_t i = 1; i < N; ++i) th.emplace_back(phase2, i);
+        phase2(0);
+        for (std::thread &t : th) t.join();
+    }
+    for (uint64_t i = 0; i < N; ++i)
+        if (res[i].rc) {
+            g_last_error = res[i].err;
+            return res[i].rc;
+        }
+    return MM_OK;
+}
+
+int mm_run_batch_sharded_host(const mm_plan_t *plan, mm_device_group_t *g, uint64_t n_seqs,
+                              const uint8_t *const *packed, const uint64_t *base_offsets, const uint64_t *n_bases,
+                              uint32_t *out_pos, uint32_t *out_sk, uint64_t capacity, uint64_t *out_offsets) {
+    if (!plan || !g || g->ws.empty() || !out_offsets) return MM_ERR_NULL;
+    if (n_seqs && (!packed || !n_bases)) return MM_ERR_NULL;
+    if (out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;
+    const uint64_t N = g->ws.size();
+    for (uint64_t s = 0; s <= n_seqs; ++s) out_offsets[s] = 0;
+    if (n_seqs == 0) return MM_OK;
+    // greedy placement, longest sequence first onto the least loaded shard (sharding.assign_contigs)
+    std::vector<uint64_t> order(n_seqs);
+    for (uint64_t s = 0; s < n_seqs; ++s) order[s] = s;
+    std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return n_bases[a] > n_bases[b]; });
+    std::vector<std::vector<uint64_t>> mine(N);
+    std::vector<uint64_t> load(N, 0);
+    for (uint64_t s : order) {
+        uint64_t best = 0;
+        for (uint64_t i = 1; i < N; ++i)
+            if (load[i] < load[best]) best = i;
+        mine[best].push_back(s);
+        load[best] += n_bases[s];
+    }
+    for (uint64_t i = 0; i < N; ++i) std::sort(mine[i].begin(), mine[i].end());
+    std::vector<ShardResult> res(N);
+    std::vector<std::vector<uint64_t>> local_offs(N);  // per shard: offsets of its sequences in its staging buffer
+    auto phase1 = [&](uint64_t i) {
+        ShardResult &r = res[i];
+        mm_workspace *ws = g->ws[i];
+        const std::vector<uint64_t> &my = mine[i];
+        if (my.empty()) return;
+        auto fail = [&](int rc) {
+            r.rc = rc;
+            r.err = g_last_error;
+        };
+        if (hipSetDevice(ws->device) != hipSuccess) return fail(MM_ERR_HIP);
+        // the shard's sequences back to back in one device buffer, each at a 16-byte boundary
+        std::vector<uint64_t> at(my.size()), nbytes(my.size());
+        uint64_t total = 0, windows = 0;
+        const uint64_t l = (uint64_t)plan->k + plan->w - 1;
+        for (size_t j = 0; j < my.size(); ++j) {
+            const uint64_t s = my[j];
+            nbytes[j] = ((base_offsets ? base_offsets[s] : 0) + n_bases[s] + 3) / 4;
+            at[j] = total;
+            total += (nbytes[j] + 16 + 15) & ~15ull;
+            windows += n_bases[s] >= l ? n_bases[s] - l + 1 : 0;
+        }
+        uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
+        int rc = grow(din, ws->d_in_bytes, total + 16, 1);
+        ws->d_in = din;
+        if (rc) return fail(rc);
+        std::vector<const void *> dptr(my.size());
+        std::vector<uint64_t> dbytes(my.size()), offs(my.size()), lens(my.size());
+        for (size_t j = 0; j < my.size(); ++j) {
+            const uint64_t s = my[j];
+            if (nbytes[j]) {
+                if (!packed[s]) return fail(MM_ERR_NULL);
+                if (hipMemcpyAsync(din + at[j], packed[s], nbytes[j], hipMemcpyHostToDevice, ws->stream) != hipSuccess)
+                    return fail(MM_ERR_HIP);
+            }
+            dptr[j] = din + at[j];
+            dbytes[j] = nbytes[j] + 16;
+            offs[j] = base_offsets ? base_offsets[s] : 0;
+            lens[j] = n_bases[s];
+        }
+        const uint64_t cap = out_pos ? (windows < capacity ? windows : capacity) : 0;
+        rc = grow(ws->d_out, ws->d_out_elems, cap ? cap : 1, sizeof(uint32_t));
+        if (rc == MM_OK && out_sk) rc = grow(ws->d_sk, ws->d_sk_elems, cap ? cap : 1, sizeof(uint32_t));
+        if (rc) return fail(rc);
+        local_offs[i].assign(my.size() + 1, 0);
+        rc = mm_run_batch_device(plan, ws, my.size(), dptr.data(), dbytes.data(), offs.data(), lens.data(),
+                                 cap ? ws->d_out : nullptr, (out_sk && cap) ? ws->d_sk : nullptr, cap,
+                                 local_offs[i].data());
+        r.count = local_offs[i][my.size()];
+        if (rc && rc != MM_ERR_CAPACITY) return fail(rc);
+        r.rc = rc;
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint64_t i = 1; i < N; ++i) th.emplace_back(phase1, i);
+        phase1(0);
+        for (std::thread &t : th) t.join();
+    }
+    bool over = false;
+    for (uint64_t i = 0; i < N; ++i) {
+        if (res[i].rc == MM_ERR_CAPACITY) over = true;
+        else if (res[i].rc) {
+            g_last_error = res[i].err;
+            return res[i].rc;
+        }
+    }
+    // counts per sequence (input order) -> offsets in the caller's buffer
+    std::vector<uint64_t> cnt(n_seqs, 0);
+    for (uint64_t i = 0; i < N; ++i)
+        for (size_t j = 0; j < mine[i].size(); ++j) cnt[mine[i][j]] = local_offs[i][j + 1] - local_offs[i][j];
+    for (uint64_t s = 0; s < n_seqs; ++s) out_offsets[s + 1] = out_offsets[s] + cnt[s];
+    if (over || (out_pos && out_offsets[n_seqs] > capacity)) return MM_ERR_CAPACITY;
+    if (!out_pos) return MM_OK;
+    auto phase2 = [&](uint64_t i) {
+        mm_workspace *ws = g->ws[i];
+        if (mine[i].empty()) return;
+        bool bad = hipSetDevice(ws->device) != hipSuccess;
+        // (runs of sequences that are neighbours in the input are neighbours in both buffers: one copy per run)
+        for (size_t j = 0; j < mine[i].size() && !bad;) {
+            size_t e = j + 1;
+            while (e < mine[i].size() && mine[i][e] == mine[i][e - 1] + 1) ++e;
+            bad = copy_shard_out(ws, local_offs[i][j], local_offs[i][e] - local_offs[i][j], out_pos, out_sk,
+                                 out_offsets[mine[i][j]]) != MM_OK;
+            j = e;
+        }
+        if (!bad) bad = hipStreamSynchronize(ws->stream) != hipSuccess;
+        if (bad) {
+            res[i].rc = MM_ERR_HIP;
+            res[i].err = g_last_error;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint64_t i = 1; i < N; ++i) th.emplace_back(phase2, i);
+        phase2(0);
+        for (std::thread &t : th) t.join();
+    }
+    for (uint64_t i = 0; i < N; ++i)
+        if (res[i].rc) {
+            g_last_error = res[i].err;
+            return res[i].rc;
+        }
     return MM_OK;
 }
 

@@ -99,6 +99,34 @@ int main() {
         for (u128 x : gv)
             if (x != allg) return 20;
     }
+    // several devices from one call (bench/src/bin/paper.rs:442-459): two workspaces on device 0
+    {
+        DeviceGroup group({0, 0});
+        if (group.size() != 2) return 21;
+        std::string big;
+        uint64_t z = 12345;
+        for (int i = 0; i < 200000; ++i) {
+            z = z * 6364136223846793005ull + 1442695040888963407ull;
+            big.push_back("ACGT"[(z >> 33) & 3]);
+        }
+        auto pb = pack(big.c_str());
+        const PackedSeq whole{pb.data(), 0, big.size()};
+        std::vector<uint32_t> one, two;
+        canonical_minimizers(21, 11).run(whole, one);
+        group.run(canonical_minimizers(21, 11), whole, two);
+        if (one.empty() || one != two) return 22;
+        // contigs: slices of the same sequence, sequence-local positions in input order
+        std::vector<PackedSeq> parts{PackedSeq{pb.data(), 0, 50000}, PackedSeq{pb.data() + 12500, 1, 70001},
+                                     PackedSeq{pb.data(), 0, 10}, PackedSeq{pb.data() + 30000, 2, 79000}};
+        std::vector<uint32_t> pos;
+        std::vector<uint64_t> offs;
+        group.run_batch(canonical_minimizers(21, 11), parts, pos, offs);
+        if (offs.size() != 5) return 23;
+        for (size_t i = 0; i < parts.size(); ++i) {
+            std::vector<uint32_t> want = canonical_minimizers(21, 11).run_once(parts[i]);
+            if (std::vector<uint32_t>(pos.begin() + offs[i], pos.begin() + offs[i + 1]) != want) return 24 + (int)i;
+        }
+    }
     printf("builder_example ok\n");
     return 0;
 }

@@ -197,3 +197,53 @@ def test_fasta_packer_refuses_fastq(sm, gpu):
     with pytest.raises(sm.MinimizerError) as e:
         sm.fasta_pack_device(b">a\nACGT\n>b\nTT\n>c\nA\n", max_records=2)
     assert e.value.code == sm.ERR["CAPACITY"] and "records" in str(e.value)
+
+
+# ------------------------------------------------------------------ several devices behind the C ABI
+def test_device_group_sharded_host(sm, oracle, gpu):
+    """mm_run_sharded_host / mm_run_batch_sharded_host (multi-GPU behind the C ABI): a group of two
+    workspaces on this GPU - and one entry per GPU when the box has more - gives the oracle's result: window
+    ranges with the exact seam, super-k-mer indices, syncmers (no seam rule), contigs placed greedily."""
+    import torch
+    ngpu = torch.cuda.device_count()
+    groups = [[0, 0], [0, 0, 0]] + ([list(range(ngpu))] if ngpu > 1 else [])
+    n = 5_000_011
+    data = oracle.gen_packed(21, n + 3)
+    for devices in groups:
+        g = sm.DeviceGroup(devices)
+        assert len(g) == len(devices)
+        for canon, k, w, mode in ((True, 21, 11, 0), (False, 21, 11, 0), (True, 15, 17, 1), (True, 31, 51, 0)):
+            b = sm.Builder(k, w, canon, mode)
+            for off in (0, 3):
+                want = oracle.run(data, n, k, w, canonical=canon, mode=mode, base_offset=off)
+                pos, _ = g.run(b, data, n, base_offset=off)
+                assert np.array_equal(pos, want), (devices, canon, k, w, mode, off)
+        # a homopolymer run across the seams: the same minimizer position on both sides of a cut
+        flat = np.zeros((n + 3) // 4, dtype=np.uint8)
+        want = oracle.run(flat, n, 21, 11, canonical=False)
+        pos, _ = g.run(sm.minimizers(21, 11), flat, n)
+        assert np.array_equal(pos, want)
+        # super-k-mer indices
+        skv = []
+        b = sm.canonical_minimizers(21, 11).super_kmers(skv)
+        want_p, want_s = oracle.run(data, n, 21, 11, canonical=True, super_kmers=True)
+        pos, sk = g.run(b, data, n)
+        assert np.array_equal(pos, want_p) and np.array_equal(sk, want_s)
+        # too small a capacity is reported, not overrun
+        with pytest.raises(sm.MinimizerError) as e:
+            g.run(sm.canonical_minimizers(21, 11), data, n, capacity=1000)
+        assert e.value.code == sm.ERR["CAPACITY"]
+        # sequences shorter than a window, empty input
+        pos, _ = g.run(sm.canonical_minimizers(21, 11), data, 20)
+        assert len(pos) == 0
+        # contigs: greedy placement, sequence-local positions in input order
+        lens = [700_001, 30, 1_200_000, 0, 450_017, 2_000_003, 90_000]
+        seqs = [oracle.gen_packed(50 + i, m + 2) for i, m in enumerate(lens)]
+        offs_in = [0, 1, 2, 0, 3, 0, 1]
+        b = sm.canonical_minimizers(21, 11)
+        pos, _, o = g.run_batch(b, seqs, lens, base_offsets=offs_in)
+        assert len(o) == len(lens) + 1
+        for i, m in enumerate(lens):
+            want = oracle.run(seqs[i], m, 21, 11, canonical=True, base_offset=offs_in[i])
+            assert np.array_equal(pos[o[i]:o[i + 1]], want), (devices, i)
+        g.close()
