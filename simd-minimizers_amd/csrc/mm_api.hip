@@ -114,6 +114,7 @@ struct mm_workspace {
     // split path (walk + expander on a second stream): dump slots, tile status, redo list, fork / join events
     mm::SplitBuffers split;
     bool no_split = false;  // the split path failed once on this workspace: fused kernel from then on
+    bool fasta_three_pass = false;  // a look-back of the one-pass FASTA packer timed out: three-pass kernels from then on
     // diagnostics: shader-clock probe on a stream of its own (mm_clock_probe_*)
     hipStream_t probe_stream = nullptr;
     unsigned long long *probe_out = nullptr;
@@ -504,6 +505,7 @@ int mm_workspace_check(mm_workspace_t *ws) {
         // tile ids from an atomic ticket; the caller repeats the runs since the last check
         ws->force_ticket = true;
         ws->no_split = true;
+        ws->fasta_three_pass = true;
         g_last_error = "a look-back scan timed out in an asynchronous run: its output is invalid";
         return MM_ERR_ORDER;
     }
@@ -1536,6 +1538,7 @@ int mm_pack_ascii_device_async(mm_workspace_t *ws, const uint8_t *d_ascii, uint6
 int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes,
                                uint8_t *d_packed, uint64_t packed_capacity_bytes, uint64_t *d_rec_base,
                                uint64_t *d_rec_text_pos, uint64_t max_records, uint64_t *d_counts) {
+    // (the synchronous wrapper below checks the error word itself; a direct asynchronous caller asks mm_workspace_check)
     if (!ws || !d_counts || !d_rec_base) return MM_ERR_NULL;
     if (n_bytes >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     if (reinterpret_cast<uintptr_t>(d_packed) % 4 != 0) return MM_ERR_NULL;
@@ -1550,10 +1553,19 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
     const int r = grow(sp, ws->scratch_bytes, mm::fasta_scratch_bytes(n_bytes), 1);
     ws->scratch = sp;
     if (r) return r;
+    // MM_FASTA_ONEPASS=1: the text is read once (decoupled look-backs between the chunks) instead of three times.
+    // Measured SLOWER on MI355X (round 3, 1 GiB of text: 2.07 ms against 1.66 ms): the packer is bound by its
+    // per-iteration workgroup barriers and staging, not by the two extra reads of the text, and the look-backs
+    // serialise what three independent grids overlap - so the three passes stay the default.  A look-back
+    // time-out of the one-pass kernel sends the workspace back to the three-pass kernels.
+    const char *env_one = getenv("MM_FASTA_ONEPASS");
+    const bool one_pass = env_one && env_one[0] == '1' && !ws->fasta_three_pass;
+    if (one_pass) MM_HIP(hipMemsetAsync(ws->total + 1, 0, sizeof(unsigned long long), ws->stream));
     if (mm::launch_fasta_pack(d_text, n_bytes, d_packed, packed_capacity_bytes & ~3ull,
                               reinterpret_cast<unsigned long long *>(d_rec_base),
                               reinterpret_cast<unsigned long long *>(d_rec_text_pos), max_records,
-                              reinterpret_cast<unsigned long long *>(d_counts), ws->scratch, ws->stream))
+                              reinterpret_cast<unsigned long long *>(d_counts), ws->scratch, ws->stream, one_pass,
+                              reinterpret_cast<uint32_t *>(ws->total + 1)))
         return hip_fail(hipGetLastError(), "fasta_pack");
     return MM_OK;
 }
@@ -1576,11 +1588,19 @@ int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_b
             return MM_ERR_FORMAT;
         }
     }
-    const int r = mm_fasta_pack_device_async(ws, d_text, n_bytes, d_packed, packed_capacity_bytes, d_rec_base,
-                                             d_rec_text_pos, max_records, d_counts);
-    if (r) return r;
-    MM_HIP(hipMemcpyAsync(out_counts, d_counts, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ws->stream));
-    MM_HIP(hipStreamSynchronize(ws->stream));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int r = mm_fasta_pack_device_async(ws, d_text, n_bytes, d_packed, packed_capacity_bytes, d_rec_base,
+                                                 d_rec_text_pos, max_records, d_counts);
+        if (r) return r;
+        MM_HIP(hipMemcpyAsync(out_counts, d_counts, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ws->stream));
+        MM_HIP(hipMemcpyAsync(ws->h_total + 1, ws->total + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                              ws->stream));
+        MM_HIP(hipStreamSynchronize(ws->stream));
+        if (n_bytes == 0 || ws->fasta_three_pass || (uint32_t)ws->h_total[1] == 0) break;
+        // a look-back of the one-pass packer timed out (chunks not dispatched in order): once more, three passes
+        ws->fasta_three_pass = true;
+        if (!ws->async_unchecked) MM_HIP(hipMemsetAsync(ws->total + 2, 0, sizeof(unsigned long long), ws->stream));
+    }
     if (out_counts[0] > (packed_capacity_bytes & ~3ull) * 4 || out_counts[1] > max_records) return MM_ERR_CAPACITY;
     return MM_OK;
 }

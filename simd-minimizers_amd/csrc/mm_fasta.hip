@@ -435,15 +435,238 @@ __global__ __launch_bounds__(kBlockThreads) void fasta_walk_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------- one pass (round 3)
+// The same compaction with the text read ONCE: a chunk keeps its 32 KB in registers and resolves what it needs
+// from its predecessors through decoupled look-backs (status words as in mm_common.h, one word per chunk and
+// quantity, relaxed agent-scope accesses):
+//   A  the line / record context at the chunk's start, which is only two bits - "inside a header line" and "a
+//      record has started" - and context-free to publish: a chunk that holds a newline or a record start decides
+//      the first bit for its successors by itself (kind 1 / 2), one that holds neither is transparent (kind 0);
+//   B, R  the number of sequence bytes and of record starts before the chunk (sums), published once the context
+//      is known; wave 0 looks back over B while wave 1 looks back over R.
+// Chunk ids are blockIdx.x (in-order dispatch, as the fused kernel assumes); every spin is bounded and a time-out
+// raises the workspace's error word, upon which the host repeats the call with the three-pass kernels above.
+constexpr unsigned long long kCtxHeader = 2ull, kCtxPlain = 1ull, kCtxRec = 4ull;  // payload bits of an A word
+
+// exclusive context of chunk `bid`: bit 0 = inside a header line, bit 1 = a record has started
+__device__ __forceinline__ uint32_t lookback_context(unsigned long long *status, uint32_t bid, uint32_t kind, uint32_t has_rec,
+                                                     uint32_t *error) {
+    const int lane = threadIdx.x & (kWave - 1);
+    uint32_t h = 0, started = 0;  // before the text: no header line, no record
+    bool have_h = false;
+    if (bid != 0) {
+        if (lane == 0) st_status(&status[bid], kFlagAgg | (kind & 3u) | (has_rec ? kCtxRec : 0ull));
+        long long j = (long long)bid - 1;
+        while (true) {
+            const long long idx = j - lane;
+            unsigned long long s = idx >= 0 ? ld_status(&status[idx]) : (kFlagIncl | kCtxPlain);
+            for (uint32_t spins = 0; (s >> 62) == 0; ++spins) {
+                if (spins > kMaxLookbackSpins) {
+                    flag_error(error, 1u);
+                    s = kFlagIncl | kCtxPlain;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                s = ld_status(&status[idx]);
+            }
+            const unsigned long long incl_mask = __ballot((s >> 62) == 2);
+            const int first = incl_mask ? __builtin_ctzll(incl_mask) : kWave;  // lanes 0 .. first count (nearest first)
+            const bool mine = lane <= first;
+            const unsigned long long kmask = __ballot(mine && (s & 3ull) != 0ull);
+            const unsigned long long rmask = __ballot(mine && (s & kCtxRec) != 0ull);
+            if (!have_h && kmask) {
+                const int src = __builtin_ctzll(kmask);
+                h = ((uint32_t)__shfl((int)(uint32_t)(s & 3ull), src, kWave) == (uint32_t)kCtxHeader) ? 1u : 0u;
+                have_h = true;
+            }
+            if (rmask) started = 1;
+            if (incl_mask) break;
+            j -= kWave;
+        }
+    }
+    // inclusive state of this chunk (an inclusive word always carries a decided kind)
+    const uint32_t h_out = kind ? (kind == (uint32_t)kCtxHeader ? 1u : 0u) : h;
+    if (lane == 0)
+        st_status(&status[bid], kFlagIncl | (h_out ? kCtxHeader : kCtxPlain) | ((started | has_rec) ? kCtxRec : 0ull));
+    return h | (started << 1);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void fasta_onepass_kernel(
+    const uint8_t *__restrict__ text, uint64_t n, unsigned long long *__restrict__ st_ctx,
+    unsigned long long *__restrict__ st_bases, unsigned long long *__restrict__ st_recs, uint32_t *__restrict__ out32,
+    uint64_t out_dwords, unsigned long long *__restrict__ rec_base, unsigned long long *__restrict__ rec_pos,
+    uint64_t max_records, unsigned long long *__restrict__ counts, uint32_t n_chunks, uint32_t *error) {
+    __shared__ uint32_t s[2 * kWavesPerBlock];
+    __shared__ uint32_t s_stage[2][kIterBytes / 16 + 2];
+    __shared__ uint32_t s_ctx;
+    __shared__ unsigned long long s_off[2];
+    const uint32_t tid = threadIdx.x, bid = blockIdx.x;
+    const int lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint64_t c0 = (uint64_t)bid * kChunkBytes;
+    for (uint32_t i = tid; i < kIterBytes / 16 + 2; i += kBlockThreads) s_stage[0][i] = s_stage[1][i] = 0;
+    Raw raw[kIters];
+#pragma unroll
+    for (uint32_t it = 0; it < kIters; ++it) raw[it] = load_raw(text, n, c0 + (uint64_t)it * kIterBytes + 16ull * tid);
+    // ---- what the chunk says about the context of its successors (context-free)
+    uint32_t mnl = 0, mrec = 0;  // last newline / record start of the thread, position + 1 relative to the chunk
+#pragma unroll
+    for (uint32_t it = 0; it < kIters; ++it) {
+        const uint32_t rel = it * kIterBytes + 16u * tid;
+        const Piece p = make_piece(raw[it], text, n, c0 + rel);
+        uint32_t ls, rs;
+        starts(p, ls, rs);
+        if (p.nl) mnl = rel + top_bit_pos1(p.nl);
+        if (rs) mrec = rel + top_bit_pos1(rs);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mnl = max(mnl, (uint32_t)__shfl_xor((int)mnl, d, kWave));
+        mrec = max(mrec, (uint32_t)__shfl_xor((int)mrec, d, kWave));
+    }
+    if (lane == 0) {
+        s[wave] = mnl;
+        s[kWavesPerBlock + wave] = mrec;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t a = 0, b = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) {
+            a = max(a, s[w]);
+            b = max(b, s[kWavesPerBlock + w]);
+        }
+        const uint32_t kind = (b > a) ? (uint32_t)kCtxHeader : (a ? (uint32_t)kCtxPlain : 0u);
+        const uint32_t ctx = lookback_context(st_ctx, bid, kind, b != 0u, error);
+        if (lane == 0) s_ctx = ctx;
+    }
+    __syncthreads();
+    const uint32_t ctx = s_ctx;
+    // the context as K2 / K3 take it: positions + 1 of the last newline / record start before the chunk; only their
+    // order and whether a record exists matter
+    const unsigned long long ln0 = (ctx & 2u) ? 1ull : 0ull, lr0 = (ctx & 2u) ? ((ctx & 1u) ? 2ull : 1ull) : 0ull;
+    // (started, in header: lr0 = 2 > ln0 = 1; started, not in header: lr0 = 1 = ln0, i.e. lr0 > ln0 is false and
+    // lr0 > 0; not started: both 0)
+    // ---- counts of the chunk with its context
+    unsigned long long ln_run = ln0, lr_run = lr0;
+    uint32_t my_bases = 0, my_recs = 0;
+#pragma unroll
+    for (uint32_t it = 0; it < kIters; ++it) {
+        const uint64_t i0 = c0 + (uint64_t)it * kIterBytes;
+        if (i0 >= n) break;  // (uniform)
+        const Piece p = make_piece(raw[it], text, n, i0 + 16ull * tid);
+        uint32_t ls, rs;
+        starts(p, ls, rs);
+        const uint32_t tnl = p.nl ? 16u * tid + top_bit_pos1(p.nl) : 0u;
+        const uint32_t trec = rs ? 16u * tid + top_bit_pos1(rs) : 0u;
+        uint32_t xnl, xrec, tot_nl, tot_rec;
+        block_prev_marks(tnl, trec, s, xnl, xrec, tot_nl, tot_rec);
+        // (marks inside the chunk are later than any before it: offset them past the two context values)
+        const unsigned long long ln = xnl ? 3ull + it * kIterBytes + xnl : ln_run, lr = xrec ? 3ull + it * kIterBytes + xrec : lr_run;
+        my_bases += (uint32_t)__builtin_popcount(base_mask(p, ls, rs, ln, lr));
+        my_recs += (uint32_t)__builtin_popcount(rs);
+        ln_run = tot_nl ? 3ull + it * kIterBytes + tot_nl : ln_run;
+        lr_run = tot_rec ? 3ull + it * kIterBytes + tot_rec : lr_run;
+    }
+    uint32_t tot;
+    block_sum_excl((my_recs << 16) | my_bases, s, tot);  // (at most 32768 bases and 16384 record starts per chunk)
+    const uint32_t chunk_bases = tot & 0xffffu, chunk_recs = tot >> 16;
+    // ---- output offsets: wave 0 sums the bases, wave 1 the records of all earlier chunks
+    if (wave == 0) {
+        const unsigned long long ex = lookback_exclusive(st_bases, bid, chunk_bases, 0ull, error);
+        if (lane == 0) s_off[0] = ex;
+    } else if (wave == 1) {
+        const unsigned long long ex = lookback_exclusive(st_recs, bid, chunk_recs, 0ull, error);
+        if (lane == 0) s_off[1] = ex;
+    }
+    __syncthreads();
+    unsigned long long bases_run = s_off[0], recs_run = s_off[1];
+    // ---- pack (fasta_walk_kernel<true>'s loop)
+    ln_run = ln0;
+    lr_run = lr0;
+#pragma unroll
+    for (uint32_t it = 0; it < kIters; ++it) {
+        const uint64_t i0 = c0 + (uint64_t)it * kIterBytes;
+        if (i0 >= n) break;  // (uniform)
+        const uint64_t o = i0 + 16ull * tid;
+        const Piece p = make_piece(raw[it], text, n, o);
+        uint32_t ls, rs;
+        starts(p, ls, rs);
+        const uint32_t tnl = p.nl ? 16u * tid + top_bit_pos1(p.nl) : 0u;
+        const uint32_t trec = rs ? 16u * tid + top_bit_pos1(rs) : 0u;
+        uint32_t xnl, xrec, tot_nl, tot_rec;
+        block_prev_marks(tnl, trec, s, xnl, xrec, tot_nl, tot_rec);
+        const unsigned long long ln = xnl ? 3ull + it * kIterBytes + xnl : ln_run, lr = xrec ? 3ull + it * kIterBytes + xrec : lr_run;
+        const uint32_t bm = base_mask(p, ls, rs, ln, lr);
+        const uint32_t nb = (uint32_t)__builtin_popcount(bm), nr = (uint32_t)__builtin_popcount(rs);
+        uint32_t tot2;
+        const uint32_t ex = block_sum_excl((nr << 16) | nb, s, tot2);
+        const uint32_t xb = ex & 0xffffu, xr = ex >> 16, tot_b = tot2 & 0xffffu, tot_r = tot2 >> 16;
+        const unsigned long long g0 = bases_run + xb;  // global index of this thread's first base
+        for (uint32_t m = rs, k = 0; m; m &= m - 1u, ++k) {
+            const uint32_t j = (uint32_t)__builtin_ctz(m);
+            const unsigned long long r = recs_run + xr + k;
+            if (r < max_records) {
+                rec_base[r] = g0 + (uint32_t)__builtin_popcount(bm & ((1u << j) - 1u));
+                if (rec_pos) rec_pos[r] = o + j;
+            }
+        }
+        uint32_t v = 0;
+        if (bm) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t t = (p.w[g] >> 1) & 0x03030303u;
+                v |= ((t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xffu) << (8 * g);
+            }
+            for (uint32_t holes = ~bm & 0xffffu; holes;) {
+                const uint32_t j = 31u - (uint32_t)__builtin_clz(holes);
+                holes &= ~(1u << j);
+                const uint32_t low = (1u << (2u * j)) - 1u;
+                v = (v & low) | ((v >> 2) & ~low);
+            }
+        }
+        uint32_t *stage = s_stage[it & 1u];
+        const unsigned long long G0 = bases_run, G0a = G0 & ~15ull;
+        const uint32_t n_stage = (uint32_t)((G0 - G0a + tot_b + 15ull) / 16ull);
+        if (nb) {
+            const uint32_t rel = (uint32_t)(g0 - G0a), d = rel >> 4, bsh = 2u * (rel & 15u);
+            atomicOr(&stage[d], v << bsh);
+            if (bsh && bsh + 2u * nb > 32u) atomicOr(&stage[d + 1], v >> (32u - bsh));
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < n_stage; i += kBlockThreads) {
+            const unsigned long long dw = G0a / 16ull + i;
+            const uint32_t val = stage[i];
+            stage[i] = 0;
+            if (dw < out_dwords) {
+                if (i == 0 || i + 1 == n_stage) {
+                    if (val) atomicOr(&out32[dw], val);
+                } else {
+                    out32[dw] = val;
+                }
+            }
+        }
+        ln_run = tot_nl ? 3ull + it * kIterBytes + tot_nl : ln_run;
+        lr_run = tot_rec ? 3ull + it * kIterBytes + tot_rec : lr_run;
+        bases_run += tot_b;
+        recs_run += tot_r;
+    }
+    if (tid == 0 && bid == n_chunks - 1) {
+        counts[0] = bases_run;
+        counts[1] = recs_run;
+        if (recs_run <= max_records) rec_base[recs_run] = bases_run;
+    }
+}
+
 }  // namespace
 
 uint64_t fasta_chunks(uint64_t n_bytes) { return (n_bytes + kChunkBytes - 1) / kChunkBytes; }
-// scratch: six arrays of chunks + 1 64-bit words
+// scratch: six arrays of chunks + 1 64-bit words (three-pass kernels; the one-pass kernel uses three of them as
+// its status words)
 uint64_t fasta_scratch_bytes(uint64_t n_bytes) { return 6 * (fasta_chunks(n_bytes) + 1) * sizeof(unsigned long long); }
 
 int launch_fasta_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed, uint64_t packed_capacity_bytes,
                       unsigned long long *d_rec_base, unsigned long long *d_rec_pos, uint64_t max_records,
-                      unsigned long long *d_counts, void *scratch, hipStream_t stream) {
+                      unsigned long long *d_counts, void *scratch, hipStream_t stream, bool one_pass, uint32_t *d_error) {
     const uint64_t chunks = fasta_chunks(n_bytes);
     if (chunks == 0 || chunks >= (1ull << 31)) return -1;
     unsigned long long *a = reinterpret_cast<unsigned long long *>(scratch);
@@ -453,6 +676,13 @@ int launch_fasta_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed
     // the packed bytes are OR-ed together where chunks meet: clear what the text can fill at most
     const uint64_t clear = packed_capacity_bytes < (n_bytes + 3) / 4 + 8 ? packed_capacity_bytes : (n_bytes + 3) / 4 + 8;
     if (clear && hipMemsetAsync(d_packed, 0, clear, stream) != hipSuccess) return -1;
+    if (one_pass) {
+        if (hipMemsetAsync(a, 0, 3 * (chunks + 1) * sizeof(unsigned long long), stream) != hipSuccess) return -1;
+        hipLaunchKernelGGL(fasta_onepass_kernel, dim3((uint32_t)chunks), dim3(kBlockThreads), 0, stream, d_text, n_bytes,
+                           last_nl, last_rec, ctx_nl, reinterpret_cast<uint32_t *>(d_packed), out_dwords, d_rec_base,
+                           d_rec_pos, max_records, d_counts, (uint32_t)chunks, d_error);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     hipLaunchKernelGGL(fasta_marks_kernel, dim3((uint32_t)chunks), dim3(kBlockThreads), 0, stream, d_text, n_bytes,
                        last_nl, last_rec);
     hipLaunchKernelGGL(fasta_scan2_kernel<MaxOp>, dim3(1), dim3(kScanThreads), 0, stream, last_nl, last_rec, chunks,

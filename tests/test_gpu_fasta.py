@@ -8,6 +8,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["three-pass", "one-pass"])
+def packer_flavour(request, monkeypatch):
+    """Every test runs with the default three-pass kernels and with the one-pass kernel (MM_FASTA_ONEPASS=1: the
+    text read once, decoupled look-backs between the chunks; measured slower, kept as an A/B - DESIGN.md 4.3a)."""
+    monkeypatch.setenv("MM_FASTA_ONEPASS", "1" if request.param == "one-pass" else "0")
+
+
 def expect(oracle, text):
     recs = oracle.fasta_records(text)
     seq = b"".join(s for _, _, s in recs)
