@@ -40,6 +40,16 @@
 #ifndef MM_PREFETCH_BLOCKS
 #define MM_PREFETCH_BLOCKS 2
 #endif
+// Stage-incremental timing (tools/gpu_stages.py, mirrors bench/src/bin/paper.rs:231-300; WRONG RESULTS by design, only
+// through MM_JIT_DEFS): -DMM_STAGE=n keeps the walk up to stage n and folds what it computed into a sink word so that
+// nothing before it is dead code: 1 sequence loads + 2-bit decode (table addresses), 2 + table look-ups and hash
+// roll, 3 + keys and the leftmost sliding minimum, 4 + rightmost minimum and strand vote (canonical walks).  The
+// emit (5) and phase 2 (6) are timed with the product kernel and MM_DEBUG=3 / 0.
+#ifdef MM_STAGE
+#define MM_STAGE_GE(n) (MM_STAGE >= (n))
+#else
+#define MM_STAGE_GE(n) 1
+#endif
 
 // 8-byte words between the look-back status words of consecutive tiles.  One word per 64 bytes: tiles that
 // finish at about the same time publish and poll neighbouring words, and with the words packed 8 bytes apart
@@ -171,6 +181,54 @@ constexpr bool kTwoBodies = W <= 12;
 template <int W>
 constexpr int kSkShift = W < 2 ? 1 : W < 4 ? 2 : W < 8 ? 3 : W < 16 ? 4 : W < 32 ? 5 : W < 64 ? 6 : W < 128 ? 7 : 8;
 
+// Wide sequence loads (round 3).  The walk reads its bases through per-lane loads: lanes sit S / 4 bytes apart, so ONE
+// wave-level load costs the CU's vector memory pipeline about one cycle per cache line it touches whatever its width
+// (tools/ubench/lane_load_rate.hip: 29 clk for 64 lanes 60 bytes apart, 8 or 16 bytes each; 110 clk at the 370 bytes
+// of k=31 w=51), and that pipeline - not the VALU - set the pace of the forward walk (decode alone 0.71 ms of a 0.95
+// ms walk; with every lane of a wave reading the same line the full forward kernel ran 1.27 -> 1.04 ms, k=31 w=51
+// 1.87 -> 1.68: tools/gpu_loadsame.py).  With 8-byte loads every W-block re-fetched mostly bytes it already had
+// (W = 11 consumes 2.75 bytes per block and stream).  Now a lane loads kWideDwords<W> (4 or 5) DWORD-ALIGNED dwords
+// once per GROUP of kWideGroup<W> blocks (loads at odd byte offsets split per dword and cost 2-4 x: same ubench) and
+// shifts the buffer down by the byte part of its position with v_alignbyte when the group starts.  The views of the
+// group's blocks then begin at bit s + 2 * W * k + 32 * g of the buffer with s = 2 * (pos & 3) <= 6, so the dword pair
+// a view comes from is a compile-time function of (k, g) as long as (2 * W * k) % 32 <= 24 and the view ends inside
+// the 32 * dwords - 24 bits that are valid for every lane - which bounds the group.  W = 11: one load per stream and
+// 4 blocks instead of 4; W = 51: two loads per block and stream instead of four.
+// 0 blocks = the window size keeps the per-block 8-byte loads (W >= 64, W a multiple of 16, unlucky phases).
+#ifndef MM_WIDE_LOADS
+#define MM_WIDE_LOADS 1
+#endif
+constexpr int wide_group_blocks_nd(int W, int nd) {
+    if (!MM_WIDE_LOADS || W % 16 == 0) return 0;
+    const int nsub = (W + 15) / 16, valid = 32 * nd - 24;
+    int m = 0;
+    for (; m < 8; ++m) {
+        bool ok = true;
+        for (int g = 0; g < nsub; ++g) {
+            const int off = 2 * W * m + 32 * g, low = off % 32;
+            const int bases = W - 16 * g < 16 ? W - 16 * g : 16;  // bases this view has to hold
+            if (low > 24 || off + 6 + 2 * bases > valid) ok = false;
+        }
+        if (!ok) break;
+    }
+    return m;
+}
+// loads per block and stream: 1 / blocks with four dwords, 2 / blocks with five (a 16-byte and a 4-byte load)
+constexpr int wide_dwords(int W) {
+    const int m4 = wide_group_blocks_nd(W, 4), m5 = wide_group_blocks_nd(W, 5);
+    return (m4 > 0 && 2 * m4 >= m5) ? 4 : 5;  // (cost 1 / m4 against 2 / m5)
+}
+constexpr int wide_group_blocks(int W) { return wide_group_blocks_nd(W, wide_dwords(W)); }
+template <int W>
+constexpr int kWideGroup = wide_group_blocks(W);
+template <int W>
+constexpr int kWideDwords = wide_dwords(W);
+
+template <int N>
+struct IntTag {
+    static constexpr int value = N;
+};
+
 template <bool B>
 struct BoolTag {
     static constexpr bool value = B;
@@ -237,7 +295,11 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // the same in two steps, for loads issued two W-blocks ahead of their use
     using RawView = decltype(__builtin_amdgcn_raw_buffer_load_b64(rsrc, 0, 0, 0));
     auto raw = [&](int32_t pos) -> RawView {
+#ifdef MM_EXP_LOADSAME  // timing experiment (wrong results): every lane of the wave reads the same cache line
+        return __builtin_amdgcn_raw_buffer_load_b64(rsrc, (((uint32_t)pos >> 4) << 2) & 0x78u, 0, 0);
+#else
         return __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((uint32_t)pos >> 4) << 2, 0, 0);
+#endif
     };
     auto aligned = [&](const RawView &d, int32_t pos) -> uint32_t {
         return __builtin_amdgcn_alignbit(d[1], d[0], 2u * ((uint32_t)pos & 15u));
@@ -297,6 +359,44 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     };
     constexpr int PFD = MM_PREFETCH_BLOCKS;  // global loads run PFD W-blocks ahead of their use
     RawView qa[PFD - 1][NSUB], qr[PFD - 1][NSUB], q2[PFD - 1][NSUB];  // raw dwords of blocks b+2 .. b+PFD
+    // wide loads (kWideGroup): ND dwords per lane, stream and group of MG blocks; Wa / Wr[0] serve the group whose
+    // views are being made, Wa / Wr[1] are in flight (one group ahead)
+    constexpr int MG = kWideGroup<W>;
+    constexpr int ND = kWideDwords<W>;
+    struct WideBuf {
+        uint32_t q[5];
+        uint32_t sh;  // 2 * (first base & 15): bit of the first base in q[0]
+    };
+    WideBuf Wa[2], Wr[2];  // [0] working buffer of the current group, [1] landing buffer of the next one
+    uint32_t gp_in = 0, gp_out = 0;  // first base (tile-relative) of the next group to load
+    auto wide_load = [&](uint32_t gpos, WideBuf &w) {
+        const uint32_t off = (gpos >> 4) << 2;
+        w.sh = (gpos << 1) & 30u;
+        typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
+        const u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        w.q[0] = v.x;
+        w.q[1] = v.y;
+        w.q[2] = v.z;
+        w.q[3] = v.w;
+        w.q[4] = ND == 5 ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 16, 0) : 0u;
+    };
+    // the buffer that becomes current: shifted down by the byte part of the lane's position; returns the bit part
+    auto wide_normalise = [&](WideBuf &dst, const WideBuf &w) -> uint32_t {
+        const uint32_t a = w.sh >> 3;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+            dst.q[i] = __builtin_amdgcn_alignbyte(i + 1 < ND ? w.q[i + 1 < ND ? i + 1 : i] : 0u, w.q[i], a);
+        return w.sh & 6u;
+    };
+    // views of block k of a group (k compile-time): dword pair and shift as derived above
+    auto wide_views = [&](const WideBuf &w, uint32_t sh, auto ktag, uint32_t (&v)[NSUB]) {
+        constexpr int K = decltype(ktag)::value;
+#pragma unroll
+        for (int g = 0; g < NSUB; ++g) {
+            const int p = (2 * W * K + 32 * g) / 32;
+            v[g] = __builtin_amdgcn_alignbit(p + 1 < ND ? w.q[p + 1 < ND ? p + 1 : 0] : 0u, w.q[p < ND ? p : 0], sh);
+        }
+    };
 #pragma unroll
     for (int g = 0; g < NSUB; ++g) {
         va[g] = view(pos_in + 16 * g);
@@ -331,14 +431,24 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         // ... and the raw dwords of block 2: global loads run two W-blocks ahead of their use, so
         // that a burst of copy-out stores of a neighbouring workgroup in the CU's memory pipeline
         // does not stall the walk
+        if (MG == 0) {
 #pragma unroll
-        for (int d = 0; d < PFD - 1; ++d)
+            for (int d = 0; d < PFD - 1; ++d)
 #pragma unroll
-            for (int g = 0; g < NSUB; ++g) {
-                qa[d][g] = raw(pos_in + (d + 1) * W + 16 * g);
-                qr[d][g] = raw(pos_out + (d + 1) * W + 16 * g);
-                if (kV2Load) q2[d][g] = raw(pb + 1 + (d + 1) * W + 16 * g);
-            }
+                for (int g = 0; g < NSUB; ++g) {
+                    qa[d][g] = raw(pos_in + (d + 1) * W + 16 * g);
+                    qr[d][g] = raw(pos_out + (d + 1) * W + 16 * g);
+                    if (kV2Load) q2[d][g] = raw(pb + 1 + (d + 1) * W + 16 * g);
+                }
+        } else {
+            // wide loads: group 0 = blocks 2 .. MG + 1 (the views of block 1 were loaded above)
+            gp_in = (uint32_t)(pos_in + W);
+            gp_out = (uint32_t)(pos_out + W);
+            wide_load(gp_in, Wa[1]);
+            wide_load(gp_out, Wr[1]);
+            gp_in += (uint32_t)(MG * W);
+            gp_out += (uint32_t)(MG * W);
+        }
 #pragma unroll
         for (int j = 0; j < W; ++j) {
             const uint32_t h = HASH_RC ? fw + rc : fw;
@@ -414,6 +524,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     uint32_t lp32 = list0 + ctx.list_used * kStride;
     const uint32_t lp_end = list0 + ctx.list_bytes;
     uint32_t dropped = 0;              // entries that did not fit the list
+    uint32_t sink = 0;                 // (MM_STAGE timing builds: keeps the stages alive)
+    (void)sink;
     uint32_t valreg = 0;
     (void)valreg;
     uint32_t stride_v;  // list stride in a VGPR: v_add with two VGPR sources issues at full rate
@@ -430,6 +542,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     uint32_t sh_in = 2u * (uint32_t)pos_in, sh_out = 2u * (uint32_t)pos_out;
     uint32_t pl_in = (uint32_t)pos_in + (uint32_t)((PFD - 1) * W), pl_out = (uint32_t)pos_out + (uint32_t)((PFD - 1) * W);
 #define MM_BUMP(x, c) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "n"(c))
+    uint32_t kn = 0;  // wide loads: index of block b + 1 within its group (wave-uniform)
     for (uint32_t b = 1; b <= nblk; ++b) {
         uint32_t me[NSUB], mo[NSUB], tgw[NSUB];
 #pragma unroll
@@ -458,8 +571,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         pos_r2 += W;
         MM_BUMP(sh_in, 2 * W);
         MM_BUMP(sh_out, 2 * W);
-        MM_BUMP(pl_in, W);
-        MM_BUMP(pl_out, W);
+        if (MG == 0) {
+            MM_BUMP(pl_in, W);
+            MM_BUMP(pl_out, W);
+        }
         if (CANON && !kV2Load) {  // the next block's strand view, before vr moves on
             uint32_t t2[NSUB];
 #pragma unroll
@@ -472,6 +587,39 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 asm volatile("" : "+v"(v2[g]));
             }
         }
+        if (MG != 0) {
+            // wide loads: block b + 1 is block kn of its group; a new group takes the next buffer and starts the load
+            // of the group after it (a harmless over-read after the last block)
+            if (kn == 0) {
+                // (the landing buffer [1] is shifted into the working buffer [0]; then it takes the next load)
+                sh_in = wide_normalise(Wa[0], Wa[1]);
+                sh_out = wide_normalise(Wr[0], Wr[1]);
+                wide_load(gp_in, Wa[1]);
+                wide_load(gp_out, Wr[1]);
+                MM_BUMP(gp_in, MG * W);
+                MM_BUMP(gp_out, MG * W);
+            }
+            switch (kn) {
+#define MM_WIDE_CASE(K)                                                   \
+    case K:                                                               \
+        if (K < (MG ? MG : 1)) {                                          \
+            wide_views(Wa[0], sh_in, IntTag<(K < (MG ? MG : 1) ? K : 0)>{}, va); \
+            wide_views(Wr[0], sh_out, IntTag<(K < (MG ? MG : 1) ? K : 0)>{}, vr); \
+        }                                                                 \
+        break;
+                MM_WIDE_CASE(0)
+                MM_WIDE_CASE(1)
+                MM_WIDE_CASE(2)
+                MM_WIDE_CASE(3)
+                MM_WIDE_CASE(4)
+                MM_WIDE_CASE(5)
+                MM_WIDE_CASE(6)
+                MM_WIDE_CASE(7)
+#undef MM_WIDE_CASE
+                default: break;
+            }
+            kn = (kn + 1 == (uint32_t)(MG ? MG : 1)) ? 0u : kn + 1u;
+        } else
         // views of the next block from the dwords loaded one block ago; issue the loads of the
         // block after it (a harmless over-read after the last block)
 #pragma unroll
@@ -526,13 +674,16 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         // (round 2, 3.1 Gbp, against 12 steps ahead: w = 25 +4 %, 31 +5 %, and together with the tighter
         // register bounds below w = 33 +11 %, 37 +19 %, 51 +18 %; tools/gpu_jit_w.py).  Smaller windows
         // and forward walks are indifferent to it.
-        constexpr int PF = W < 12 ? W : (CANON && W >= 19 ? (W >= 48 ? 1 : 2) : 12);
+        // (canonical walks over small windows: 4 steps ahead since round 3 - the wide loads need the registers, and
+        // the depth was measured indifferent there: w = 11 1.786 ms at 11 steps, 1.791 at 4)
+        constexpr int PF = (CANON && MG != 0 && W < 19) ? 4 : (W < 12 ? W : (CANON && W >= 19 ? (W >= 48 ? 1 : 2) : 12));
 #endif
         uint2 tq[W];
         auto lookup = [&](int j) -> uint2 {
             const int jj = j & 15, g = j >> 4, m = jj >> 1;
             const uint32_t mw = (jj & 1) ? mo[g] : me[g];
             const uint32_t a8 = (m == 0 ? (mw << 3) : (mw >> (4 * m - 3))) & 0x78u;
+            if (!MM_STAGE_GE(2)) return uint2{a8, a8};
             return *reinterpret_cast<const uint2 *>(tabb + a8);
         };
 #pragma unroll
@@ -546,6 +697,19 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             const uint32_t e = e0 + (uint32_t)j;  // uniform
             if (j + PF < W) tq[j + PF] = lookup(j + PF);
             const uint32_t h = HASH_RC ? fw + rc : fw;
+#ifdef MM_STAGE
+            if (!MM_STAGE_GE(3)) {  // timing build: stages 1 / 2 end here
+                const uint2 t0 = tq[j];
+                if (MM_STAGE_GE(2)) {
+                    fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t0.x;
+                    if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t0.y;
+                    sink ^= h;
+                } else {
+                    sink += t0.x;
+                }
+                continue;
+            }
+#endif
             const uint32_t kl = and_or3(h, kmask, e);
             // prefix minimum over the block so far and the window minimum; odd steps fold the
             // previous key in with one v_min3 (3 ops per 2 steps and side instead of 4)
@@ -560,7 +724,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 sel = (j + 1 < W) ? min(pl, ring_l[(j + 1 < W) ? j + 1 : 0]) : pl;
             }
             ring_l[j] = kl;
-            if (CANON) {
+            if (CANON && MM_STAGE_GE(4)) {
                 const uint32_t kr = kl ^ kmask;
                 uint32_t selr;
                 if (j == 0) {
@@ -577,6 +741,16 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             }
             // window i = e - W starts at element i + 1
             const uint32_t i = e - (uint32_t)W;  // uniform
+#ifdef MM_STAGE
+            if (!MM_STAGE_GE(5)) {  // timing build: stages 3 / 4 end here (no emit)
+                sink ^= sel;
+                const uint2 t0 = tq[j];
+                fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t0.x;
+                if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t0.y;
+                if (CANON && MM_STAGE_GE(4)) dn += __builtin_amdgcn_sbfe((int)tgw[j >> 4], 2 * (j & 15), 2);
+                continue;
+            }
+#endif
             if (FE) {
                 // Common path: compare, and under the resulting exec mask append the 16-bit value
                 // to the lane's list and advance its slot pointer (2 VALU + 2 SALU + 1 LDS).
@@ -737,12 +911,21 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         } else {
             steps(BoolTag<false>{});
         }
+        if (MM_STAGE_GE(3)) {
 #pragma unroll
-        for (int j = W - 2; j >= 0; --j) {
-            ring_l[j] = min(ring_l[j], ring_l[j + 1]);
-            if (CANON) ring_r[j] = max(ring_r[j], ring_r[j + 1]);
+            for (int j = W - 2; j >= 0; --j) {
+                ring_l[j] = min(ring_l[j], ring_l[j + 1]);
+                if (CANON && MM_STAGE_GE(4)) ring_r[j] = max(ring_r[j], ring_r[j + 1]);
+            }
         }
     }
+#ifdef MM_STAGE
+    if (!MM_STAGE_GE(5)) {  // keep the sink alive: one list slot per lane
+        if (!DIRECT) *reinterpret_cast<volatile uint8_t *>(ctx.list) = (uint8_t)(sink ^ (sink >> 8) ^ (sink >> 16) ^ (sink >> 24));
+        overflowed = false;
+        return 0;
+    }
+#endif
     overflowed = dropped != 0 || lp32 > lp_end;  // entries were dropped (or a parked list is out of order)
     if (DIRECT) return (uint32_t)(dst - ctx.dst);
     return (lp32 - list0) / kStride + dropped;

@@ -59,7 +59,49 @@ for i, s in enumerate(insts):
     if best is None or len(body) < len(best):
         best = body
 assert best, "main loop not found"
-cls = collections.Counter(classify(b.split()[0], b) for b in best)
+
+
+def wide_group(w):
+    """kWideGroup<W> of mm_fused_impl.h (blocks per wide sequence load; 0 = per-block loads)."""
+    def blocks(nd):
+        if w % 16 == 0:
+            return 0
+        nsub, valid, m = (w + 15) // 16, 32 * nd - 24, 0
+        while m < 8:
+            if any((2 * w * m + 32 * g) % 32 > 24 or 2 * w * m + 32 * g + 6 + 2 * min(16, w - 16 * g) > valid
+                   for g in range(nsub)):
+                break
+            m += 1
+        return m
+    m4, m5 = blocks(4), blocks(5)
+    return m4 if (m4 > 0 and 2 * m4 >= m5) else m5
+
+
+# With wide loads the block loop holds one view-extraction case per block of a group (a wave-uniform switch: ONE of
+# them runs per iteration) and the group's start (buffer rotation, v_alignbyte, the loads: once per group).  The
+# listing is split at its inner labels; pieces that are such a case or the group start count 1 / group.
+MG = wide_group(W)
+first = None
+for i, s_ in enumerate(insts):
+    if s_ is best[0] and insts[i:i + len(best)] == best:
+        first = i
+        break
+inner = sorted(v - first for v in labels.values() if first is not None and first < v < first + len(best))
+pieces, prev = [], 0
+for cut in inner + [len(best)]:
+    if cut > prev:
+        pieces.append(best[prev:cut])
+    prev = cut
+cls = collections.Counter()
+for piece in pieces:
+    ops = [b.split()[0] for b in piece]
+    valu = [o for o in ops if o.startswith("v_")]
+    group_start = any(o.startswith(("v_alignbyte", "buffer_load")) for o in ops)
+    view_case = bool(valu) and all(o.startswith("v_alignbit") for o in valu) and len(valu) <= 2 * ((W + 15) // 16)
+    wgt = 1.0 / MG if (MG > 1 and (group_start or view_case)) else 1.0
+    for b in piece:
+        cls[classify(b.split()[0], b)] += wgt
+cls = collections.Counter({k: round(v, 2) for k, v in cls.items()})
 meta = {}
 for ln in lines:
     for key in (".vgpr_count:", ".sgpr_count:", ".vgpr_spill_count:"):
@@ -73,7 +115,8 @@ full, half = cls["valu_full"], cls["valu_half"]
 # "by wall time at that clock"); the architectural figures are 2 and 4 (MI355X_MICROARCH.md)
 FULL, HALF = 2.31, 4.14
 rec = {"kernel": f"mm::fused_kernel<{W}, {c}, {c}, 0, false, false>", "kernel_source_sha": h.hexdigest()[:16],
-       "main_loop_windows": W, "main_loop_instructions": len(best), "valu_full_rate": full, "valu_half_rate": half,
+       "main_loop_windows": W, "main_loop_instructions": len(best), "wide_group_blocks": MG,
+       "valu_full_rate": full, "valu_half_rate": half,
        "salu": cls["salu"], "lds": cls["lds"], "vmem": cls["vmem"],
        "valu_per_window": round((full + half) / W, 2),
        "issue_clk_per_valu": round((FULL * full + HALF * half) / (full + half), 3),
