@@ -1322,9 +1322,17 @@ template <int W, bool CANON, bool HASH_RC, int MODE, bool SK, bool READS>
 // round 2): the next tighter bound loses everywhere (w = 39 at 128: 1207 against 1687 Gbases/s at 168;
 // w = 55 at 168: 1270 against 1449 at 256; w = 100 bounded to 256: 519 against 784 unbounded).  Forward
 // walks and the reads-mode kernels gain nothing from bounds and stay unbounded.
+// Forward walks with 8-bit lists (w <= 13, no super-k-mer indices): 7 workgroups per CU, i.e. at most 72 VGPRs,
+// since round 3 - with the wide sequence loads the kernel needed 85 registers (5 waves per SIMD) and a third of a
+// forward tile's time is look-back and copy-out, which only other resident waves can cover: k=21 w=11 on 3.1 Gbp
+// 1.174 ms unbounded, 1.099 at 6, 1.057 at 7, 1.055 at 8 (tools/gpu_jit_w.py).
 #ifndef MM_MIN_BLOCKS
-#define MM_MIN_BLOCKS \
-    (W <= 12 ? 4 : (CANON && !READS ? (W >= 19 && W <= 37 ? 4 : (W >= 38 && W <= 54 ? 3 : (W >= 55 && W <= 64 ? 2 : 1))) : 1))
+#define MM_MIN_BLOCKS                                                                                             \
+    (!CANON && !READS && !SK && W <= 13                                                                           \
+         ? 7                                                                                                      \
+         : (W <= 12 ? 4                                                                                           \
+                    : (CANON && !READS ? (W >= 19 && W <= 37 ? 4 : (W >= 38 && W <= 54 ? 3 : (W >= 55 && W <= 64 ? 2 : 1))) \
+                                       : 1)))
 #endif
 #ifndef MM_MIN_BLOCKS_WALK
 #define MM_MIN_BLOCKS_WALK MM_MIN_BLOCKS
