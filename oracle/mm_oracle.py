@@ -95,6 +95,9 @@ def lib(path: str | None = None):
     global _LIB
     if path is not None:
         return _bind(C.CDLL(path))
+    if _LIB is None and os.environ.get("MM_ORACLE_LIB"):
+        # (tests/test_sanitizers.py: the same suite against the -fsanitize=address,undefined build)
+        _LIB = _bind(C.CDLL(os.environ["MM_ORACLE_LIB"]))
     if _LIB is None:
         so = os.path.join(_HERE, "libmm_oracle.so")
         src_m = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("mm_oracle.c", "mm_oracle.h"))

@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsimd_minimizers_amd.so")
+# (MM_LIB_PATH: tests/test_sanitizers.py loads the build whose HOST objects carry AddressSanitizer + UBSan)
+LIB_PATH = os.environ.get("MM_LIB_PATH") or os.path.join(_HERE, "libsimd_minimizers_amd.so")
 
 MM_MINIMIZERS, MM_CLOSED_SYNCMERS, MM_OPEN_SYNCMERS = 0, 1, 2
 PATH_FUSED, PATH_GENERIC, PATH_SPLIT = 1, 2, 3

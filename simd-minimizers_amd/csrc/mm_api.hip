@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/simd_minimizers_amd.h"
+#include "mm_env.h"
 #include "mm_launch.h"
 
 namespace {
@@ -622,7 +623,7 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
         a.out.ticket = ws->ticket;
         a.out.error = reinterpret_cast<uint32_t *>(ws->total + 1);
         a.nblk = ws->nblk;
-        a.use_ticket = (ws->force_ticket || getenv("MM_FORCE_TICKET")) ? 1 : 0;
+        a.use_ticket = (ws->force_ticket || mm::mm_env("MM_FORCE_TICKET")) ? 1 : 0;
         a.scratch = nullptr;
         a.generic_round_windows = 0;
         a.timing_start = a.timing_stop = nullptr;
@@ -821,7 +822,7 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
 
     std::vector<unsigned long long> offs(n_seqs + 1);
     for (int attempt = 0; attempt < 2; ++attempt) {
-        a.use_ticket = (ws->force_ticket || getenv("MM_FORCE_TICKET")) ? 1 : 0;
+        a.use_ticket = (ws->force_ticket || mm::mm_env("MM_FORCE_TICKET")) ? 1 : 0;
         a.timing_start = a.timing_stop = nullptr;
         MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
         MM_HIP(hipMemsetAsync(ws->batch_offsets, 0xFF, (n_seqs + 1) * sizeof(unsigned long long), ws->stream));
@@ -963,7 +964,7 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
         a.out.total = ws->total;
         a.out.ticket = ws->ticket;
         a.out.error = reinterpret_cast<uint32_t *>(ws->total + 1);
-        a.use_ticket = (ws->force_ticket || getenv("MM_FORCE_TICKET")) ? 1 : 0;
+        a.use_ticket = (ws->force_ticket || mm::mm_env("MM_FORCE_TICKET")) ? 1 : 0;
         a.timing_start = a.timing_stop = nullptr;
         a.wamb = nullptr;
         a.wamb_dwords = 0;
@@ -1209,7 +1210,7 @@ static int run_host_pipelined(const mm_plan_t *plan, mm_workspace_t *ws, const u
                               uint64_t capacity, uint64_t *out_count) {
     const uint64_t l = (uint64_t)plan->k + plan->w - 1;
     const uint64_t n_w = n_bases >= l ? n_bases - l + 1 : 0;
-    if (!out_pos || n_w < kPipeMinWindows || getenv("MM_NO_PIPELINE")) return MM_PIPE_FALLBACK;
+    if (!out_pos || n_w < kPipeMinWindows || mm::mm_env("MM_NO_PIPELINE")) return MM_PIPE_FALLBACK;
     const uint64_t cap = capacity < n_w ? capacity : n_w;
     if (cap == 0) return MM_PIPE_FALLBACK;
     const uint64_t bytes = (base_offset + n_bases + 3) / 4;
@@ -1558,7 +1559,7 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
     // per-iteration workgroup barriers and staging, not by the two extra reads of the text, and the look-backs
     // serialise what three independent grids overlap - so the three passes stay the default.  A look-back
     // time-out of the one-pass kernel sends the workspace back to the three-pass kernels.
-    const char *env_one = getenv("MM_FASTA_ONEPASS");
+    const char *env_one = mm::mm_env("MM_FASTA_ONEPASS");
     const bool one_pass = env_one && env_one[0] == '1' && !ws->fasta_three_pass;
     if (one_pass) MM_HIP(hipMemsetAsync(ws->total + 1, 0, sizeof(unsigned long long), ws->stream));
     if (mm::launch_fasta_pack(d_text, n_bytes, d_packed, packed_capacity_bytes & ~3ull,

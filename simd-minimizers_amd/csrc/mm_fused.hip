@@ -5,6 +5,7 @@
 // back to the generic family (mm_generic.hip) — still HIP, never the CPU.
 #include "mm_fused_impl.h"
 #include "mm_fused_inst.h"
+#include "mm_env.h"
 #include "mm_launch.h"
 #include "mm_split.h"
 
@@ -22,7 +23,8 @@ using Instance = FusedInstance;
 
 const Instance *find_instance(uint32_t w, int canonical_windows, int hasher_canonical) {
     using Getter = const Instance *(*)(int *);
-    static const Getter kGroups[] = {fused_instances_a, fused_instances_b, fused_instances_c, fused_instances_d, fused_instances_e, fused_instances_f, fused_instances_g, fused_instances_h, fused_instances_i};
+    static const Getter kGroups[] = {fused_instances_a, fused_instances_b, fused_instances_c, fused_instances_d, fused_instances_e, fused_instances_f, fused_instances_g, fused_instances_h, fused_instances_i,
+                                     fused_instances_j, fused_instances_k, fused_instances_l, fused_instances_m};
     for (Getter get : kGroups) {
         int n = 0;
         const Instance *inst = get(&n);
@@ -78,7 +80,7 @@ uint32_t default_cap_limit(uint32_t w, bool canonical, bool e8 = false) {
 
 uint32_t legal_nblk(uint32_t w, uint32_t mode, uint32_t want, uint32_t cap_limit = 76u) {
     if (want == 0) {
-        if (const char *e = getenv("MM_CAP_LIMIT")) cap_limit = (uint32_t)atoi(e);  // experiments
+        if (const char *e = mm_env("MM_CAP_LIMIT")) cap_limit = (uint32_t)atoi(e);  // experiments
         want = (uint32_t)(68.0 / (1.3 * emit_density(w, mode)) / w) + 1u;
         while (want > 12u && list_capacity(w, mode, w * want) > cap_limit) --want;
         // open syncmers come in irregular clumps: their lists overflow far more often at the same
@@ -160,7 +162,7 @@ thread_local std::string t_jit_error;
 KernelRef resolve_kernel(uint32_t w, int canonical_windows, int hasher_canonical, uint32_t mode, bool sk) {
     KernelRef kr;
     if (mode > 2) return kr;
-    const bool force_jit = getenv("MM_JIT_FORCE") != nullptr;  // tuning experiments
+    const bool force_jit = mm_env("MM_JIT_FORCE") != nullptr;  // tuning experiments
     const Instance *inst = force_jit ? nullptr : find_instance(w, canonical_windows, hasher_canonical);
     if (inst) {
         kr.host = inst->fn[(mode == 0 && sk) ? 3 : mode];
@@ -178,7 +180,7 @@ int launch_kernel(const KernelRef &kr, uint32_t grid, uint32_t lds_bytes, hipStr
             hipFuncSetAttribute(reinterpret_cast<const void *>(kr.host),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return -1;
-        if (getenv("MM_PRINT_OCC")) {  // occupancy experiments: what the runtime computes from the kernel's resources
+        if (mm_env("MM_PRINT_OCC")) {  // occupancy experiments: what the runtime computes from the kernel's resources
             int nb = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kr.host),
                                                                (int)kFusedThreads, lds_bytes);
@@ -382,7 +384,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.redo_n = nullptr;
     p.use_ticket = a.use_ticket ? 1u : 0u;
     {
-        const char *dbg = getenv("MM_DEBUG");
+        const char *dbg = mm_env("MM_DEBUG");
         p.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
     }
     if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (g.nblocks + 8) * status_stride_host(), stream) != hipSuccess)
@@ -394,9 +396,9 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         p.list_cap = g.list_cap / 2 > a.w + 2 ? g.list_cap / 2 : a.w + 2;
         lds_bytes = p.list_cap * stride_of(a);
     }
-    if (const char *pad = getenv("MM_LDS_PAD")) g_lds_pad = (uint32_t)atoi(pad);  // occupancy experiments
+    if (const char *pad = mm_env("MM_LDS_PAD")) g_lds_pad = (uint32_t)atoi(pad);  // occupancy experiments
     p.trace = nullptr;
-    if (const char *tr = getenv("MM_TRACE")) {
+    if (const char *tr = mm_env("MM_TRACE")) {
         // timing experiment: per-tile timestamps dumped to the file MM_TRACE (synchronous)
         unsigned long long *d_tr = nullptr;
         const size_t bytes = sizeof(unsigned long long) * 10 * g.nblocks;
@@ -427,7 +429,7 @@ namespace {
 KernelRef resolve_walk_kernel(uint32_t w, int canonical_windows, int hasher_canonical, uint32_t mode, bool sk) {
     KernelRef kr;
     if (mode > 2) return kr;
-    const bool force_jit = getenv("MM_JIT_FORCE") != nullptr;
+    const bool force_jit = mm_env("MM_JIT_FORCE") != nullptr;
     int n = 0;
     const WalkInstance *inst = walk_instances(&n);
     for (int i = 0; i < n && !force_jit; ++i)
@@ -447,7 +449,7 @@ uint32_t split_dump_stride(const Geometry &g) { return (kSplitHeader + g.lds_byt
 // workgroups move 2.3 TB/s, 512 move 3.6)
 uint32_t split_expanders(const RunArgs &a, uint64_t tiles) {
     uint32_t e = a.canonical_windows ? 256u : 512u;
-    if (const char *v = getenv("MM_SPLIT_E")) e = (uint32_t)atoi(v);
+    if (const char *v = mm_env("MM_SPLIT_E")) e = (uint32_t)atoi(v);
     if (e < 1u) e = 1u;
     if (e > tiles) e = (uint32_t)tiles;
     return e;
@@ -462,7 +464,7 @@ void split_requirements(const RunArgs &a, uint64_t *tiles, uint64_t *dump_bytes)
 }
 
 bool split_wanted(const RunArgs &a) {
-    if (const char *v = getenv("MM_SPLIT")) return v[0] == '1';
+    if (const char *v = mm_env("MM_SPLIT")) return v[0] == '1';
     return false;
 }
 
@@ -500,7 +502,7 @@ int launch_split(const RunArgs &a, const SplitBuffers &b, hipStream_t stream) {
     p.out = a.out;
     p.use_ticket = 0;
     {
-        const char *dbg = getenv("MM_DEBUG");
+        const char *dbg = mm_env("MM_DEBUG");
         p.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
     }
     p.trace = nullptr;
@@ -568,7 +570,8 @@ namespace {
 const FusedReadsInstance *find_reads_instance(uint32_t w, int canonical_windows, int hasher_canonical) {
     using Getter = const FusedReadsInstance *(*)(int *);
     static const Getter kGroups[] = {fused_reads_instances_a, fused_reads_instances_b,
-                                     fused_reads_instances_c, fused_reads_instances_d};
+                                     fused_reads_instances_c, fused_reads_instances_d,
+                                     fused_reads_instances_e};
     for (Getter get : kGroups) {
         int n = 0;
         const FusedReadsInstance *inst = get(&n);
@@ -613,7 +616,7 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     // default_cap_limit)
     const uint32_t r_cache = a.read_stride >= 400u ? 1u : 400u / (a.read_stride ? a.read_stride : 1u);
     while (R < 4u && R < r_cache && cap_for(R + 1) * kListStride <= 40u * 1024u) ++R;
-    if (const char *e = getenv("MM_READS_PER_LANE")) R = (uint32_t)atoi(e);
+    if (const char *e = mm_env("MM_READS_PER_LANE")) R = (uint32_t)atoi(e);
     if (R < 1u) R = 1u;
     if (R > 4u) R = 4u;
     const uint32_t cap = cap_for(R);

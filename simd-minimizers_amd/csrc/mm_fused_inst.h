@@ -30,6 +30,10 @@ const FusedInstance *fused_instances_f(int *count);
 const FusedInstance *fused_instances_g(int *count);
 const FusedInstance *fused_instances_h(int *count);
 const FusedInstance *fused_instances_i(int *count);
+const FusedInstance *fused_instances_j(int *count);
+const FusedInstance *fused_instances_k(int *count);
+const FusedInstance *fused_instances_l(int *count);
+const FusedInstance *fused_instances_m(int *count);
 
 // reads-mode instances (minimizers only), mm_fused_inst_reads_*.hip
 struct FusedReadsInstance {
@@ -44,6 +48,7 @@ const FusedReadsInstance *fused_reads_instances_a(int *count);
 const FusedReadsInstance *fused_reads_instances_b(int *count);
 const FusedReadsInstance *fused_reads_instances_c(int *count);
 const FusedReadsInstance *fused_reads_instances_d(int *count);
+const FusedReadsInstance *fused_reads_instances_e(int *count);
 
 // walk kernels of the split path (walk_kernel), mm_walk_inst.hip
 struct WalkInstance {

@@ -1,0 +1,20 @@
+// Explicit instantiations of the fused kernel (split over several files so that the
+// build parallelises); the launcher in mm_fused.hip looks them up through fused_instances_m().
+// Round 3: the even window sizes 18..32 (30, 32 here), which used to be compiled at first use.
+#include "mm_fused_impl.h"
+#include "mm_fused_inst.h"
+
+namespace mm {
+
+const FusedInstance *fused_instances_m(int *count) {
+    static const FusedInstance kInst[] = {
+        MM_FUSED_INST(30, true, true),
+        MM_FUSED_INST(30, false, false),
+        MM_FUSED_INST(32, true, true),
+        MM_FUSED_INST(32, false, false),
+    };
+    *count = (int)(sizeof(kInst) / sizeof(kInst[0]));
+    return kInst;
+}
+
+}  // namespace mm

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "mm_env.h"
 #include "mm_launch.h"
 
 namespace mm {
@@ -131,7 +132,7 @@ bool compile(const std::string &name, std::vector<char> &code, std::string &lowe
     hiprtcAddNameExpression(prog, name.c_str());
     const std::string threads = "-DMM_FUSED_THREADS=" + std::to_string(kFusedThreads);
     std::vector<std::string> extra;  // MM_JIT_DEFS: extra -D options (tuning experiments)
-    if (const char *d = getenv("MM_JIT_DEFS")) {
+    if (const char *d = mm_env("MM_JIT_DEFS")) {
         std::string cur;
         for (const char *c = d;; ++c) {
             if (*c == ' ' || *c == '\0') {
@@ -174,7 +175,7 @@ bool compile(const std::string &name, std::vector<char> &code, std::string &lowe
 }  // namespace
 
 bool jit_enabled() {
-    const char *e = getenv("MM_JIT");
+    const char *e = mm_env("MM_JIT");
     return !(e && e[0] == '0');
 }
 
@@ -199,7 +200,7 @@ hipFunction_t jit_fused_kernel(uint32_t w, bool canon, bool hash_rc, int mode, b
         return nullptr;
     }
     const std::string name = fused_kernel_name(w, canon, hash_rc, mode, sk, reads, walk);
-    const char *defs = getenv("MM_JIT_DEFS");
+    const char *defs = mm_env("MM_JIT_DEFS");
     const std::string key = std::to_string(device) + ":" + name + "|" + (defs ? defs : "");
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_functions.find(key);

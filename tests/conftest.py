@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the tests flip MM_* switches between runs of one process: the library must read them every time (mm_env.h)
+os.environ.setdefault("MM_ENV_DYNAMIC", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:

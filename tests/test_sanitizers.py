@@ -1,0 +1,121 @@
+"""Sanitizer passes on the CPU side (GPU sanitizers are not available on this pool):
+
+* the oracle - the checker every parity claim rests on - built with -fsanitize=address,undefined
+  (oracle/Makefile `asan`) and driven through its whole CPU test file;
+* (GPU box) the HOST side of the product - workspaces, tile tables of batch and reads runs, the pipelined and the
+  sharded host entry points, capacity arithmetic - from a library whose host objects are built with clang's
+  AddressSanitizer + UBSan (csrc/Makefile `hostasan`; device code is the normal build).
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gcc_runtime(name):
+    p = subprocess.run(["gcc", "-print-file-name=" + name], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+def test_oracle_under_asan_ubsan():
+    asan, ubsan = _gcc_runtime("libasan.so"), _gcc_runtime("libubsan.so")
+    if not asan:
+        pytest.skip("gcc has no libasan here")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "asan"], check=True, capture_output=True)
+    env = dict(os.environ, MM_ORACLE_LIB=os.path.join(ROOT, "oracle", "libmm_oracle_asan.so"),
+               LD_PRELOAD=":".join(x for x in (asan, ubsan) if x),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_oracle.py"), "-x", "-q",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0 and "passed" in r.stdout, tail
+    assert "ERROR: AddressSanitizer" not in tail and "runtime error" not in tail, tail
+
+
+_HOST_SCRIPT = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/oracle")
+import simd_minimizers_amd as sm
+import mm_oracle as oracle
+rng = np.random.default_rng(3)
+k, w = 21, 11
+b = sm.canonical_minimizers(k, w)
+# batches: many tile tables of different shapes on one workspace (grow / reuse), empty and short sequences
+for trial in range(6):
+    lens = [int(x) for x in rng.integers(0, 400_000, size=int(rng.integers(1, 40)))] + [0, 5, 31]
+    seqs = [oracle.gen_packed(100 + i, m + 3) for i, m in enumerate(lens)]
+    d = [torch.from_numpy(s).cuda() for s in seqs]
+    out = torch.zeros(sum(lens) // 3 + 64, dtype=torch.int32, device="cuda")
+    offs = sm.run_batch_device(b, d, lens, out)
+    for i in (0, len(lens) // 2, len(lens) - 1):
+        want = oracle.run(seqs[i], lens[i], k, w, canonical=True)
+        assert np.array_equal(out[offs[i]:offs[i + 1]].cpu().numpy().view(np.uint32), want)
+# reads: fixed and per-read lengths, super-k-mer indices
+n_reads, rl = 5000, 150
+data = oracle.gen_packed(9, n_reads * rl)
+d = torch.from_numpy(data).cuda()
+out = torch.zeros(n_reads * rl // 2, dtype=torch.int32, device="cuda")
+sk = torch.zeros_like(out)
+offs = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
+lens = torch.from_numpy(rng.integers(0, rl + 1, size=n_reads).astype(np.uint32)).cuda()
+for kw in ({}, {"read_lens": lens}, {"out_sk": sk}):
+    sm.run_reads_device(b, d, n_reads, rl, rl, out, offs, **kw)
+# host entry points: one shot, pipelined (long), sharded over two workspaces, contigs over three
+for n in (1000, 3_000_017, 60_000_000):
+    data = oracle.gen_packed(5, n)
+    got, _ = b._run_arrays(sm.PackedSeq(data, 0, n))
+    if n < 10_000_000:
+        assert np.array_equal(np.asarray(got, dtype=np.uint32), oracle.run(data, n, k, w, canonical=True))
+g = sm.DeviceGroup([0, 0, 0])
+data = oracle.gen_packed(6, 4_000_003)
+pos, _ = g.run(b, data, 4_000_003)
+assert np.array_equal(pos, oracle.run(data, 4_000_003, k, w, canonical=True))
+lens = [300_000, 7, 0, 1_000_001, 250_000]
+seqs = [oracle.gen_packed(60 + i, m + 3) for i, m in enumerate(lens)]
+pos, _, o = g.run_batch(b, seqs, lens)
+assert np.array_equal(pos[o[3]:o[4]], oracle.run(seqs[3], lens[3], k, w, canonical=True))
+try:
+    g.run(b, data, 4_000_003, capacity=100)
+    raise SystemExit("capacity error expected")
+except sm.MinimizerError:
+    pass
+g.close()
+# FASTA text, values
+text = b">a\nACGTACGTTTGACCA\nACGT\n>b\n\n>c\nTTTTGGGG\n" * 50
+rec = sm.fasta_pack_device(text)
+assert len(rec) == 150
+print("host paths ok")
+"""
+
+
+@pytest.mark.gpu
+def test_host_side_under_asan_ubsan():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    lib = os.path.join(ROOT, "simd-minimizers_amd", "libsimd_minimizers_amd_hostasan.so")
+    if not os.path.exists(lib):
+        pytest.skip("host-sanitized library not built (make -C simd-minimizers_amd/csrc hostasan)")
+    # gcc's AddressSanitizer runtime (ROCm's clang runtime intercepts the HSA allocator for GPU sanitizing, which
+    # this pool does not support; the interface the instrumented host objects call is the same)
+    rt = _gcc_runtime("libasan.so")
+    if not rt:
+        pytest.skip("no AddressSanitizer runtime")
+    # (libstdc++ preloaded as well: the runtime looks __cxa_throw up when it starts, and python itself does not
+    # link the C++ library - without it the first C++ exception inside torch trips an internal check)
+    stdcxx = _gcc_runtime("libstdc++.so.6") or _gcc_runtime("libstdc++.so")
+    # (and torch's library directory on the search path: dlopen through the runtime's interceptor loses the RUNPATH
+    # of the caller, so torch would not find its own lazily loaded libraries)
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    env = dict(os.environ, MM_LIB_PATH=lib, LD_PRELOAD=":".join(x for x in (rt, _gcc_runtime("libubsan.so"), stdcxx) if x),
+               LD_LIBRARY_PATH=torch_lib + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""),
+               ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0:abort_on_error=1:detect_odr_violation=0",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-c", _HOST_SCRIPT, ROOT], env=env, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-4000:]
+    assert r.returncode == 0 and "host paths ok" in r.stdout, tail
+    assert "ERROR: AddressSanitizer" not in tail and "runtime error:" not in tail, tail

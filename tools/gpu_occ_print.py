@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["MM_PRINT_OCC"] = "1"
 import torch
+os.environ.setdefault("MM_ENV_DYNAMIC", "1")  # this script flips MM_* switches between runs (mm_env.h)
 import simd_minimizers_amd as sm
 n = 400_000_000
 d = sm.generate_device(n, 3)

@@ -5,6 +5,7 @@ import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+os.environ.setdefault("MM_ENV_DYNAMIC", "1")  # this script flips MM_* switches between runs (mm_env.h)
 import simd_minimizers_amd as sm
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3_100_000_000

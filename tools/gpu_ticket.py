@@ -3,6 +3,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+os.environ.setdefault("MM_ENV_DYNAMIC", "1")  # this script flips MM_* switches between runs (mm_env.h)
 import simd_minimizers_amd as sm
 n = 3_100_000_000
 d = sm.generate_device(n, 3); ws = sm.default_workspace(0)
