@@ -79,7 +79,9 @@ def headline(tag):
     d = kernel_durations(db)
     lines.append("-- fused_kernel launches in order, us: " + " ".join(f"{x:.0f}" for x in d) + "\n")
     if len(d) >= 20:
-        lines.append(f"-- average of the last 20 launches (the timed steps): {sum(d[-20:]) / 20:.1f} us\n")
+        # launches in order: 40 warm-up, 20 timed, then the steps of the clock probe (a second queue is active there)
+        timed = d[40:60] if len(d) >= 60 else d[-20:]
+        lines.append(f"-- average of launches 41..60 (the timed steps): {sum(timed) / len(timed):.1f} us\n")
     try:
         log = open(os.path.join(OUT, tag + "_stats.log")).read().strip().split("\n")
         js = [x for x in log if x.startswith("{")][-1]
@@ -187,8 +189,16 @@ def component(tag, cfg):
     open(os.path.join(OUT, f"{tag}_{cfg}.txt"), "w").writelines(lines)
 
 
+def cleanup():
+    """The profiler's databases are large and gpurun copies back at most 64 MiB: keep only the condensed files."""
+    for d in glob.glob(os.path.join(OUT, "prof_*")):
+        subprocess.run(["rm", "-rf", d])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    import atexit
+    atexit.register(cleanup)
     tag = sys.argv[1]
     for what in sys.argv[2:]:
         if what == "headline":
