@@ -1555,10 +1555,10 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
     ws->scratch = sp;
     if (r) return r;
     // MM_FASTA_ONEPASS=1: the text is read once (decoupled look-backs between the chunks) instead of three times.
-    // Measured SLOWER on MI355X (round 3, 1 GiB of text: 2.07 ms against 1.66 ms): the packer is bound by its
-    // per-iteration workgroup barriers and staging, not by the two extra reads of the text, and the look-backs
-    // serialise what three independent grids overlap - so the three passes stay the default.  A look-back
-    // time-out of the one-pass kernel sends the workspace back to the three-pass kernels.
+    // Measured no faster on MI355X (round 3, 1 GiB of text: 1.77 ms against 1.68 ms; 1.15 ms without its look-backs):
+    // a third of it is waiting in two consecutive look-backs, the rest the packer's own instruction work - so the
+    // three passes stay the default.  A look-back time-out of the one-pass kernel sends the
+    // workspace back to the three-pass kernels.
     const char *env_one = mm::mm_env("MM_FASTA_ONEPASS");
     const bool one_pass = env_one && env_one[0] == '1' && !ws->fasta_three_pass;
     if (one_pass) MM_HIP(hipMemsetAsync(ws->total + 1, 0, sizeof(unsigned long long), ws->stream));

@@ -174,6 +174,17 @@ __device__ __forceinline__ uint32_t block_sum_excl(uint32_t v, uint32_t *s, uint
     return base + incl - v;
 }
 
+// inclusive prefix sum over the lanes of a wave
+__device__ __forceinline__ uint32_t wave_scan_sum(uint32_t v) {
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, d, kWave);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
 struct MaxOp {
     __device__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a > b ? a : b; }
 };
@@ -491,32 +502,61 @@ __device__ __forceinline__ uint32_t lookback_context(unsigned long long *status,
     return h | (started << 1);
 }
 
+// One-pass kernel, wave-serial (round 3, second version).  A chunk is 16 KB: every wave owns a contiguous 4 KB of it and
+// walks its four 1 KB pieces (64 lanes x 16 bytes, coalesced) by itself - the line / record context inside a wave comes
+// from a ballot and a shuffle, the offsets from a DPP scan, the packed codes go through a staging area in LDS that
+// belongs to the wave - so the workgroup meets at FOUR barriers per chunk (marks, context, counts, offsets) instead
+// of five per 4 KB.  The first version kept the three-pass kernels' workgroup-wide iterations behind the look-backs
+// and ran 25 % slower than the three passes.
+#ifndef MM_FASTA_OP_ITERS
+#define MM_FASTA_OP_ITERS 4
+#endif
+constexpr uint32_t kOpIters = MM_FASTA_OP_ITERS;                  // 1 KB pieces per wave
+constexpr uint32_t kOpWaveBytes = 16u * kWave * kOpIters;         // 4 KB
+constexpr uint32_t kOpChunkBytes = kOpWaveBytes * kWavesPerBlock;  // 16 KB
+constexpr uint32_t kOpStage = 16u * kWave * 2u / 32u + 2u;        // dwords a 1 KB piece can pack into, + 2
+
+// latest mark (position + 1, 0 = none) among the lower lanes of the wave / in the whole wave
+__device__ __forceinline__ void wave_prev_mark(uint32_t v, uint32_t &excl, uint32_t &last) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const unsigned long long m = __ballot(v != 0u);
+    const unsigned long long lower = m & ((1ull << lane) - 1ull);
+    const uint32_t from_lower = (uint32_t)__shfl((int)v, lower ? 63 - __builtin_clzll(lower) : 0, kWave);
+    const uint32_t from_top = (uint32_t)__shfl((int)v, m ? 63 - __builtin_clzll(m) : 0, kWave);
+    excl = lower ? from_lower : 0u;
+    last = m ? from_top : 0u;
+}
+
 __global__ __launch_bounds__(kBlockThreads) void fasta_onepass_kernel(
     const uint8_t *__restrict__ text, uint64_t n, unsigned long long *__restrict__ st_ctx,
     unsigned long long *__restrict__ st_bases, unsigned long long *__restrict__ st_recs, uint32_t *__restrict__ out32,
     uint64_t out_dwords, unsigned long long *__restrict__ rec_base, unsigned long long *__restrict__ rec_pos,
     uint64_t max_records, unsigned long long *__restrict__ counts, uint32_t n_chunks, uint32_t *error) {
-    __shared__ uint32_t s[2 * kWavesPerBlock];
-    __shared__ uint32_t s_stage[2][kIterBytes / 16 + 2];
+    __shared__ uint32_t s_mark[2][kWavesPerBlock];  // last newline / record start of every wave (position + 1 in the chunk)
+    __shared__ uint32_t s_cnt[2][kWavesPerBlock];   // sequence bytes / record starts of every wave
     __shared__ uint32_t s_ctx;
     __shared__ unsigned long long s_off[2];
+    __shared__ uint32_t s_stage[kWavesPerBlock][kOpStage];
     const uint32_t tid = threadIdx.x, bid = blockIdx.x;
     const int lane = tid & (kWave - 1), wave = tid / kWave;
-    const uint64_t c0 = (uint64_t)bid * kChunkBytes;
-    for (uint32_t i = tid; i < kIterBytes / 16 + 2; i += kBlockThreads) s_stage[0][i] = s_stage[1][i] = 0;
-    Raw raw[kIters];
+    const uint64_t c0 = (uint64_t)bid * kOpChunkBytes;
+    const uint32_t w0 = (uint32_t)wave * kOpWaveBytes;  // first byte of the wave's part, relative to the chunk
+    for (uint32_t i = (uint32_t)lane; i < kOpStage; i += kWave) s_stage[wave][i] = 0;
+    Raw raw[kOpIters];
 #pragma unroll
-    for (uint32_t it = 0; it < kIters; ++it) raw[it] = load_raw(text, n, c0 + (uint64_t)it * kIterBytes + 16ull * tid);
-    // ---- what the chunk says about the context of its successors (context-free)
-    uint32_t mnl = 0, mrec = 0;  // last newline / record start of the thread, position + 1 relative to the chunk
+    for (uint32_t it = 0; it < kOpIters; ++it) raw[it] = load_raw(text, n, c0 + w0 + it * (16u * kWave) + 16ull * lane);
+    // ---- the masks of every piece, made once and kept (the three-pass kernels make them in every pass), and the marks
+    // of the wave's part (context-free)
+    Piece pc[kOpIters];
+    uint32_t pls[kOpIters], prs[kOpIters];
+    uint32_t mnl = 0, mrec = 0;
 #pragma unroll
-    for (uint32_t it = 0; it < kIters; ++it) {
-        const uint32_t rel = it * kIterBytes + 16u * tid;
-        const Piece p = make_piece(raw[it], text, n, c0 + rel);
-        uint32_t ls, rs;
-        starts(p, ls, rs);
-        if (p.nl) mnl = rel + top_bit_pos1(p.nl);
-        if (rs) mrec = rel + top_bit_pos1(rs);
+    for (uint32_t it = 0; it < kOpIters; ++it) {
+        const uint32_t rel = w0 + it * (16u * kWave) + 16u * (uint32_t)lane;
+        pc[it] = make_piece(raw[it], text, n, c0 + rel);
+        starts(pc[it], pls[it], prs[it]);
+        if (pc[it].nl) mnl = rel + top_bit_pos1(pc[it].nl);
+        if (prs[it]) mrec = rel + top_bit_pos1(prs[it]);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -524,120 +564,129 @@ __global__ __launch_bounds__(kBlockThreads) void fasta_onepass_kernel(
         mrec = max(mrec, (uint32_t)__shfl_xor((int)mrec, d, kWave));
     }
     if (lane == 0) {
-        s[wave] = mnl;
-        s[kWavesPerBlock + wave] = mrec;
+        s_mark[0][wave] = mnl;
+        s_mark[1][wave] = mrec;
     }
     __syncthreads();
     if (wave == 0) {
         uint32_t a = 0, b = 0;
 #pragma unroll
         for (int w = 0; w < kWavesPerBlock; ++w) {
-            a = max(a, s[w]);
-            b = max(b, s[kWavesPerBlock + w]);
+            a = max(a, s_mark[0][w]);
+            b = max(b, s_mark[1][w]);
         }
         const uint32_t kind = (b > a) ? (uint32_t)kCtxHeader : (a ? (uint32_t)kCtxPlain : 0u);
+#ifdef MM_FASTA_NOLB  // timing experiment (wrong results): no look-backs
+        const uint32_t ctx = 2u + (kind & 0u);
+#else
         const uint32_t ctx = lookback_context(st_ctx, bid, kind, b != 0u, error);
+#endif
         if (lane == 0) s_ctx = ctx;
     }
     __syncthreads();
     const uint32_t ctx = s_ctx;
-    // the context as K2 / K3 take it: positions + 1 of the last newline / record start before the chunk; only their
-    // order and whether a record exists matter
-    const unsigned long long ln0 = (ctx & 2u) ? 1ull : 0ull, lr0 = (ctx & 2u) ? ((ctx & 1u) ? 2ull : 1ull) : 0ull;
-    // (started, in header: lr0 = 2 > ln0 = 1; started, not in header: lr0 = 1 = ln0, i.e. lr0 > ln0 is false and
-    // lr0 > 0; not started: both 0)
-    // ---- counts of the chunk with its context
-    unsigned long long ln_run = ln0, lr_run = lr0;
-    uint32_t my_bases = 0, my_recs = 0;
+    // context as pseudo-positions (only their order and lr > 0 matter): marks inside the chunk are 3 + position
+    unsigned long long ln_run = (ctx & 2u) ? 1ull : 0ull, lr_run = (ctx & 2u) ? ((ctx & 1u) ? 2ull : 1ull) : 0ull;
 #pragma unroll
-    for (uint32_t it = 0; it < kIters; ++it) {
-        const uint64_t i0 = c0 + (uint64_t)it * kIterBytes;
-        if (i0 >= n) break;  // (uniform)
-        const Piece p = make_piece(raw[it], text, n, i0 + 16ull * tid);
-        uint32_t ls, rs;
-        starts(p, ls, rs);
-        const uint32_t tnl = p.nl ? 16u * tid + top_bit_pos1(p.nl) : 0u;
-        const uint32_t trec = rs ? 16u * tid + top_bit_pos1(rs) : 0u;
-        uint32_t xnl, xrec, tot_nl, tot_rec;
-        block_prev_marks(tnl, trec, s, xnl, xrec, tot_nl, tot_rec);
-        // (marks inside the chunk are later than any before it: offset them past the two context values)
-        const unsigned long long ln = xnl ? 3ull + it * kIterBytes + xnl : ln_run, lr = xrec ? 3ull + it * kIterBytes + xrec : lr_run;
-        my_bases += (uint32_t)__builtin_popcount(base_mask(p, ls, rs, ln, lr));
-        my_recs += (uint32_t)__builtin_popcount(rs);
-        ln_run = tot_nl ? 3ull + it * kIterBytes + tot_nl : ln_run;
-        lr_run = tot_rec ? 3ull + it * kIterBytes + tot_rec : lr_run;
+    for (int w = 0; w < kWavesPerBlock; ++w)
+        if (w < wave) {
+            if (s_mark[0][w]) ln_run = 3ull + s_mark[0][w];
+            if (s_mark[1][w]) lr_run = 3ull + s_mark[1][w];
+        }
+    // ---- base masks, counts and offsets inside the wave
+    uint32_t bm[kOpIters], ex[kOpIters], tot[kOpIters];
+    uint32_t wave_b = 0, wave_r = 0;
+#pragma unroll
+    for (uint32_t it = 0; it < kOpIters; ++it) {
+        const uint32_t rel = w0 + it * (16u * kWave) + 16u * (uint32_t)lane;
+        const Piece &p = pc[it];
+        const uint32_t ls = pls[it], rs = prs[it];
+        const uint32_t tnl = p.nl ? rel + top_bit_pos1(p.nl) : 0u, trec = rs ? rel + top_bit_pos1(rs) : 0u;
+        uint32_t xnl, xrec, tnl_w, trec_w;
+        wave_prev_mark(tnl, xnl, tnl_w);
+        wave_prev_mark(trec, xrec, trec_w);
+        const unsigned long long ln = xnl ? 3ull + xnl : ln_run, lr = xrec ? 3ull + xrec : lr_run;
+        bm[it] = base_mask(p, ls, rs, ln, lr);
+        const uint32_t c = (uint32_t)__builtin_popcount(bm[it]) | ((uint32_t)__builtin_popcount(rs) << 16);
+        const uint32_t incl = wave_scan_sum(c);
+        ex[it] = incl - c;
+        tot[it] = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+        wave_b += tot[it] & 0xffffu;
+        wave_r += tot[it] >> 16;
+        if (tnl_w) ln_run = 3ull + tnl_w;
+        if (trec_w) lr_run = 3ull + trec_w;
     }
-    uint32_t tot;
-    block_sum_excl((my_recs << 16) | my_bases, s, tot);  // (at most 32768 bases and 16384 record starts per chunk)
-    const uint32_t chunk_bases = tot & 0xffffu, chunk_recs = tot >> 16;
-    // ---- output offsets: wave 0 sums the bases, wave 1 the records of all earlier chunks
-    if (wave == 0) {
-        const unsigned long long ex = lookback_exclusive(st_bases, bid, chunk_bases, 0ull, error);
-        if (lane == 0) s_off[0] = ex;
-    } else if (wave == 1) {
-        const unsigned long long ex = lookback_exclusive(st_recs, bid, chunk_recs, 0ull, error);
-        if (lane == 0) s_off[1] = ex;
+    if (lane == 0) {
+        s_cnt[0][wave] = wave_b;
+        s_cnt[1][wave] = wave_r;
+    }
+    __syncthreads();
+    if (wave < 2) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) t += s_cnt[wave][w];
+#ifdef MM_FASTA_NOLB
+        const unsigned long long e = wave == 0 ? (unsigned long long)bid * 16000ull + (t & 0u) : 0ull;
+#else
+        const unsigned long long e = lookback_exclusive(wave == 0 ? st_bases : st_recs, bid, t, 0ull, error);
+#endif
+        if (lane == 0) s_off[wave] = e;
     }
     __syncthreads();
     unsigned long long bases_run = s_off[0], recs_run = s_off[1];
-    // ---- pack (fasta_walk_kernel<true>'s loop)
-    ln_run = ln0;
-    lr_run = lr0;
 #pragma unroll
-    for (uint32_t it = 0; it < kIters; ++it) {
-        const uint64_t i0 = c0 + (uint64_t)it * kIterBytes;
-        if (i0 >= n) break;  // (uniform)
-        const uint64_t o = i0 + 16ull * tid;
-        const Piece p = make_piece(raw[it], text, n, o);
-        uint32_t ls, rs;
-        starts(p, ls, rs);
-        const uint32_t tnl = p.nl ? 16u * tid + top_bit_pos1(p.nl) : 0u;
-        const uint32_t trec = rs ? 16u * tid + top_bit_pos1(rs) : 0u;
-        uint32_t xnl, xrec, tot_nl, tot_rec;
-        block_prev_marks(tnl, trec, s, xnl, xrec, tot_nl, tot_rec);
-        const unsigned long long ln = xnl ? 3ull + it * kIterBytes + xnl : ln_run, lr = xrec ? 3ull + it * kIterBytes + xrec : lr_run;
-        const uint32_t bm = base_mask(p, ls, rs, ln, lr);
-        const uint32_t nb = (uint32_t)__builtin_popcount(bm), nr = (uint32_t)__builtin_popcount(rs);
-        uint32_t tot2;
-        const uint32_t ex = block_sum_excl((nr << 16) | nb, s, tot2);
-        const uint32_t xb = ex & 0xffffu, xr = ex >> 16, tot_b = tot2 & 0xffffu, tot_r = tot2 >> 16;
-        const unsigned long long g0 = bases_run + xb;  // global index of this thread's first base
-        for (uint32_t m = rs, k = 0; m; m &= m - 1u, ++k) {
-            const uint32_t j = (uint32_t)__builtin_ctz(m);
-            const unsigned long long r = recs_run + xr + k;
+    for (int w = 0; w < kWavesPerBlock; ++w)
+        if (w < wave) {
+            bases_run += s_cnt[0][w];
+            recs_run += s_cnt[1][w];
+        }
+    // ---- pack: the wave's own staging area, no barrier
+    uint32_t *stage = s_stage[wave];
+#pragma unroll
+    for (uint32_t it = 0; it < kOpIters; ++it) {
+        const uint32_t rel = w0 + it * (16u * kWave) + 16u * (uint32_t)lane;
+        const uint64_t o = c0 + rel;
+        const Piece &p = pc[it];
+        const uint32_t rs = prs[it];
+        const uint32_t m = bm[it], nb = (uint32_t)__builtin_popcount(m);
+        const uint32_t tot_b = tot[it] & 0xffffu, tot_r = tot[it] >> 16;
+        const unsigned long long g0 = bases_run + (ex[it] & 0xffffu);
+        for (uint32_t q = rs, k = 0; q; q &= q - 1u, ++k) {
+            const uint32_t j = (uint32_t)__builtin_ctz(q);
+            const unsigned long long r = recs_run + (ex[it] >> 16) + k;
             if (r < max_records) {
-                rec_base[r] = g0 + (uint32_t)__builtin_popcount(bm & ((1u << j) - 1u));
+                rec_base[r] = g0 + (uint32_t)__builtin_popcount(m & ((1u << j) - 1u));
                 if (rec_pos) rec_pos[r] = o + j;
             }
         }
         uint32_t v = 0;
-        if (bm) {
+        if (m) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const uint32_t t = (p.w[g] >> 1) & 0x03030303u;
                 v |= ((t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xffu) << (8 * g);
             }
-            for (uint32_t holes = ~bm & 0xffffu; holes;) {
+            for (uint32_t holes = ~m & 0xffffu; holes;) {
                 const uint32_t j = 31u - (uint32_t)__builtin_clz(holes);
                 holes &= ~(1u << j);
                 const uint32_t low = (1u << (2u * j)) - 1u;
                 v = (v & low) | ((v >> 2) & ~low);
             }
         }
-        uint32_t *stage = s_stage[it & 1u];
-        const unsigned long long G0 = bases_run, G0a = G0 & ~15ull;
-        const uint32_t n_stage = (uint32_t)((G0 - G0a + tot_b + 15ull) / 16ull);
+        const unsigned long long G0a = bases_run & ~15ull;
+        const uint32_t n_stage = (uint32_t)((bases_run - G0a + tot_b + 15ull) / 16ull);  // <= kOpStage - 1
         if (nb) {
-            const uint32_t rel = (uint32_t)(g0 - G0a), d = rel >> 4, bsh = 2u * (rel & 15u);
+            const uint32_t r = (uint32_t)(g0 - G0a), d = r >> 4, bsh = 2u * (r & 15u);
             atomicOr(&stage[d], v << bsh);
             if (bsh && bsh + 2u * nb > 32u) atomicOr(&stage[d + 1], v >> (32u - bsh));
         }
-        __syncthreads();
-        for (uint32_t i = tid; i < n_stage; i += kBlockThreads) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (LDS operations of one wave complete in order)
+        for (uint32_t i = (uint32_t)lane; i < n_stage; i += kWave) {
             const unsigned long long dw = G0a / 16ull + i;
             const uint32_t val = stage[i];
             stage[i] = 0;
             if (dw < out_dwords) {
+                // the first and the last dword may be shared with the neighbouring piece / wave / chunk
                 if (i == 0 || i + 1 == n_stage) {
                     if (val) atomicOr(&out32[dw], val);
                 } else {
@@ -645,12 +694,11 @@ __global__ __launch_bounds__(kBlockThreads) void fasta_onepass_kernel(
                 }
             }
         }
-        ln_run = tot_nl ? 3ull + it * kIterBytes + tot_nl : ln_run;
-        lr_run = tot_rec ? 3ull + it * kIterBytes + tot_rec : lr_run;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         bases_run += tot_b;
         recs_run += tot_r;
     }
-    if (tid == 0 && bid == n_chunks - 1) {
+    if (tid == kBlockThreads - 1 && bid == n_chunks - 1) {  // (the last wave ends where the chunk ends)
         counts[0] = bases_run;
         counts[1] = recs_run;
         if (recs_run <= max_records) rec_base[recs_run] = bases_run;
@@ -660,9 +708,13 @@ __global__ __launch_bounds__(kBlockThreads) void fasta_onepass_kernel(
 }  // namespace
 
 uint64_t fasta_chunks(uint64_t n_bytes) { return (n_bytes + kChunkBytes - 1) / kChunkBytes; }
-// scratch: six arrays of chunks + 1 64-bit words (three-pass kernels; the one-pass kernel uses three of them as
-// its status words)
-uint64_t fasta_scratch_bytes(uint64_t n_bytes) { return 6 * (fasta_chunks(n_bytes) + 1) * sizeof(unsigned long long); }
+static uint64_t fasta_onepass_chunks(uint64_t n_bytes) { return (n_bytes + kOpChunkBytes - 1) / kOpChunkBytes; }
+// scratch: six arrays of chunks + 1 64-bit words (three-pass kernels); the one-pass kernel keeps three status words
+// per 16 KB chunk in the same area
+uint64_t fasta_scratch_bytes(uint64_t n_bytes) {
+    const uint64_t a = 6 * (fasta_chunks(n_bytes) + 1), b = 3 * (fasta_onepass_chunks(n_bytes) + 1);
+    return (a > b ? a : b) * sizeof(unsigned long long);
+}
 
 int launch_fasta_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed, uint64_t packed_capacity_bytes,
                       unsigned long long *d_rec_base, unsigned long long *d_rec_pos, uint64_t max_records,
@@ -677,10 +729,12 @@ int launch_fasta_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed
     const uint64_t clear = packed_capacity_bytes < (n_bytes + 3) / 4 + 8 ? packed_capacity_bytes : (n_bytes + 3) / 4 + 8;
     if (clear && hipMemsetAsync(d_packed, 0, clear, stream) != hipSuccess) return -1;
     if (one_pass) {
-        if (hipMemsetAsync(a, 0, 3 * (chunks + 1) * sizeof(unsigned long long), stream) != hipSuccess) return -1;
-        hipLaunchKernelGGL(fasta_onepass_kernel, dim3((uint32_t)chunks), dim3(kBlockThreads), 0, stream, d_text, n_bytes,
-                           last_nl, last_rec, ctx_nl, reinterpret_cast<uint32_t *>(d_packed), out_dwords, d_rec_base,
-                           d_rec_pos, max_records, d_counts, (uint32_t)chunks, d_error);
+        const uint64_t oc = fasta_onepass_chunks(n_bytes);
+        if (oc >= (1ull << 31)) return -1;
+        if (hipMemsetAsync(a, 0, 3 * (oc + 1) * sizeof(unsigned long long), stream) != hipSuccess) return -1;
+        hipLaunchKernelGGL(fasta_onepass_kernel, dim3((uint32_t)oc), dim3(kBlockThreads), 0, stream, d_text, n_bytes, a,
+                           a + (oc + 1), a + 2 * (oc + 1), reinterpret_cast<uint32_t *>(d_packed), out_dwords, d_rec_base,
+                           d_rec_pos, max_records, d_counts, (uint32_t)oc, d_error);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     hipLaunchKernelGGL(fasta_marks_kernel, dim3((uint32_t)chunks), dim3(kBlockThreads), 0, stream, d_text, n_bytes,
