@@ -247,3 +247,14 @@ def test_device_group_sharded_host(sm, oracle, gpu):
             want = oracle.run(seqs[i], m, 21, 11, canonical=True, base_offset=offs_in[i])
             assert np.array_equal(pos[o[i]:o[i + 1]], want), (devices, i)
         g.close()
+
+
+def test_config1_literal_input_on_the_gpu(sm, gpu):
+    """BASELINE.json configs[0] on its literal 1 000-base ASCII input through the ASCII entry point (mm_run_host_ascii)
+    and the free function the reference's doctest uses (src/lib.rs:92-99, :639): the committed vector."""
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "config1.json")))
+    seq = g["ascii"].encode()
+    assert sm.minimizer_positions(sm.AsciiSeq(seq), 5, 7) == g["positions"]
+    assert sm.minimizers(5, 7).run_once(sm.PackedSeqVec.from_ascii(seq)) == g["positions"]
+    assert gpu.last_path() == sm.PATH_FUSED
