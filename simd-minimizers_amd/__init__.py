@@ -368,13 +368,17 @@ class DeviceGroup:
         except Exception:
             pass
 
-    def run(self, builder: "Builder", packed: np.ndarray, n_bases: int, base_offset: int = 0, capacity=None):
-        """One host PackedSeq over all entries (``mm_run_sharded_host``): (positions, super-k-mer indices or None)."""
+    def run(self, builder: "Builder", packed: np.ndarray, n_bases: int, base_offset: int = 0, capacity=None, out=None):
+        """One host PackedSeq over all entries (``mm_run_sharded_host``): (positions, super-k-mer indices or None).
+        ``out``: a caller-owned uint32 array to receive the positions (e.g. page-locked, ``pinned_array``) instead of
+        a fresh one per call."""
         plan = builder.plan()
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         l = builder.k + builder.w - 1
         cap = max(1, n_bases - l + 1) if capacity is None else capacity
-        pos = np.empty(cap, dtype=np.uint32)
+        if out is not None:
+            cap = min(cap, out.size) if capacity is not None else out.size
+        pos = out if out is not None else np.empty(cap, dtype=np.uint32)
         sk = np.empty(cap, dtype=np.uint32) if builder._sk is not None else None
         cnt = C.c_uint64()
         code = lib().mm_run_sharded_host(plan.h, self.h, packed.ctypes.data_as(C.POINTER(C.c_uint8)), base_offset, n_bases,
