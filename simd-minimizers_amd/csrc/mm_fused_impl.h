@@ -31,6 +31,15 @@
 #ifndef MM_LB_SLEEP_SHORT
 #define MM_LB_SLEEP_SHORT 120
 #endif
+// Poll interval of a tile that waits for its nearest missing predecessor (s_sleep argument, x 64 clocks).  Forward
+// walks keep the longest sleep (MM_LB_SLEEP = 120, mm_common.h: seven workgroups per CU, many pollers - w = 7 runs 3 %
+// slower at 32); canonical walks poll four times as often since round 3: with the status words 64 bytes apart and the
+// wide sequence loads the polls no longer cost the walking waves anything measurable, and a waiting tile notices its
+// predecessor 1-2 us earlier: k=21 w=11 on 3.1 Gbp 1.722 -> 1.681 ms (120 -> 32; 60, 16, 8, 4 and 1 all within 1 % of
+// it), closed syncmers w = 17 -0.6 %, w = 51 -0.5 % (tools/gpu_jit_w.py, profiles/r03_lookback_poll.txt).
+#ifndef MM_LB_SLEEP_CANON
+#define MM_LB_SLEEP_CANON 32
+#endif
 #ifndef MM_STORE_MOD
 #define MM_STORE_MOD "nt"  // cache policy of the copy-out stores (fast path); see MM_STORE_AUX
 #endif
@@ -76,7 +85,11 @@ constexpr uint32_t kListStride = 2u * (kFusedThreads + 2u);
 // kFusedThreads + 4 bytes apart (65 dwords, odd).  Canonical walks are bounded by registers, not LDS,
 // and want longer lanes; reads-mode positions are read-local (up to the read length); super-k-mer
 // entries pack two fields: all of those keep 16 bits.
+#ifndef MM_NO_E8  // (experiment: -DMM_NO_E8 for the whole library = 16-bit lists everywhere, longer forward lanes)
 constexpr bool kEntry8Rule(uint32_t w, bool canon, bool sk) { return !canon && !sk && w <= 13u; }
+#else
+constexpr bool kEntry8Rule(uint32_t, bool, bool) { return false; }
+#endif
 template <int W, bool CANON, bool SK, bool READS>
 constexpr bool kEntry8 = !READS && kEntry8Rule((uint32_t)W, CANON, SK);
 constexpr uint32_t kListStride8 = kFusedThreads + 4u;
@@ -944,6 +957,7 @@ __device__ __forceinline__ void publish_aggregate(unsigned long long *status, ui
 // nearest missing one, consumes what is there (nearest first), and publishes the inclusive prefix
 // when the prefix and the tile's own total are both known.
 // Status words and bounds as in lookback_exclusive (mm_common.h).  Returns the exclusive prefix.
+template <int SLEEP>
 __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long long *status, uint32_t bid,
                                                                   unsigned long long carry_in, uint32_t *error,
                                                                   uint32_t *done, const uint32_t *wave_tot) {
@@ -992,7 +1006,7 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
             if (!have_excl) {
                 unsigned long long s0 = 0;
                 for (uint32_t spins = 0; spins < 64u; ++spins) {
-                    __builtin_amdgcn_s_sleep(MM_LB_SLEEP);
+                    __builtin_amdgcn_s_sleep(SLEEP);
 #ifdef MM_LB_SLEEP2
                     __builtin_amdgcn_s_sleep(MM_LB_SLEEP2);  // experiment: poll even less often than the longest sleep
 #endif
@@ -1569,7 +1583,8 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         const unsigned long long ex =
             redo ? p.redo_list[blockIdx.x].prefix
                  : ((p.debug & 1u) ? (unsigned long long)bid * (NB / 6u)
-                                   : lookback_overlapped(p.out.status, bid, carry, p.out.error, &s_done, s_wave_tot));
+                                   : lookback_overlapped<(CANON ? MM_LB_SLEEP_CANON : MM_LB_SLEEP)>(
+                                         p.out.status, bid, carry, p.out.error, &s_done, s_wave_tot));
 #else
         const unsigned long long carry = s_carry;  // base of chunk 0: every tile of that chunk needs it
         const unsigned long long ex =
