@@ -70,11 +70,14 @@ uint32_t default_cap_limit(uint32_t w, bool canonical, bool e8 = false) {
     // (forward w <= 13: 8-bit list entries, half the LDS per list - a slightly longer lane pays: round 2, 3.1 Gbp,
     // limit 51 -> 60: w = 7 1.629 -> 1.579 ms, w = 10 1.395 -> 1.343, w = 11 1.340 -> 1.318; the lane length is
     // bounded by S + w <= 255 anyway)
-    if (!canonical) return e8 ? 60u : (w <= 20u ? 51u : 38u);
-    if (w <= 16u) return 76u;
-    if (w <= 20u) return 62u;
-    if (w <= 31u) return 51u;  // (round 2, with the short look-ahead: w = 25: 1.737 ms at 51 against 1.778 at 44)
-    if (w <= 37u) return 44u;  // (four workgroups per CU since round 2: w = 33: 1.813 at 44, 1.838 at 51, 2.10 at 76)
+    // Round 3 re-swept the limits after the wide sequence loads (a lane's loads are four times fewer, so longer lanes
+    // cost the cache less; tools/gpu_caplimit.py, profiles/r03_caplimit.txt, 3.1 Gbp, ms at limit 44 / 51 / 62 / 68 /
+    // 76): canonical w = 19: 1.805 / 1.746 / 1.677 / 1.656 / 1.649, w = 25: 1.741 / 1.711 / 1.699 / 1.758 / 1.768,
+    // w = 33: 1.760 / 1.748 / 1.707 / 1.702 / 1.700, w = 11 and w = 51 still best at 76; forward w = 25 (30 / 38 / 44 /
+    // 51 / 62): 1.069 / 1.070 / 1.026 / 1.003 / 1.174, w = 33: 0.976 / 0.973 / 0.965 / 1.168 / 1.234, w = 19 unchanged.
+    if (!canonical) return e8 ? 60u : (w <= 28u ? 51u : 44u);
+    if (w <= 20u) return 76u;
+    if (w <= 31u) return 62u;
     return 76u;
 }
 
