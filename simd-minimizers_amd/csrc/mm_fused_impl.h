@@ -167,6 +167,70 @@ __device__ __forceinline__ uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) {
     return r;
 }
 
+// ---- two-stacks sliding minimum with a SPARSE suffix stack (round 3).
+// After a block of W keys has been walked, ring[j] holds key j.  The block turn keeps suffix minima at every second
+// element only - those with the parity of W - 1: ring[e] = min(key e .. key W-1) - the elements between stay raw
+// keys: one v_min3 per TWO elements.  A window that needs the suffix from a raw element r takes
+// min3(prefix, ring[r], ring[r + 1]), which costs what min(prefix, suffix) did; a window whose suffix starts at a
+// kept element folds its own key in with the third operand instead (the prefix minimum is then brought up to date
+// every second step, again with one v_min3).  Per block and side: (W-3)/2 + ~1.5 (W-1) three-operand minima
+// instead of (W-1) + 1.5 (W-1) - 19 instead of 25 for W = 11.  min is associative and the keys carry their
+// position, so every regrouping returns the same (leftmost / rightmost) element: src/sliding_min.rs:86-212.
+template <int W, bool RIGHT>
+__device__ __forceinline__ void ring_turn(uint32_t (&ring)[W]) {
+#ifdef MM_DENSE_SUFFIX  // (A/B: the rounds-1/2 form, a suffix minimum at every element)
+#pragma unroll
+    for (int e = W - 2; e >= 0; --e) ring[e] = RIGHT ? max(ring[e], ring[e + 1]) : min(ring[e], ring[e + 1]);
+    return;
+#endif
+#pragma unroll
+    for (int e = W - 3; e >= 1; e -= 2)
+        ring[e] = RIGHT ? max3u(ring[e], ring[e + 1], ring[e + 2]) : min3u(ring[e], ring[e + 1], ring[e + 2]);
+}
+// minimum of the whole turned ring (the window that ends with the block; used once per lane)
+template <int W, bool RIGHT>
+__device__ __forceinline__ uint32_t ring_all(const uint32_t (&ring)[W]) {
+#ifdef MM_DENSE_SUFFIX
+    return ring[0];
+#endif
+    if (W == 1) return ring[0];
+    if (W == 2) return RIGHT ? max(ring[0], ring[1]) : min(ring[0], ring[1]);
+    if (W & 1) return RIGHT ? max3u(ring[0], ring[1], ring[2]) : min3u(ring[0], ring[1], ring[2]);  // ring[2] is kept
+    return RIGHT ? max(ring[0], ring[1]) : min(ring[0], ring[1]);                                   // ring[1] is kept
+}
+// step j of a block: key = the new key, pre = prefix minimum (brought up to date on every second step),
+// ring = the turned previous block below j + 1 .. W - 1 and this block's keys below j.  Returns the window minimum.
+// (J is a constant after the caller's unrolling)
+template <int W, bool RIGHT>
+__device__ __forceinline__ uint32_t ring_step(uint32_t (&ring)[W], uint32_t &pre, const uint32_t key, const int J) {
+    auto m2 = [](uint32_t a, uint32_t b) { return RIGHT ? max(a, b) : min(a, b); };
+    auto m3 = [](uint32_t a, uint32_t b, uint32_t c) { return RIGHT ? max3u(a, b, c) : min3u(a, b, c); };
+    const bool kept_next = ((J ^ W) & 1) == 0;  // element J + 1 has the parity of W - 1: a kept suffix
+    const int N1 = (J + 1 < W) ? J + 1 : 0, N2 = (J + 2 < W) ? J + 2 : 0, P1 = (J > 0) ? J - 1 : 0;
+    uint32_t sel;
+#ifdef MM_DENSE_SUFFIX
+    if (J == 0) {
+        pre = key;
+        sel = (W > 1) ? m2(key, ring[N1]) : key;
+    } else if (J & 1) {
+        sel = (J + 1 < W) ? m3(pre, key, ring[N1]) : m2(pre, key);
+    } else {
+        pre = m3(pre, ring[P1], key);
+        sel = (J + 1 < W) ? m2(pre, ring[N1]) : pre;
+    }
+    ring[J] = key;
+    return sel;
+#endif
+    if (kept_next) {  // (never the last step: W - 1 has the other parity)
+        sel = (J == 0) ? m2(key, ring[N1]) : m3(pre, key, ring[N1]);
+    } else {
+        pre = (J == 0) ? key : (J == 1) ? m2(ring[0], key) : m3(pre, ring[P1], key);  // ring[J-1] holds key J-1
+        sel = (J + 1 < W) ? m3(pre, ring[N1], ring[N2]) : pre;                         // J + 1 raw, J + 2 kept
+    }
+    ring[J] = key;
+    return sel;
+}
+
 // gfx950 issues v_bitop3_b32 / v_xor / v_add / shifts at full rate (2 clk per wave64) but
 // v_and_or, v_cndmask, v_cmp, v_bfe, v_alignbit, v_min/v_max at half rate (tools/ubench), so the
 // walk prefers the former.
@@ -475,11 +539,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t.x;
             if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t.y;
         }
-#pragma unroll
-        for (int j = W - 2; j >= 0; --j) {
-            ring_l[j] = min(ring_l[j], ring_l[j + 1]);
-            if (CANON) ring_r[j] = max(ring_r[j], ring_r[j + 1]);
-        }
+        ring_turn<W, false>(ring_l);
+        if (CANON) ring_turn<W, true>(ring_r);
     }
 
     // strand vote: dn = #(T|G among the l bases of the current window) - l/2 - 1, so the window
@@ -504,13 +565,13 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             c += __popc(wd);
         }
         int cnt = (int)c;
-        prev = (cnt > thr) ? ring_l[0] : ring_r[0];
+        prev = (cnt > thr) ? ring_all<W, false>(ring_l) : ring_all<W, true>(ring_r);
         // move to window 0: + base pb + l, - base pb
         cnt += (int)((view(pb + (int32_t)l) >> 1) & 1u);
         cnt -= (int)((view_first(pb) >> 1) & 1u);
         dn = cnt - thr - 1;
     } else {
-        prev = ring_l[0];
+        prev = ring_all<W, false>(ring_l);
     }
     if (ctx.no_prev) prev = 0xffffffffu;  // no predecessor window: the first window always emits
 
@@ -724,32 +785,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             }
 #endif
             const uint32_t kl = and_or3(h, kmask, e);
-            // prefix minimum over the block so far and the window minimum; odd steps fold the
-            // previous key in with one v_min3 (3 ops per 2 steps and side instead of 4)
-            uint32_t sel;
-            if (j == 0) {
-                pl = kl;
-                sel = (W > 1) ? min(kl, ring_l[(W > 1) ? 1 : 0]) : kl;
-            } else if (j & 1) {
-                sel = (j + 1 < W) ? min3u(pl, kl, ring_l[(j + 1 < W) ? j + 1 : 0]) : min(pl, kl);
-            } else {
-                pl = min3u(pl, ring_l[j - 1], kl);  // ring_l[j-1] holds key j-1
-                sel = (j + 1 < W) ? min(pl, ring_l[(j + 1 < W) ? j + 1 : 0]) : pl;
-            }
-            ring_l[j] = kl;
+            // window minimum (sparse-suffix two-stacks, see ring_step)
+            uint32_t sel = ring_step<W, false>(ring_l, pl, kl, j);
             if (CANON && MM_STAGE_GE(4)) {
-                const uint32_t kr = kl ^ kmask;
-                uint32_t selr;
-                if (j == 0) {
-                    pr_ = kr;
-                    selr = (W > 1) ? max(kr, ring_r[(W > 1) ? 1 : 0]) : kr;
-                } else if (j & 1) {
-                    selr = (j + 1 < W) ? max3u(pr_, kr, ring_r[(j + 1 < W) ? j + 1 : 0]) : max(pr_, kr);
-                } else {
-                    pr_ = max3u(pr_, ring_r[j - 1], kr);
-                    selr = (j + 1 < W) ? max(pr_, ring_r[(j + 1 < W) ? j + 1 : 0]) : pr_;
-                }
-                ring_r[j] = kr;
+                const uint32_t selr = ring_step<W, true>(ring_r, pr_, kl ^ kmask, j);
                 sel = select3((uint32_t)(dn >> 31), selr, sel);  // dn < 0: rightmost
             }
             // window i = e - W starts at element i + 1
@@ -925,11 +964,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             steps(BoolTag<false>{});
         }
         if (MM_STAGE_GE(3)) {
-#pragma unroll
-            for (int j = W - 2; j >= 0; --j) {
-                ring_l[j] = min(ring_l[j], ring_l[j + 1]);
-                if (CANON && MM_STAGE_GE(4)) ring_r[j] = max(ring_r[j], ring_r[j + 1]);
-            }
+            ring_turn<W, false>(ring_l);
+            if (CANON && MM_STAGE_GE(4)) ring_turn<W, true>(ring_r);
         }
     }
 #ifdef MM_STAGE

@@ -102,6 +102,15 @@ for piece in pieces:
     for b in piece:
         cls[classify(b.split()[0], b)] += wgt
 cls = collections.Counter({k: round(v, 2) for k, v in cls.items()})
+if os.environ.get("CENSUS_HIST"):  # opcode histogram of the loop (unweighted), half-rate ones marked, + the listing
+    hist = collections.Counter()
+    for b in best:
+        if b.startswith("v_"):
+            hist[(b.split()[0], classify(b.split()[0], b))] += 1
+    for (o, k_), v in sorted(hist.items(), key=lambda t: -t[1]):
+        print(f"  {v:4d}  {'HALF' if k_ == 'valu_half' else 'full'}  {o}", file=sys.stderr)
+    if os.environ["CENSUS_HIST"] == "2":
+        print("\n".join(best), file=sys.stderr)
 meta = {}
 for ln in lines:
     for key in (".vgpr_count:", ".sgpr_count:", ".vgpr_spill_count:"):
