@@ -116,6 +116,7 @@ struct mm_workspace {
     mm::SplitBuffers split;
     bool no_split = false;  // the split path failed once on this workspace: fused kernel from then on
     bool fasta_three_pass = false;  // a look-back of the one-pass FASTA packer timed out: three-pass kernels from then on
+    bool fasta_three_once = false;  // this text has too many short lines for the one-pass packer's tables
     // diagnostics: shader-clock probe on a stream of its own (mm_clock_probe_*)
     hipStream_t probe_stream = nullptr;
     unsigned long long *probe_out = nullptr;
@@ -278,6 +279,14 @@ int judge_run_error(mm_workspace *ws) {
         }
         ws->force_ticket = true;
         return 1;
+    }
+    if (code == 3u) {
+        // the one-pass FASTA packer met a text whose lines are too short for its tables: the three-pass kernels take
+        // over on this workspace; the caller repeats the calls since the last check (as for a look-back time-out)
+        ws->fasta_three_pass = true;
+        g_last_error = "mm_fasta_pack_device_async: lines too short for the one-pass packer; its output is invalid, "
+                       "repeat the call (three-pass kernels from now on)";
+        return MM_ERR_ORDER;
     }
     char buf[96];
     snprintf(buf, sizeof(buf), code == 2u ? "kernel error 2: dynamic LDS does not lie behind the static LDS"
@@ -508,6 +517,14 @@ int mm_workspace_check(mm_workspace_t *ws) {
         ws->no_split = true;
         ws->fasta_three_pass = true;
         g_last_error = "a look-back scan timed out in an asynchronous run: its output is invalid";
+        return MM_ERR_ORDER;
+    }
+    if (code == 3u) {
+        // the one-pass FASTA packer met a text whose lines are too short for its tables: the three-pass kernels take
+        // over on this workspace; the caller repeats the calls since the last check (as for a look-back time-out)
+        ws->fasta_three_pass = true;
+        g_last_error = "mm_fasta_pack_device_async: lines too short for the one-pass packer; its output is invalid, "
+                       "repeat the call (three-pass kernels from now on)";
         return MM_ERR_ORDER;
     }
     char buf[96];
@@ -1554,13 +1571,12 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
     const int r = grow(sp, ws->scratch_bytes, mm::fasta_scratch_bytes(n_bytes), 1);
     ws->scratch = sp;
     if (r) return r;
-    // MM_FASTA_ONEPASS=1: the text is read once (decoupled look-backs between the chunks) instead of three times.
-    // Measured no faster on MI355X (round 3, 1 GiB of text: 1.77 ms against 1.68 ms; 1.15 ms without its look-backs):
-    // a third of it is waiting in two consecutive look-backs, the rest the packer's own instruction work - so the
-    // three passes stay the default.  A look-back time-out of the one-pass kernel sends the
-    // workspace back to the three-pass kernels.
+    // The one-pass kernel over lines (mm_fasta.hip: the text read once, one decoupled look-back between 16 KB chunks)
+    // is the default since its third version (round 3: 0.96 ms for 1 GiB of 60-base lines against 1.66 ms for the
+    // three passes); MM_FASTA_ONEPASS=0 takes the three-pass kernels, which also serve texts the one-pass kernel
+    // gives up on (lines shorter than 16 bytes on average; a look-back time-out).
     const char *env_one = mm::mm_env("MM_FASTA_ONEPASS");
-    const bool one_pass = env_one && env_one[0] == '1' && !ws->fasta_three_pass;
+    const bool one_pass = !(env_one && env_one[0] == '0') && !ws->fasta_three_pass && !ws->fasta_three_once;
     if (one_pass) MM_HIP(hipMemsetAsync(ws->total + 1, 0, sizeof(unsigned long long), ws->stream));
     if (mm::launch_fasta_pack(d_text, n_bytes, d_packed, packed_capacity_bytes & ~3ull,
                               reinterpret_cast<unsigned long long *>(d_rec_base),
@@ -1597,11 +1613,14 @@ int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_b
         MM_HIP(hipMemcpyAsync(ws->h_total + 1, ws->total + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                               ws->stream));
         MM_HIP(hipStreamSynchronize(ws->stream));
-        if (n_bytes == 0 || ws->fasta_three_pass || (uint32_t)ws->h_total[1] == 0) break;
-        // a look-back of the one-pass packer timed out (chunks not dispatched in order): once more, three passes
-        ws->fasta_three_pass = true;
+        if (n_bytes == 0 || ws->fasta_three_pass || ws->fasta_three_once || (uint32_t)ws->h_total[1] == 0) break;
+        // the one-pass packer gave up: a look-back timed out (chunks not dispatched in order: three passes from now
+        // on) or this text's lines are too short for its tables (error 3: three passes for this call)
+        if ((uint32_t)ws->h_total[1] == 3u) ws->fasta_three_once = true;
+        else ws->fasta_three_pass = true;
         if (!ws->async_unchecked) MM_HIP(hipMemsetAsync(ws->total + 2, 0, sizeof(unsigned long long), ws->stream));
     }
+    ws->fasta_three_once = false;
     if (out_counts[0] > (packed_capacity_bytes & ~3ull) * 4 || out_counts[1] > max_records) return MM_ERR_CAPACITY;
     return MM_OK;
 }

@@ -18,6 +18,8 @@
 // text in, so the passes are kept simple rather than fused behind a look-back.
 #include "mm_common.h"
 #include "mm_launch.h"
+#include "mm_env.h"
+#include <stdlib.h>
 
 namespace mm {
 namespace {
@@ -502,213 +504,535 @@ __device__ __forceinline__ uint32_t lookback_context(unsigned long long *status,
     return h | (started << 1);
 }
 
-// One-pass kernel, wave-serial (round 3, second version).  A chunk is 16 KB: every wave owns a contiguous 4 KB of it and
-// walks its four 1 KB pieces (64 lanes x 16 bytes, coalesced) by itself - the line / record context inside a wave comes
-// from a ballot and a shuffle, the offsets from a DPP scan, the packed codes go through a staging area in LDS that
-// belongs to the wave - so the workgroup meets at FOUR barriers per chunk (marks, context, counts, offsets) instead
-// of five per 4 KB.  The first version kept the three-pass kernels' workgroup-wide iterations behind the look-backs
-// and ran 25 % slower than the three passes.
-#ifndef MM_FASTA_OP_ITERS
-#define MM_FASTA_OP_ITERS 4
-#endif
-constexpr uint32_t kOpIters = MM_FASTA_OP_ITERS;                  // 1 KB pieces per wave
-constexpr uint32_t kOpWaveBytes = 16u * kWave * kOpIters;         // 4 KB
-constexpr uint32_t kOpChunkBytes = kOpWaveBytes * kWavesPerBlock;  // 16 KB
-constexpr uint32_t kOpStage = 16u * kWave * 2u / 32u + 2u;        // dwords a 1 KB piece can pack into, + 2
+// One-pass kernel over LINES (round 3, third version; the first two kept the three-pass kernels' per-byte masks behind
+// the look-backs and ran no faster than the three passes: 2.07 and 1.77 ms for 1 GiB against 1.68 ms).
+//
+// FASTA text is long runs of sequence bytes between a few separators, so the work is split by what it is proportional
+// to.  A chunk is 16 KB of text, staged in LDS once:
+//   A1 (per text byte, SWAR, ~0.13 VALU cycles / byte)  candidate separators = bytes below 0x0E ('\n', '\r' and the odd
+//       control character), four adds and logic operations per dword; their positions go to a sorted list in LDS
+//       (a wave owns 4 KB: 64 lanes x 16 bytes x 4 rows; one packed scan of the per-lane counts orders them);
+//   A2 (per SEGMENT = the bytes between two candidates, one thread each)  where it starts and ends, whether it starts
+//       a line ('\n' before it), whether it starts a record ('>' at a line start); the chunk's kind goes to the
+//       context look-back; header state by "latest line start == latest record start"; lengths, output offsets and
+//       the compact table of segments that hold sequence through one packed workgroup scan; the totals to the two
+//       sum look-backs;
+//   B  (per OUTPUT dword, ~0.2 VALU cycles / byte)  lane q packs output dword q of the chunk: the segment that holds
+//       its first base comes from a mark every segment leaves at the first dword boundary it covers (nearest mark
+//       below: one ballot), then 16 text bytes from LDS at any byte offset, 2-bit codes by one multiply per dword,
+//       and on to the next segment while bases are missing (a line end costs a second round, nothing else).  Stores
+//       are whole dwords in order; only the two dwords a chunk shares with its neighbours are OR-ed in.
+// Bytes that are neither '\n' nor '\r' but below 0x0E stay sequence bytes (they end a segment of width zero).  A chunk
+// with more than kLnMaxSeg - 1 candidates (lines shorter than 16 bytes on average) raises error 3 and the host takes
+// the three-pass kernels for that text.
+constexpr uint32_t kLnChunk = 16384;                               // text bytes per chunk = workgroup
+constexpr uint32_t kLnWaveBytes = kLnChunk / kWavesPerBlock;       // 4 KB
+constexpr uint32_t kLnRows = kLnWaveBytes / (16u * kWave);         // 4 rows of 1 KB per wave
+constexpr uint32_t kLnMaxSeg = 1024;                               // segments of a chunk (candidates + 1)
+constexpr uint32_t kLnPad = 16;                                    // bytes in front of the chunk's text in LDS
+constexpr uint32_t kLnMaxQ = kLnChunk / 16u + 2u;                  // output dwords a chunk can touch
+static_assert(kLnRows == 4, "the packed scans below hold four rows");
 
-// latest mark (position + 1, 0 = none) among the lower lanes of the wave / in the whole wave
-__device__ __forceinline__ void wave_prev_mark(uint32_t v, uint32_t &excl, uint32_t &last) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const unsigned long long m = __ballot(v != 0u);
-    const unsigned long long lower = m & ((1ull << lane) - 1ull);
-    const uint32_t from_lower = (uint32_t)__shfl((int)v, lower ? 63 - __builtin_clzll(lower) : 0, kWave);
-    const uint32_t from_top = (uint32_t)__shfl((int)v, m ? 63 - __builtin_clzll(m) : 0, kWave);
-    excl = lower ? from_lower : 0u;
-    last = m ? from_top : 0u;
+struct LnShared {
+    uint32_t text[(kLnPad + kLnChunk + 32u) / 4u];
+    uint32_t tab[kLnMaxSeg + 1];     // segments that hold sequence: output offset in the chunk | text start << 16
+    uint32_t recs[kLnMaxSeg];        // record starts: output offset | text position << 16
+    uint16_t list[kLnMaxSeg];        // candidate positions, ascending
+    uint16_t marks[kLnMaxQ];         // per output dword: 1 + the table entry that holds its first base (0 = none)
+    uint32_t s[2 * kWavesPerBlock];
+    unsigned long long s64[kWavesPerBlock];
+    uint32_t cnt[kWavesPerBlock];
+    uint32_t ctx;
+    uint32_t u_end, v_end;           // sequence bytes | table entries << 16 before the first line start / record start
+    uint32_t edge[kWavesPerBlock];   // the last output dword every wave holds (for its neighbour's funnel shift)
+    unsigned long long off[2];
+};
+
+// ---- the look-back of the one-pass kernel: ONE status word per chunk.
+// What a chunk adds to the running sums depends on the state it is entered in - inside a header line or not, a record
+// started or not - and that state comes from the chunks before it.  So that a chunk can publish BEFORE it knows its
+// state (the point of a decoupled look-back), its aggregate is the function itself: its sequence bytes in three
+// classes - U before its first line start (count if a record has started and the text is not inside a header), V
+// between the first line start and the first record start (count if a record has started), K behind the first record
+// start (always count) - its record starts, and what it does to the state (kind: 0 nothing, 1 ends outside a header
+// line, 2 ends inside one; whether it holds a record start).  The chunk that looks back evaluates the functions of
+// its predecessors from the nearest inclusive word forwards; the states along the way come from three ballots.
+//   aggregate: K 0..14 | V 15..29 | U 30..44 | records 45..55 | kind 56..57 | has record 58 | flag 62..63 (= 1)
+//   inclusive: sequence bytes 0..31 | records 32..59 | inside header 60 | record started 61 | flag (= 2)
+// (texts are below 4 GB, a chunk holds fewer than 1024 segments: 28 bits hold the records.)
+struct LnPrefix {
+    uint32_t h, started;
+    unsigned long long bases, recs;
+};
+constexpr int kLnGroups = 16;  // 64-chunk groups kept in registers while looking for the nearest inclusive word
+#ifndef MM_FASTA_LB_BATCH
+#define MM_FASTA_LB_BATCH 4
+#endif
+constexpr int kLnBatch = MM_FASTA_LB_BATCH;  // groups loaded together
+
+// one thread, as soon as the chunk's classes are counted (chunk 0 publishes its inclusive word straight away)
+__device__ __forceinline__ void ln_publish(unsigned long long *status, uint32_t bid, uint32_t K, uint32_t V, uint32_t U,
+                                           uint32_t nr, uint32_t kind, uint32_t has_rec) {
+    st_status(&status[bid], kFlagAgg | K | ((unsigned long long)V << 15) | ((unsigned long long)U << 30) |
+                                ((unsigned long long)nr << 45) | ((unsigned long long)kind << 56) |
+                                ((unsigned long long)has_rec << 58));
 }
 
-__global__ __launch_bounds__(kBlockThreads) void fasta_onepass_kernel(
-    const uint8_t *__restrict__ text, uint64_t n, unsigned long long *__restrict__ st_ctx,
-    unsigned long long *__restrict__ st_bases, unsigned long long *__restrict__ st_recs, uint32_t *__restrict__ out32,
+__device__ __forceinline__ LnPrefix lookback_lines(unsigned long long *status, uint32_t bid, uint32_t K, uint32_t V, uint32_t U,
+                                                   uint32_t nr, uint32_t kind, uint32_t has_rec, uint32_t *error,
+                                                   const bool no_wait = false) {
+    const int lane = threadIdx.x & (kWave - 1);
+    LnPrefix r;
+    r.h = r.started = 0;
+    r.bases = r.recs = 0;
+    if (bid != 0) {
+        unsigned long long s[kLnGroups];
+#pragma unroll
+        for (int c = 0; c < kLnGroups; ++c) s[c] = kFlagIncl;
+        int gF = -1, F = 0;
+        for (uint32_t tries = 0; gF < 0; ++tries) {
+            if (tries > 64u) {  // (every try spins up to kMaxLookbackSpins per word)
+                flag_error(error, 1u);
+                return r;
+            }
+            // kLnBatch groups' loads in flight together (one memory round trip for 64 * kLnBatch predecessors: the
+            // frontier of finished chunks has to advance ~100 chunks per microsecond to keep up with the packing),
+            // examined nearest first; a word that was still empty is polled when its group's turn comes
+#pragma unroll
+            for (int c0 = 0; c0 < kLnGroups; c0 += kLnBatch) {
+                if (gF >= 0) continue;
+#pragma unroll
+                for (int c = c0; c < c0 + kLnBatch; ++c) {
+                    const long long idx = (long long)bid - 1 - 64ll * c - lane;
+                    s[c] = idx >= 0 ? ld_status(&status[idx]) : kFlagIncl;  // before the text: all zero
+                }
+#pragma unroll
+                for (int c = c0; c < c0 + kLnBatch; ++c) {
+                    if (gF >= 0) continue;
+                    const long long idx = (long long)bid - 1 - 64ll * c - lane;
+                    unsigned long long w = s[c];
+                    if (no_wait && (w >> 62) != 2) w = kFlagIncl | (1ull << 61);  // (timing experiment: one round trip, no polling)
+                    for (uint32_t spins = 0; (w >> 62) == 0; ++spins) {
+                        if (spins > kMaxLookbackSpins) {
+                            flag_error(error, 1u);
+                            w = kFlagIncl;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                        w = ld_status(&status[idx]);
+                    }
+                    s[c] = w;
+                    const unsigned long long incl_mask = __ballot((w >> 62) == 2);
+                    if (incl_mask) {
+                        gF = c;
+                        F = __builtin_ctzll(incl_mask);
+                    }
+                }
+            }
+            if (gF < 0) __builtin_amdgcn_s_sleep(32);  // more than 1024 chunks ahead of every finished one: look again
+        }
+        // from the inclusive word forwards (far to near: group gF .. 0, within a group lane 63 .. 0)
+        uint32_t h = 0, st = 0;
+        unsigned long long sums = 0, mine = 0;  // sequence bytes | records << 32: of the inclusive word / this lane's share
+#pragma unroll
+        for (int c = kLnGroups - 1; c >= 0; --c) {
+            if (c > gF) continue;
+            const unsigned long long w = s[c];
+            unsigned long long part = ~0ull;
+            if (c == gF) {
+                const unsigned long long wi = __shfl(w, F, kWave);
+                h = (uint32_t)(wi >> 60) & 1u;
+                st = (uint32_t)(wi >> 61) & 1u;
+                sums = (wi & 0xffffffffull) | (((wi >> 32) & 0xfffffffull) << 32);
+                part = F ? ((1ull << F) - 1ull) : 0ull;
+            }
+            const uint32_t wk = (uint32_t)(w >> 56) & 3u;
+            const unsigned long long D = __ballot(wk != 0u) & part, Hd = __ballot(wk == 2u) & part,
+                                     Rc = __ballot(((w >> 58) & 1ull) != 0ull) & part;
+            const unsigned long long above = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
+            const unsigned long long da = D & above;
+            const uint32_t h_in = da ? (uint32_t)(Hd >> __builtin_ctzll(da)) & 1u : h;
+            const uint32_t st_in = (st || (Rc & above)) ? 1u : 0u;
+            if ((part >> lane) & 1ull) {
+                const uint32_t k = (uint32_t)w & 0x7fffu, v = (uint32_t)(w >> 15) & 0x7fffu, u = (uint32_t)(w >> 30) & 0x7fffu;
+                mine += (unsigned long long)(k + (st_in ? v + (h_in ? 0u : u) : 0u)) | (((w >> 45) & 0x7ffull) << 32);
+            }
+            if (D) h = (uint32_t)(Hd >> __builtin_ctzll(D)) & 1u;
+            if (Rc) st = 1u;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, kWave);  // (one reduction for all groups)
+        sums += mine;
+        r.h = h;
+        r.started = st;
+        r.bases = sums & 0xffffffffull;
+        r.recs = sums >> 32;
+    }
+    const uint32_t mine = K + (r.started ? V + (r.h ? 0u : U) : 0u);
+    const uint32_t h_out = kind ? (kind == 2u ? 1u : 0u) : r.h, st_out = r.started | has_rec;
+    const unsigned long long rb = r.bases + mine, rr = r.recs + nr;
+    if (rb >= (1ull << 32) || rr >= (1ull << 28)) flag_error(error, 3u);  // (cannot happen below 4 GB of text)
+    if (lane == 0)
+        st_status(&status[bid], kFlagIncl | (rb & 0xffffffffull) | ((rr & 0xfffffffull) << 32) |
+                                    ((unsigned long long)h_out << 60) | ((unsigned long long)st_out << 61));
+    return r;
+}
+
+// exclusive sum over the workgroup of three packed counts (16-bit fields of a 64-bit word)
+__device__ __forceinline__ unsigned long long block_sum_excl64(unsigned long long v, unsigned long long *s,
+                                                               unsigned long long &total) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const unsigned long long o = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += o;
+    }
+    if (lane == kWave - 1) s[wave] = incl;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+        const unsigned long long t = s[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
+
+// 16 text bytes (four dwords, first byte lowest) -> their sixteen 2-bit codes, first base lowest: (c >> 1) & 3 per
+// byte, then one multiply gathers the four fields of a dword in its top byte (the partial products do not overlap)
+__device__ __forceinline__ uint32_t pack16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+    const uint32_t m0 = ((x0 >> 1) & 0x03030303u) * 0x01041040u, m1 = ((x1 >> 1) & 0x03030303u) * 0x01041040u;
+    const uint32_t m2 = ((x2 >> 1) & 0x03030303u) * 0x01041040u, m3 = ((x3 >> 1) & 0x03030303u) * 0x01041040u;
+    return __builtin_amdgcn_perm(m1, m0, 0x0c0c0703u) | __builtin_amdgcn_perm(m3, m2, 0x07030c0cu);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void fasta_lines_kernel(
+    const uint8_t *__restrict__ text, uint64_t n, unsigned long long *__restrict__ st_ctx, uint32_t *__restrict__ out32,
     uint64_t out_dwords, unsigned long long *__restrict__ rec_base, unsigned long long *__restrict__ rec_pos,
-    uint64_t max_records, unsigned long long *__restrict__ counts, uint32_t n_chunks, uint32_t *error) {
-    __shared__ uint32_t s_mark[2][kWavesPerBlock];  // last newline / record start of every wave (position + 1 in the chunk)
-    __shared__ uint32_t s_cnt[2][kWavesPerBlock];   // sequence bytes / record starts of every wave
-    __shared__ uint32_t s_ctx;
-    __shared__ unsigned long long s_off[2];
-    __shared__ uint32_t s_stage[kWavesPerBlock][kOpStage];
+    uint64_t max_records, unsigned long long *__restrict__ counts, uint32_t n_chunks, uint32_t *error, uint32_t debug) {
+    // debug (MM_FASTA_DEBUG, timing experiments with wrong results): 1 no look-backs, 2 stop before B, 4 stop after A1,
+    // 8 stop before A2's scans, 16 the look-back takes whatever its first loads return
+    __shared__ __attribute__((aligned(16))) LnShared sh;
     const uint32_t tid = threadIdx.x, bid = blockIdx.x;
     const int lane = tid & (kWave - 1), wave = tid / kWave;
-    const uint64_t c0 = (uint64_t)bid * kOpChunkBytes;
-    const uint32_t w0 = (uint32_t)wave * kOpWaveBytes;  // first byte of the wave's part, relative to the chunk
-    for (uint32_t i = (uint32_t)lane; i < kOpStage; i += kWave) s_stage[wave][i] = 0;
-    Raw raw[kOpIters];
+    const uint64_t c0 = (uint64_t)bid * kLnChunk;
+    const uint32_t L = n - c0 < kLnChunk ? (uint32_t)(n - c0) : kLnChunk;  // text bytes of this chunk
+    uint8_t *const tx = reinterpret_cast<uint8_t *>(sh.text) + kLnPad;     // tx[p] = byte p of the chunk
+    const uint32_t w0 = (uint32_t)wave * kLnWaveBytes;
+
+    // ---- A1: the text into LDS, candidate separators into the list
+    Raw raw[kLnRows];
 #pragma unroll
-    for (uint32_t it = 0; it < kOpIters; ++it) raw[it] = load_raw(text, n, c0 + w0 + it * (16u * kWave) + 16ull * lane);
-    // ---- the masks of every piece, made once and kept (the three-pass kernels make them in every pass), and the marks
-    // of the wave's part (context-free)
-    Piece pc[kOpIters];
-    uint32_t pls[kOpIters], prs[kOpIters];
-    uint32_t mnl = 0, mrec = 0;
+    for (uint32_t r = 0; r < kLnRows; ++r) raw[r] = load_raw(text, n, c0 + w0 + r * (16u * kWave) + 16ull * lane);
+    if (tid == 0) tx[-1] = c0 ? text[c0 - 1] : (uint8_t)'\n';
+    if (tid < 8) sh.text[(kLnPad + kLnChunk) / 4u + tid] = 0x41414141u;
+    for (uint32_t i = tid; i < kLnMaxQ; i += kBlockThreads) sh.marks[i] = 0;
+    uint32_t cm[kLnRows];  // bit j = byte j of the lane's piece is a candidate
 #pragma unroll
-    for (uint32_t it = 0; it < kOpIters; ++it) {
-        const uint32_t rel = w0 + it * (16u * kWave) + 16u * (uint32_t)lane;
-        pc[it] = make_piece(raw[it], text, n, c0 + rel);
-        starts(pc[it], pls[it], prs[it]);
-        if (pc[it].nl) mnl = rel + top_bit_pos1(pc[it].nl);
-        if (prs[it]) mrec = rel + top_bit_pos1(prs[it]);
-    }
+    for (uint32_t r = 0; r < kLnRows; ++r) {
+        const uint32_t rel = w0 + r * (16u * kWave) + 16u * (uint32_t)lane;
+        uint32_t m = 0;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        mnl = max(mnl, (uint32_t)__shfl_xor((int)mnl, d, kWave));
-        mrec = max(mrec, (uint32_t)__shfl_xor((int)mrec, d, kWave));
-    }
-    if (lane == 0) {
-        s_mark[0][wave] = mnl;
-        s_mark[1][wave] = mrec;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        uint32_t a = 0, b = 0;
-#pragma unroll
-        for (int w = 0; w < kWavesPerBlock; ++w) {
-            a = max(a, s_mark[0][w]);
-            b = max(b, s_mark[1][w]);
-        }
-        const uint32_t kind = (b > a) ? (uint32_t)kCtxHeader : (a ? (uint32_t)kCtxPlain : 0u);
-#ifdef MM_FASTA_NOLB  // timing experiment (wrong results): no look-backs
-        const uint32_t ctx = 2u + (kind & 0u);
-#else
-        const uint32_t ctx = lookback_context(st_ctx, bid, kind, b != 0u, error);
-#endif
-        if (lane == 0) s_ctx = ctx;
-    }
-    __syncthreads();
-    const uint32_t ctx = s_ctx;
-    // context as pseudo-positions (only their order and lr > 0 matter): marks inside the chunk are 3 + position
-    unsigned long long ln_run = (ctx & 2u) ? 1ull : 0ull, lr_run = (ctx & 2u) ? ((ctx & 1u) ? 2ull : 1ull) : 0ull;
-#pragma unroll
-    for (int w = 0; w < kWavesPerBlock; ++w)
-        if (w < wave) {
-            if (s_mark[0][w]) ln_run = 3ull + s_mark[0][w];
-            if (s_mark[1][w]) lr_run = 3ull + s_mark[1][w];
-        }
-    // ---- base masks, counts and offsets inside the wave
-    uint32_t bm[kOpIters], ex[kOpIters], tot[kOpIters];
-    uint32_t wave_b = 0, wave_r = 0;
-#pragma unroll
-    for (uint32_t it = 0; it < kOpIters; ++it) {
-        const uint32_t rel = w0 + it * (16u * kWave) + 16u * (uint32_t)lane;
-        const Piece &p = pc[it];
-        const uint32_t ls = pls[it], rs = prs[it];
-        const uint32_t tnl = p.nl ? rel + top_bit_pos1(p.nl) : 0u, trec = rs ? rel + top_bit_pos1(rs) : 0u;
-        uint32_t xnl, xrec, tnl_w, trec_w;
-        wave_prev_mark(tnl, xnl, tnl_w);
-        wave_prev_mark(trec, xrec, trec_w);
-        const unsigned long long ln = xnl ? 3ull + xnl : ln_run, lr = xrec ? 3ull + xrec : lr_run;
-        bm[it] = base_mask(p, ls, rs, ln, lr);
-        const uint32_t c = (uint32_t)__builtin_popcount(bm[it]) | ((uint32_t)__builtin_popcount(rs) << 16);
-        const uint32_t incl = wave_scan_sum(c);
-        ex[it] = incl - c;
-        tot[it] = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
-        wave_b += tot[it] & 0xffffu;
-        wave_r += tot[it] >> 16;
-        if (tnl_w) ln_run = 3ull + tnl_w;
-        if (trec_w) lr_run = 3ull + trec_w;
-    }
-    if (lane == 0) {
-        s_cnt[0][wave] = wave_b;
-        s_cnt[1][wave] = wave_r;
-    }
-    __syncthreads();
-    if (wave < 2) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int w = 0; w < kWavesPerBlock; ++w) t += s_cnt[wave][w];
-#ifdef MM_FASTA_NOLB
-        const unsigned long long e = wave == 0 ? (unsigned long long)bid * 16000ull + (t & 0u) : 0ull;
-#else
-        const unsigned long long e = lookback_exclusive(wave == 0 ? st_bases : st_recs, bid, t, 0ull, error);
-#endif
-        if (lane == 0) s_off[wave] = e;
-    }
-    __syncthreads();
-    unsigned long long bases_run = s_off[0], recs_run = s_off[1];
-#pragma unroll
-    for (int w = 0; w < kWavesPerBlock; ++w)
-        if (w < wave) {
-            bases_run += s_cnt[0][w];
-            recs_run += s_cnt[1][w];
-        }
-    // ---- pack: the wave's own staging area, no barrier
-    uint32_t *stage = s_stage[wave];
-#pragma unroll
-    for (uint32_t it = 0; it < kOpIters; ++it) {
-        const uint32_t rel = w0 + it * (16u * kWave) + 16u * (uint32_t)lane;
-        const uint64_t o = c0 + rel;
-        const Piece &p = pc[it];
-        const uint32_t rs = prs[it];
-        const uint32_t m = bm[it], nb = (uint32_t)__builtin_popcount(m);
-        const uint32_t tot_b = tot[it] & 0xffffu, tot_r = tot[it] >> 16;
-        const unsigned long long g0 = bases_run + (ex[it] & 0xffffu);
-        for (uint32_t q = rs, k = 0; q; q &= q - 1u, ++k) {
-            const uint32_t j = (uint32_t)__builtin_ctz(q);
-            const unsigned long long r = recs_run + (ex[it] >> 16) + k;
-            if (r < max_records) {
-                rec_base[r] = g0 + (uint32_t)__builtin_popcount(m & ((1u << j) - 1u));
-                if (rec_pos) rec_pos[r] = o + j;
+        for (int g = 0; g < 4; ++g) {
+            uint32_t x = raw[r].w[g];
+            const uint32_t vb = (raw[r].valid >> (4 * g)) & 0xfu;
+            if (vb != 0xfu) {  // behind the end of the text: bytes that are no candidates
+                const uint32_t keep = (vb & 1u ? 0xffu : 0u) | (vb & 2u ? 0xff00u : 0u) | (vb & 4u ? 0xff0000u : 0u) |
+                                      (vb & 8u ? 0xff000000u : 0u);
+                x = (x & keep) | (0x41414141u & ~keep);
+                raw[r].w[g] = x;
             }
+            // bit 7 of a byte of y is set unless the byte is below 0x0E
+            const uint32_t y = ((x & 0x7f7f7f7fu) + 0x72727272u) | x;
+            const uint32_t z = (~y & 0x80808080u) >> 7;
+            m |= (((z * 0x00204081u) >> 21) & 0xfu) << (4 * g);
         }
-        uint32_t v = 0;
-        if (m) {
+        cm[r] = m;
+        *reinterpret_cast<uint4 *>(tx + rel) = make_uint4(raw[r].w[0], raw[r].w[1], raw[r].w[2], raw[r].w[3]);
+    }
+    // candidates before each lane's piece, row by row (two packed scans), and before the wave
+    const uint32_t p01 = (uint32_t)__builtin_popcount(cm[0]) | ((uint32_t)__builtin_popcount(cm[1]) << 16);
+    const uint32_t p23 = (uint32_t)__builtin_popcount(cm[2]) | ((uint32_t)__builtin_popcount(cm[3]) << 16);
+    const uint32_t i01 = wave_scan_sum(p01), i23 = wave_scan_sum(p23);
+    const uint32_t t01 = (uint32_t)__builtin_amdgcn_readlane((int)i01, kWave - 1);
+    const uint32_t t23 = (uint32_t)__builtin_amdgcn_readlane((int)i23, kWave - 1);
+    if (lane == 0) sh.cnt[wave] = (t01 & 0xffffu) + (t01 >> 16) + (t23 & 0xffffu) + (t23 >> 16);
+    __syncthreads();
+    uint32_t E = 0, before = 0;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const uint32_t t = (p.w[g] >> 1) & 0x03030303u;
-                v |= ((t | (t >> 6) | (t >> 12) | (t >> 18)) & 0xffu) << (8 * g);
-            }
-            for (uint32_t holes = ~m & 0xffffu; holes;) {
-                const uint32_t j = 31u - (uint32_t)__builtin_clz(holes);
-                holes &= ~(1u << j);
-                const uint32_t low = (1u << (2u * j)) - 1u;
-                v = (v & low) | ((v >> 2) & ~low);
-            }
+    for (int w = 0; w < kWavesPerBlock; ++w) {
+        if (w < wave) before += sh.cnt[w];
+        E += sh.cnt[w];
+    }
+    if (E > kLnMaxSeg - 1u) {
+        // too many short lines for the tables: the host repeats the text with the three-pass kernels; the successors
+        // must not wait for this chunk
+        if (tid == 0) {
+            flag_error(error, 3u);
+            st_status(&st_ctx[bid], kFlagIncl | (1ull << 61));
         }
-        const unsigned long long G0a = bases_run & ~15ull;
-        const uint32_t n_stage = (uint32_t)((bases_run - G0a + tot_b + 15ull) / 16ull);  // <= kOpStage - 1
-        if (nb) {
-            const uint32_t r = (uint32_t)(g0 - G0a), d = r >> 4, bsh = 2u * (r & 15u);
-            atomicOr(&stage[d], v << bsh);
-            if (bsh && bsh + 2u * nb > 32u) atomicOr(&stage[d + 1], v >> (32u - bsh));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (LDS operations of one wave complete in order)
-        for (uint32_t i = (uint32_t)lane; i < n_stage; i += kWave) {
-            const unsigned long long dw = G0a / 16ull + i;
-            const uint32_t val = stage[i];
-            stage[i] = 0;
-            if (dw < out_dwords) {
-                // the first and the last dword may be shared with the neighbouring piece / wave / chunk
-                if (i == 0 || i + 1 == n_stage) {
-                    if (val) atomicOr(&out32[dw], val);
-                } else {
-                    out32[dw] = val;
+        return;
+    }
+    {
+        const uint32_t e01 = i01 - p01, e23 = i23 - p23;
+        const uint32_t row_base[kLnRows] = {before, before + (t01 & 0xffffu), before + (t01 & 0xffffu) + (t01 >> 16),
+                                            before + (t01 & 0xffffu) + (t01 >> 16) + (t23 & 0xffffu)};
+        const uint32_t lane_ex[kLnRows] = {e01 & 0xffffu, e01 >> 16, e23 & 0xffffu, e23 >> 16};
+#pragma unroll
+        for (uint32_t r = 0; r < kLnRows; ++r) {
+            const uint32_t rel = w0 + r * (16u * kWave) + 16u * (uint32_t)lane;
+            uint32_t idx = row_base[r] + lane_ex[r], m = cm[r];
+            while (__ballot(m != 0u)) {
+                if (m) {
+                    sh.list[idx] = (uint16_t)(rel + (uint32_t)__builtin_ctz(m));
+                    ++idx;
+                    m &= m - 1u;
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        bases_run += tot_b;
-        recs_run += tot_r;
     }
-    if (tid == kBlockThreads - 1 && bid == n_chunks - 1) {  // (the last wave ends where the chunk ends)
-        counts[0] = bases_run;
-        counts[1] = recs_run;
-        if (recs_run <= max_records) rec_base[recs_run] = bases_run;
+    __syncthreads();
+    if (debug & 4u) return;
+
+    // ---- A2: one thread per segment.  Segment l lies between candidates l - 1 and l (the chunk's ends for the first
+    // and the last one); a candidate that is '\n' or '\r' belongs to neither side, any other one to the segment behind it.
+    // Everything here is independent of the chunks before: the table holds every segment that may hold sequence, in
+    // order, and the classes U / V / K are runs of it (see lookback_lines), so the look-back's answer only cuts the
+    // front off.
+    const uint32_t nseg = E + 1u, rounds = (nseg + kBlockThreads - 1u) / kBlockThreads;  // <= 4
+    uint32_t ln_run = 0, lr_run = 0;  // latest line start / record start so far, as 1 + segment index (0 = none)
+    unsigned long long run = 0;       // sequence bytes | table entries << 16 | record starts << 32 so far
+    for (uint32_t rd = 0; rd < rounds; ++rd) {
+        const uint32_t l = rd * kBlockThreads + tid;
+        uint32_t start = 0, end = 0, a = 0, b = 0;
+        if (l < nseg) {
+            uint32_t prev = tx[-1];  // the byte in front of the segment's first byte
+            if (l > 0) {
+                const uint32_t pp = sh.list[l - 1];
+                prev = tx[pp];
+                const bool sep = prev == (uint32_t)'\n' || prev == (uint32_t)'\r';
+                start = pp + (sep ? 1u : 0u);
+            }
+            end = l < E ? (uint32_t)sh.list[l] : L;
+            if (prev == (uint32_t)'\n') {  // a line starts here
+                a = l + 1u;
+                if (start < L && tx[start] == (uint8_t)'>') b = l + 1u;
+            }
+        }
+        uint32_t xa, xb, ta, tb;
+        block_prev_marks(a, b, sh.s, xa, xb, ta, tb);
+        const uint32_t ea = xa ? xa : ln_run, eb = xb ? xb : lr_run;  // latest marks before this segment
+        const uint32_t la = a ? a : ea, lb = b ? b : eb;              // ... up to and including it
+        const bool valid = l < nseg;
+        const bool is_rec = valid && b != 0u;
+        const bool cand = valid && end > start && !(lb != 0u && lb == la);  // not inside a header of this chunk
+        const unsigned long long v = (cand ? (unsigned long long)(end - start) | (1ull << 16) : 0ull) | (is_rec ? (1ull << 32) : 0ull);
+        unsigned long long tot;
+        const unsigned long long ex = run + block_sum_excl64(v, sh.s64, tot);
+        const uint32_t o = (uint32_t)(ex & 0xffffu);
+        if (cand) sh.tab[(uint32_t)(ex >> 16) & 0xffffu] = o | (start << 16);
+        if (is_rec) sh.recs[(uint32_t)(ex >> 32) & 0xffffu] = o | (start << 16);
+        if (a && !ea) sh.u_end = (uint32_t)ex;  // the chunk's first line start: everything before it is class U
+        if (b && !eb) sh.v_end = (uint32_t)ex;  // the first record start: U and V end here
+        run += tot;
+        ln_run = ta ? ta : ln_run;
+        lr_run = tb ? tb : lr_run;
+    }
+    const uint32_t all_b = (uint32_t)(run & 0xffffu), all_t = (uint32_t)(run >> 16) & 0xffffu, nr = (uint32_t)(run >> 32) & 0xffffu;
+    if (tid == 0) {
+        sh.tab[all_t] = all_b;  // sentinel: where the last segment ends
+        if (!ln_run) sh.u_end = (uint32_t)run;
+        if (!lr_run) sh.v_end = (uint32_t)run;
+    }
+    __syncthreads();
+    if (debug & 8u) return;
+    const uint32_t u_b = sh.u_end & 0xffffu, u_t = sh.u_end >> 16, uv_b = sh.v_end & 0xffffu, uv_t = sh.v_end >> 16;
+    const uint32_t kind = (lr_run && lr_run == ln_run) ? 2u : (ln_run ? 1u : 0u);
+    if (tid == 0 && bid != 0 && !(debug & 1u))
+        ln_publish(st_ctx, bid, all_b - uv_b, uv_b - u_b, u_b, nr, kind, lr_run != 0u);  // the successors can go on
+
+    // ---- B: one lane per output dword; a wave takes a contiguous run of 64-dword rows and keeps its dwords in
+    // registers.  The layout depends on what the look-back returns - the bit the chunk's first base lands on
+    // (r0 = bases before the chunk mod 16) and whether classes U / V count - so B runs BEFORE the look-back on the
+    // common answer (nothing dropped; r0 = 0, put right by one funnel shift between neighbouring lanes when the
+    // stores go out) and is repeated the slow way when the answer differs: the chunk's predecessors get the time of B
+    // to publish, instead of the chunk waiting for them with nothing to do.
+    constexpr int kMaxRows = (int)((kLnMaxQ + kWave - 1) / kWave + kWavesPerBlock - 1) / kWavesPerBlock;  // 5
+    uint32_t acc[kMaxRows];
+    uint32_t row0 = 0, row1 = 0;
+    // marks: a segment signs the first dword boundary it covers (dword q starts at chunk base max(0, 16 q - r))
+    auto make_marks = [&](const uint32_t *tab, uint32_t T, uint32_t drop_b, uint32_t r) {
+        for (uint32_t t = tid; t < T; t += kBlockThreads) {
+            const uint32_t o = (tab[t] & 0xffffu) - drop_b, on = (tab[t + 1] & 0xffffu) - drop_b;
+            const uint32_t q = o ? (o + r + 15u) >> 4 : 0u;
+            const uint32_t bq = q ? 16u * q - r : 0u;
+            if (bq < on) sh.marks[q] = (uint16_t)(t + 1u);
+        }
+    };
+    // dwords [0, nq) of the layout with the first base at bit 2 r of dword 0
+    auto gather = [&](const uint32_t *tab, uint32_t drop_b, uint32_t nb, uint32_t r, uint32_t nq) {
+        const uint32_t qrows = (nq + kWave - 1u) / kWave, per_wave = (qrows + kWavesPerBlock - 1u) / kWavesPerBlock;
+        row0 = (uint32_t)wave * per_wave;
+        row1 = row0 + per_wave < qrows ? row0 + per_wave : qrows;
+        if (row0 >= row1) {
+            row0 = row1 = 0;
+            return;
+        }
+        uint32_t carry = 1;  // latest mark below the wave's first dword
+        if (row0 > 0) {
+            for (int base = (int)(row0 * kWave) - 1;; base -= kWave) {
+                const int idx = base - lane;
+                const uint32_t v = idx >= 0 ? (uint32_t)sh.marks[idx] : 1u;  // (dword 0 always carries a mark)
+                const unsigned long long m = __ballot(v != 0u);
+                if (m) {
+                    carry = (uint32_t)__shfl((int)v, __builtin_ctzll(m), kWave);
+                    break;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kMaxRows; ++i) {
+            acc[i] = 0;
+            const uint32_t row = row0 + (uint32_t)i;
+            if (row >= row1) continue;  // (uniform)
+            const uint32_t q = row * kWave + (uint32_t)lane;
+            const uint32_t mk = sh.marks[q < kLnMaxQ ? q : 0u];
+            uint32_t b = q ? 16u * q - r : 0u;  // first base of the dword, counted from the chunk's first base
+            const bool live = q < nq && b < nb;
+            const uint32_t mv = live ? mk : 0u;
+            const unsigned long long m = __ballot(mv != 0u);
+            const unsigned long long le = m & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+            const uint32_t from = (uint32_t)__shfl((int)mv, le ? 63 - __builtin_clzll(le) : 0, kWave);
+            uint32_t t = (le ? from : carry) - 1u;
+            if (m) carry = (uint32_t)__shfl((int)mv, 63 - __builtin_clzll(m), kWave);
+            const uint32_t pd = (b + r) & 15u;
+            uint32_t need = 0;
+            if (live) need = (16u - pd) < (nb - b) ? (16u - pd) : (nb - b);
+            uint32_t sft = 2u * pd, a32 = 0;
+            while (__ballot(need != 0u)) {
+                if (need) {
+                    const uint32_t e = tab[t], en = tab[t + 1];
+                    const uint32_t o = (e & 0xffffu) - drop_b, on = (en & 0xffffu) - drop_b;
+                    const uint32_t take = need < on - b ? need : on - b;
+                    const uint32_t addr = kLnPad + (e >> 16) + (b - o);
+                    const uint32_t a4 = addr >> 2, bs = (addr & 3u) * 8u;
+                    const uint32_t d0 = sh.text[a4], d1 = sh.text[a4 + 1], d2 = sh.text[a4 + 2], d3 = sh.text[a4 + 3],
+                                   d4 = sh.text[a4 + 4];
+                    uint32_t v = pack16(__builtin_amdgcn_alignbit(d1, d0, bs), __builtin_amdgcn_alignbit(d2, d1, bs),
+                                        __builtin_amdgcn_alignbit(d3, d2, bs), __builtin_amdgcn_alignbit(d4, d3, bs));
+                    if (take < 16u) v &= (1u << (2u * take)) - 1u;
+                    a32 |= v << sft;
+                    sft += 2u * take;
+                    b += take;
+                    need -= take;
+                    ++t;
+                }
+            }
+            acc[i] = a32;
+        }
+    };
+    const uint32_t nq_spec = all_b ? ((all_b + 15u) >> 4) + 1u : 0u;  // (one more: the shift spills into it)
+    if (!(debug & 2u)) {
+        make_marks(sh.tab, all_t, 0u, 0u);
+        __syncthreads();
+        gather(sh.tab, 0u, all_b, 0u, nq_spec);
+        if (lane == kWave - 1 && row1 > row0) {
+            uint32_t last = 0;
+#pragma unroll
+            for (int i = 0; i < kMaxRows; ++i)
+                if (row0 + (uint32_t)i + 1u == row1) last = acc[i];
+            sh.edge[wave] = last;
+        }
+    }
+    if (wave == 0) {
+        LnPrefix pf;
+        if (debug & 1u) {  // timing experiment (wrong results): no look-back
+            pf.h = 0;
+            pf.started = 1;
+            pf.bases = (unsigned long long)bid * 16000ull;
+            pf.recs = 0;
+        } else {
+            pf = lookback_lines(st_ctx, bid, all_b - uv_b, uv_b - u_b, u_b, nr, kind, lr_run != 0u, error, (debug & 16u) != 0u);
+            if (debug & 16u) {
+                pf.h = 0;
+                pf.started = 1;
+                pf.bases = (unsigned long long)bid * 16000ull;
+                pf.recs = 0;
+            }
+        }
+        if (lane == 0) {
+            sh.ctx = pf.h | (pf.started << 1);
+            sh.off[0] = pf.bases;
+            sh.off[1] = pf.recs;
+        }
+    }
+    __syncthreads();
+    // the look-back's answer: which classes count.  Dropped segments are a run at the front of the table.
+    const uint32_t h_in = sh.ctx & 1u, started_in = (sh.ctx >> 1) & 1u;
+    const uint32_t drop_b = started_in ? (h_in ? u_b : 0u) : uv_b, drop_t = started_in ? (h_in ? u_t : 0u) : uv_t;
+    const uint32_t nb = all_b - drop_b, T = all_t - drop_t;
+    const unsigned long long G0 = sh.off[0], R0 = sh.off[1];
+    const uint32_t r0 = (uint32_t)(G0 & 15ull);
+    const uint32_t nq = nb ? (r0 + nb + 15u) >> 4 : 0u;  // output dwords this chunk writes to
+    // record table: a record's bases start at the output offset reached at its header
+    for (uint32_t i = tid; i < nr; i += kBlockThreads) {
+        const unsigned long long r = R0 + i;
+        if (r < max_records) {
+            rec_base[r] = G0 + ((sh.recs[i] & 0xffffu) - drop_b);
+            if (rec_pos) rec_pos[r] = c0 + (sh.recs[i] >> 16);
+        }
+    }
+    if (tid == 0 && bid == n_chunks - 1) {
+        counts[0] = G0 + nb;
+        counts[1] = R0 + nr;
+        if (R0 + nr <= max_records) rec_base[R0 + nr] = G0 + nb;
+    }
+    if (debug & 2u) return;
+    uint32_t shift = 2u * r0;  // what the dwords in registers still have to move up by
+    if (drop_b != 0u) {        // (uniform) the other answer: once more, with the layout as it is
+        for (uint32_t i = tid; i < kLnMaxQ; i += kBlockThreads) sh.marks[i] = 0;
+        __syncthreads();
+        make_marks(sh.tab + drop_t, T, drop_b, r0);
+        __syncthreads();
+        gather(sh.tab + drop_t, drop_b, nb, r0, nq);
+        shift = 0;
+    }
+    // ---- stores: whole dwords in order; the two dwords shared with the neighbouring chunks are OR-ed in
+    const unsigned long long D0 = G0 >> 4;
+    const uint32_t last_partial = (r0 + nb) & 15u;
+#pragma unroll
+    for (int i = 0; i < kMaxRows; ++i) {
+        const uint32_t row = row0 + (uint32_t)i;
+        if (row >= row1) continue;
+        const uint32_t q = row * kWave + (uint32_t)lane;
+        uint32_t v = acc[i];
+        if (shift) {
+            uint32_t below = (uint32_t)__shfl_up((int)v, 1, kWave);
+            const uint32_t edge = i > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)acc[i > 0 ? i - 1 : 0], kWave - 1)
+                                        : (row0 > 0 ? sh.edge[wave > 0 ? wave - 1 : 0] : 0u);
+            if (lane == 0) below = edge;
+            v = (v << shift) | (below >> (32u - shift));
+        }
+        const unsigned long long dw = D0 + q;
+        if (q < nq && dw < out_dwords) {
+            const bool partial = (q == 0 && r0 != 0u) || (q == nq - 1u && last_partial != 0u);
+            if (partial) {
+                if (v) atomicOr(&out32[dw], v);
+            } else {
+                out32[dw] = v;
+            }
+        }
     }
 }
 
 }  // namespace
 
 uint64_t fasta_chunks(uint64_t n_bytes) { return (n_bytes + kChunkBytes - 1) / kChunkBytes; }
-static uint64_t fasta_onepass_chunks(uint64_t n_bytes) { return (n_bytes + kOpChunkBytes - 1) / kOpChunkBytes; }
+static uint64_t fasta_onepass_chunks(uint64_t n_bytes) { return (n_bytes + kLnChunk - 1) / kLnChunk; }
 // scratch: six arrays of chunks + 1 64-bit words (three-pass kernels); the one-pass kernel keeps three status words
 // per 16 KB chunk in the same area
 uint64_t fasta_scratch_bytes(uint64_t n_bytes) {
@@ -731,10 +1055,12 @@ int launch_fasta_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed
     if (one_pass) {
         const uint64_t oc = fasta_onepass_chunks(n_bytes);
         if (oc >= (1ull << 31)) return -1;
-        if (hipMemsetAsync(a, 0, 3 * (oc + 1) * sizeof(unsigned long long), stream) != hipSuccess) return -1;
-        hipLaunchKernelGGL(fasta_onepass_kernel, dim3((uint32_t)oc), dim3(kBlockThreads), 0, stream, d_text, n_bytes, a,
-                           a + (oc + 1), a + 2 * (oc + 1), reinterpret_cast<uint32_t *>(d_packed), out_dwords, d_rec_base,
-                           d_rec_pos, max_records, d_counts, (uint32_t)oc, d_error);
+        const char *de = mm_env("MM_FASTA_DEBUG");
+        const uint32_t dbg = de ? (uint32_t)atoi(de) : 0u;
+        if (hipMemsetAsync(a, 0, (oc + 1) * sizeof(unsigned long long), stream) != hipSuccess) return -1;
+        hipLaunchKernelGGL(fasta_lines_kernel, dim3((uint32_t)oc), dim3(kBlockThreads), 0, stream, d_text, n_bytes, a,
+                           reinterpret_cast<uint32_t *>(d_packed), out_dwords, d_rec_base,
+                           d_rec_pos, max_records, d_counts, (uint32_t)oc, d_error, dbg);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     hipLaunchKernelGGL(fasta_marks_kernel, dim3((uint32_t)chunks), dim3(kBlockThreads), 0, stream, d_text, n_bytes,

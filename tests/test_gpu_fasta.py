@@ -10,8 +10,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True, params=["three-pass", "one-pass"])
 def packer_flavour(request, monkeypatch):
-    """Every test runs with the default three-pass kernels and with the one-pass kernel (MM_FASTA_ONEPASS=1: the
-    text read once, decoupled look-backs between the chunks; measured slower, kept as an A/B - DESIGN.md 4.3a)."""
+    """Every test runs with the one-pass kernel over lines (the default: the text read once, one decoupled look-back
+    between 16 KB chunks) and with the three-pass kernels (MM_FASTA_ONEPASS=0; also the fallback for texts whose lines
+    are shorter than 16 bytes on average - DESIGN.md 4.3a)."""
     monkeypatch.setenv("MM_FASTA_ONEPASS", "1" if request.param == "one-pass" else "0")
 
 
@@ -50,6 +51,30 @@ def test_fasta_known_cases(sm, oracle, gpu):
         b">x\n" + b"\n".join(b"ACGTTGCA"[: 1 + i % 8] for i in range(9000)) + b"\n>y\nGATTACA\n",
     ]:
         check(sm, oracle, text)
+
+
+def test_fasta_control_characters(sm, oracle, gpu):
+    """Bytes below 0x0E that are neither '\\n' nor '\\r' (TAB, NUL, VT ...) are candidates for the one-pass packer's
+    separator list but stay what they are for the reader: header text or sequence bytes."""
+    rng = np.random.default_rng(99)
+    for text in [
+        b">a\tb\x00c\nAC\tGT\x0bAC\n\x0cGG\n>b\n\t\n",
+        b">x\n" + b"".join(bytes([int(c)]) for c in rng.choice(list(b"ACGT\t\x00\x01\x0b\x0c\x0d\n"), size=40000)),
+        b"\t\n>r\x0d\x0d\nA\x0dC\x0d\x0aG\n",
+        b">x\n" + (b"ACGT" * 300 + b"\x0b") * 40 + b"\n",
+    ]:
+        check(sm, oracle, text)
+
+
+def test_fasta_short_reads(sm, oracle, gpu):
+    """A reads file: every record one header line and one sequence line (two separators per ~200 bytes)."""
+    rng = np.random.default_rng(5)
+    parts = []
+    for i in range(6000):
+        m = int(rng.integers(30, 160))
+        parts.append(b">read%d len=%d\n" % (i, m) + rng.choice(list(b"ACGT"), size=m).astype(np.uint8).tobytes() + b"\n")
+    got = check(sm, oracle, b"".join(parts))
+    assert len(got) == 6000
 
 
 def random_fasta(rng, n_target):
