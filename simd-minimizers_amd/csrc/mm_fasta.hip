@@ -523,12 +523,17 @@ __device__ __forceinline__ uint32_t lookback_context(unsigned long long *status,
 //       and on to the next segment while bases are missing (a line end costs a second round, nothing else).  Stores
 //       are whole dwords in order; only the two dwords a chunk shares with its neighbours are OR-ed in.
 // Bytes that are neither '\n' nor '\r' but below 0x0E stay sequence bytes (they end a segment of width zero).  A chunk
-// with more than kLnMaxSeg - 1 candidates (lines shorter than 16 bytes on average) raises error 3 and the host takes
+// with more than kLnMaxSeg - 1 candidates (lines shorter than 16 bytes on average) or more than kLnMaxRec record starts
+// raises error 3 and the host takes
 // the three-pass kernels for that text.
 constexpr uint32_t kLnChunk = 16384;                               // text bytes per chunk = workgroup
 constexpr uint32_t kLnWaveBytes = kLnChunk / kWavesPerBlock;       // 4 KB
 constexpr uint32_t kLnRows = kLnWaveBytes / (16u * kWave);         // 4 rows of 1 KB per wave
-constexpr uint32_t kLnMaxSeg = 1024;                               // segments of a chunk (candidates + 1)
+#ifndef MM_FASTA_MAXSEG
+#define MM_FASTA_MAXSEG 1024
+#endif
+constexpr uint32_t kLnMaxSeg = MM_FASTA_MAXSEG;                               // segments of a chunk (candidates + 1)
+constexpr uint32_t kLnMaxRec = 512;                                // record starts of a chunk
 constexpr uint32_t kLnPad = 16;                                    // bytes in front of the chunk's text in LDS
 constexpr uint32_t kLnMaxQ = kLnChunk / 16u + 2u;                  // output dwords a chunk can touch
 static_assert(kLnRows == 4, "the packed scans below hold four rows");
@@ -536,7 +541,7 @@ static_assert(kLnRows == 4, "the packed scans below hold four rows");
 struct LnShared {
     uint32_t text[(kLnPad + kLnChunk + 32u) / 4u];
     uint32_t tab[kLnMaxSeg + 1];     // segments that hold sequence: output offset in the chunk | text start << 16
-    uint32_t recs[kLnMaxSeg];        // record starts: output offset | text position << 16
+    uint32_t recs[kLnMaxRec];        // record starts: output offset | text position << 16
     uint16_t list[kLnMaxSeg];        // candidate positions, ascending
     uint16_t marks[kLnMaxQ];         // per output dword: 1 + the table entry that holds its first base (0 = none)
     uint32_t s[2 * kWavesPerBlock];
@@ -710,7 +715,10 @@ __device__ __forceinline__ uint32_t pack16(uint32_t x0, uint32_t x1, uint32_t x2
     return __builtin_amdgcn_perm(m1, m0, 0x0c0c0703u) | __builtin_amdgcn_perm(m3, m2, 0x07030c0cu);
 }
 
-__global__ __launch_bounds__(kBlockThreads) void fasta_lines_kernel(
+#ifndef MM_FASTA_WAVES
+#define MM_FASTA_WAVES 6  // 85 VGPRs and 26.8 KB of LDS: six workgroups per CU (the kernel is bound by latencies)
+#endif
+__global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_kernel(
     const uint8_t *__restrict__ text, uint64_t n, unsigned long long *__restrict__ st_ctx, uint32_t *__restrict__ out32,
     uint64_t out_dwords, unsigned long long *__restrict__ rec_base, unsigned long long *__restrict__ rec_pos,
     uint64_t max_records, unsigned long long *__restrict__ counts, uint32_t n_chunks, uint32_t *error, uint32_t debug) {
@@ -835,7 +843,7 @@ __global__ __launch_bounds__(kBlockThreads) void fasta_lines_kernel(
         const unsigned long long ex = run + block_sum_excl64(v, sh.s64, tot);
         const uint32_t o = (uint32_t)(ex & 0xffffu);
         if (cand) sh.tab[(uint32_t)(ex >> 16) & 0xffffu] = o | (start << 16);
-        if (is_rec) sh.recs[(uint32_t)(ex >> 32) & 0xffffu] = o | (start << 16);
+        if (is_rec && ((uint32_t)(ex >> 32) & 0xffffu) < kLnMaxRec) sh.recs[(uint32_t)(ex >> 32) & 0xffffu] = o | (start << 16);
         if (a && !ea) sh.u_end = (uint32_t)ex;  // the chunk's first line start: everything before it is class U
         if (b && !eb) sh.v_end = (uint32_t)ex;  // the first record start: U and V end here
         run += tot;
@@ -843,6 +851,13 @@ __global__ __launch_bounds__(kBlockThreads) void fasta_lines_kernel(
         lr_run = tb ? tb : lr_run;
     }
     const uint32_t all_b = (uint32_t)(run & 0xffffu), all_t = (uint32_t)(run >> 16) & 0xffffu, nr = (uint32_t)(run >> 32) & 0xffffu;
+    if (nr > kLnMaxRec) {  // (uniform) more records than the table holds: as for too many segments
+        if (tid == 0) {
+            flag_error(error, 3u);
+            st_status(&st_ctx[bid], kFlagIncl | (1ull << 61));
+        }
+        return;
+    }
     if (tid == 0) {
         sh.tab[all_t] = all_b;  // sentinel: where the last segment ends
         if (!ln_run) sh.u_end = (uint32_t)run;

@@ -49,6 +49,8 @@ def test_fasta_known_cases(sm, oracle, gpu):
         b">x\n" + b"ACGT" * 5000,                   # one long line
         b">" + b"h" * 100000 + b"\nACGT\n",         # a header longer than three chunks
         b">x\n" + b"\n".join(b"ACGTTGCA"[: 1 + i % 8] for i in range(9000)) + b"\n>y\nGATTACA\n",
+        b">abcdefghijklmnopqrst\n" * 3000 + b"ACGT\n",   # more record starts in a chunk than the one-pass table holds
+        b">r\n" + (b"ACGTACGTACGTACGTACGTACGTACGTAC\r\n" * 4000),  # CRLF, 30-base lines: ~1000 separators per chunk
     ]:
         check(sm, oracle, text)
 
