@@ -715,11 +715,18 @@ __device__ __forceinline__ uint32_t pack16(uint32_t x0, uint32_t x1, uint32_t x2
     return __builtin_amdgcn_perm(m1, m0, 0x0c0c0703u) | __builtin_amdgcn_perm(m3, m2, 0x07030c0cu);
 }
 
+// (Tried, round 3: the same look-back over TWO levels - super-chunks of 16 chunks whose last chunk composes their
+// functions into one level-2 word, every chunk looking back over 64 super-chunks and its own super-chunk's chunks in
+// one round trip - so that the front of finished chunks is not held to one 256-chunk window per status round trip.
+// 1.52 ms against 0.89 ms: the level-2 words of the super-chunks in flight are published a packing phase and a round
+// trip after their chunks' own words, and every chunk of the following super-chunks waits for them.  What bounds the
+// one-level form is DESIGN.md 4.3a.)
 #ifndef MM_FASTA_WAVES
 #define MM_FASTA_WAVES 6  // 85 VGPRs and 26.8 KB of LDS: six workgroups per CU (the kernel is bound by latencies)
 #endif
 __global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_kernel(
-    const uint8_t *__restrict__ text, uint64_t n, unsigned long long *__restrict__ st_ctx, uint32_t *__restrict__ out32,
+    const uint8_t *__restrict__ text, uint64_t n, unsigned long long *__restrict__ st_ctx,
+    uint32_t *__restrict__ out32,
     uint64_t out_dwords, unsigned long long *__restrict__ rec_base, unsigned long long *__restrict__ rec_pos,
     uint64_t max_records, unsigned long long *__restrict__ counts, uint32_t n_chunks, uint32_t *error, uint32_t debug) {
     // debug (MM_FASTA_DEBUG, timing experiments with wrong results): 1 no look-backs, 2 stop before B, 4 stop after A1,
@@ -731,6 +738,12 @@ __global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_ker
     const uint32_t L = n - c0 < kLnChunk ? (uint32_t)(n - c0) : kLnChunk;  // text bytes of this chunk
     uint8_t *const tx = reinterpret_cast<uint8_t *>(sh.text) + kLnPad;     // tx[p] = byte p of the chunk
     const uint32_t w0 = (uint32_t)wave * kLnWaveBytes;
+    // A chunk that cannot go on (its text does not fit the tables) raises error 3 - the host repeats the text with the
+    // three-pass kernels - and still plays its part in the look-back, with nothing to add: its successors must not wait.
+    auto give_up = [&]() {
+        if (tid == 0) flag_error(error, 3u);
+        if (tid == 0) st_status(&st_ctx[bid], kFlagIncl | (1ull << 61));
+    };
 
     // ---- A1: the text into LDS, candidate separators into the list
     Raw raw[kLnRows];
@@ -779,10 +792,7 @@ __global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_ker
     if (E > kLnMaxSeg - 1u) {
         // too many short lines for the tables: the host repeats the text with the three-pass kernels; the successors
         // must not wait for this chunk
-        if (tid == 0) {
-            flag_error(error, 3u);
-            st_status(&st_ctx[bid], kFlagIncl | (1ull << 61));
-        }
+        give_up();
         return;
     }
     {
@@ -852,10 +862,7 @@ __global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_ker
     }
     const uint32_t all_b = (uint32_t)(run & 0xffffu), all_t = (uint32_t)(run >> 16) & 0xffffu, nr = (uint32_t)(run >> 32) & 0xffffu;
     if (nr > kLnMaxRec) {  // (uniform) more records than the table holds: as for too many segments
-        if (tid == 0) {
-            flag_error(error, 3u);
-            st_status(&st_ctx[bid], kFlagIncl | (1ull << 61));
-        }
+        give_up();
         return;
     }
     if (tid == 0) {
