@@ -939,7 +939,8 @@ __global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_ker
                 if (need) {
                     const uint32_t e = tab[t], en = tab[t + 1];
                     const uint32_t o = (e & 0xffffu) - drop_b, on = (en & 0xffffu) - drop_b;
-                    const uint32_t take = need < on - b ? need : on - b;
+                    uint32_t take = need < on - b ? need : on - b;
+                    if (take == 0u) take = need;  // (cannot happen - every table entry holds a base; never spin on it)
                     const uint32_t addr = kLnPad + (e >> 16) + (b - o);
                     const uint32_t a4 = addr >> 2, bs = (addr & 3u) * 8u;
                     const uint32_t d0 = sh.text[a4], d1 = sh.text[a4 + 1], d2 = sh.text[a4 + 2], d3 = sh.text[a4 + 3],
