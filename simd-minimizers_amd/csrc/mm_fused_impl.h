@@ -543,9 +543,18 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         if (CANON) ring_turn<W, true>(ring_r);
     }
 
-    // strand vote: dn = #(T|G among the l bases of the current window) - l/2 - 1, so the window
-    // is canonical iff dn >= 0; each step adds tg(in) - tg(leaving base) from packed 2-bit signed
+    // strand vote: dn = #(T|G among the l bases of the window) - l/2 - 1, so the window is canonical iff dn >= 0.
+    // Kept per BLOCK (the value for the block's first window; see "lazy strand vote" in the steps); with
+    // -DMM_VOTE_EAGER (rounds 1-3, A/B) per window: each step adds tg(in) - tg(leaving base) from packed 2-bit signed
     // fields.
+#ifdef MM_VOTE_EAGER
+    constexpr bool kLazyVote = false;
+#else
+#ifndef MM_VOTE_LAZY_MAXW
+#define MM_VOTE_LAZY_MAXW 36  // (k=31 w=51 runs 4 % SLOWER with the lazy vote: 51 branch points, ties 5 x as frequent)
+#endif
+    constexpr bool kLazyVote = CANON && W <= MM_VOTE_LAZY_MAXW;
+#endif
     int dn = 0;
     const uint32_t l = k + (uint32_t)W - 1;
     const int thr = (int)(l / 2);
@@ -618,7 +627,9 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
 #define MM_BUMP(x, c) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "n"(c))
     uint32_t kn = 0;  // wide loads: index of block b + 1 within its group (wave-uniform)
     for (uint32_t b = 1; b <= nblk; ++b) {
-        uint32_t me[NSUB], mo[NSUB], tgw[NSUB];
+        uint32_t me[NSUB], mo[NSUB];
+        uint32_t tgw[NSUB];           // eager strand vote: signed 2-bit steps of the count
+        uint32_t xt[NSUB], yt[NSUB];  // lazy strand vote (below): T|G bits of the block's entering / leaving bases
 #pragma unroll
         for (int g = 0; g < NSUB; ++g) {
 #if !defined(MM_VGPR_MASKS) || MM_VGPR_MASKS
@@ -628,16 +639,24 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             me[g] = (va[g] & 0x33333333u) | ((vr[g] << 2) & 0xccccccccu);
             mo[g] = ((va[g] >> 2) & 0x33333333u) | (vr[g] & 0xccccccccu);
 #endif
-            // 2-bit two's-complement fields: tg(in) - tg(leaving) in {-1,0,1}
             if (CANON) {
+                const uint32_t x = va[g], y = v2[g];
+                if (!kLazyVote) {
+                // 2-bit two's-complement fields: tg(in) - tg(leaving) in {-1,0,1}
                 // (bit 2j+1 of a view word = T|G of base j: low bit of the field = in ^ out, high bit =
                 // out & ~in; four instructions: xor, shift, and-not, bit-field insert)
-                const uint32_t x = va[g], y = v2[g];
 #if !defined(MM_VGPR_MASKS) || MM_VGPR_MASKS
                 tgw[g] = select3(m55, (x ^ y) >> 1, y & ~x);
 #else
                 tgw[g] = (((x ^ y) >> 1) & 0x55555555u) | ((y & ~x) & 0xAAAAAAAAu);
 #endif
+                } else {
+                // bit 2j+1 of a view word = T|G of base j; only the block's own W bases count
+                const int kCnt = (W - 16 * g) >= 16 ? 16 : (W - 16 * g);  // (constants after unrolling)
+                const uint32_t kBlockMask = 0xAAAAAAAAu & (kCnt >= 16 ? 0xffffffffu : ((1u << (2 * (kCnt > 0 ? kCnt : 0))) - 1u));
+                xt[g] = x & kBlockMask;
+                yt[g] = y & kBlockMask;
+                }
             }
         }
         pos_in += W;
@@ -789,7 +808,27 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             uint32_t sel = ring_step<W, false>(ring_l, pl, kl, j);
             if (CANON && MM_STAGE_GE(4)) {
                 const uint32_t selr = ring_step<W, true>(ring_r, pr_, kl ^ kmask, j);
+                if (!kLazyVote) {
                 sel = select3((uint32_t)(dn >> 31), selr, sel);  // dn < 0: rightmost
+                } else {
+                // LAZY STRAND VOTE (round 3).  The vote only matters where the leftmost and the rightmost minimum are
+                // different elements - a tie of the 16 hash bits at the window's minimum, about one window in 7 000 -
+                // so the walk no longer keeps the count of T|G bases per window (bit-field extract, add, sign, select:
+                // 10 issue cycles per window).  It compares the two positions (one half-rate instruction), and the
+                // one wave-step in a hundred in which some lane differs rebuilds that window's count from the count at
+                // the block's start (dn) and the T|G bits of the block's entering / leaving bases below this step.
+                const unsigned long long differ = __builtin_amdgcn_uicmp(sel & 0xffffu, selr & 0xffffu, 33);  // (NE)
+                if (__builtin_expect(differ != 0ull, 0)) {
+                    int d = dn;
+#pragma unroll
+                    for (int g = 0; g <= (j >> 4); ++g) {
+                        const int jj = j - 16 * g;  // bases of group g below step j
+                        const uint32_t m = jj >= 16 ? 0xAAAAAAAAu : (0xAAAAAAAAu & ((1u << (2 * (jj > 0 ? jj : 0))) - 1u));
+                        if (m) d += (int)__builtin_popcount(xt[g] & m) - (int)__builtin_popcount(yt[g] & m);
+                    }
+                    sel = d < 0 ? selr : sel;  // rightmost on the reverse strand
+                }
+                }
             }
             // window i = e - W starts at element i + 1
             const uint32_t i = e - (uint32_t)W;  // uniform
@@ -799,7 +838,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 const uint2 t0 = tq[j];
                 fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t0.x;
                 if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t0.y;
-                if (CANON && MM_STAGE_GE(4)) dn += __builtin_amdgcn_sbfe((int)tgw[j >> 4], 2 * (j & 15), 2);
+                if (CANON && !kLazyVote && MM_STAGE_GE(4)) dn += __builtin_amdgcn_sbfe((int)tgw[j >> 4], 2 * (j & 15), 2);
                 continue;
             }
 #endif
@@ -936,7 +975,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             const uint2 t = tq[j];
             fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t.x;
             if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t.y;
-            if (CANON) dn += __builtin_amdgcn_sbfe((int)tgw[j >> 4], 2 * (j & 15), 2);
+            if (CANON && !kLazyVote) dn += __builtin_amdgcn_sbfe((int)tgw[j >> 4], 2 * (j & 15), 2);
         }
         };  // steps
         // The inline-assembly emit needs every window of the block inside the range and none skipped.
@@ -966,6 +1005,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         if (MM_STAGE_GE(3)) {
             ring_turn<W, false>(ring_l);
             if (CANON && MM_STAGE_GE(4)) ring_turn<W, true>(ring_r);
+            if (CANON && kLazyVote && MM_STAGE_GE(4)) {  // the count moves on by the whole block
+#pragma unroll
+                for (int g = 0; g < NSUB; ++g) dn += (int)__builtin_popcount(xt[g]) - (int)__builtin_popcount(yt[g]);
+            }
         }
     }
 #ifdef MM_STAGE

@@ -50,7 +50,10 @@ for i, s in enumerate(insts):
         continue
     body = insts[labels[m.group(1)]:i + 1]
     ops = collections.Counter(b.split()[0] for b in body)
-    if ops["v_cmp_ne_u32_sdwa"] + ops["v_cmpx_ne_u32_sdwa"] != W or ops["ds_write_b16"] + ops["ds_write_b8"] != W:
+    # (the emit compare is v_cmpx in the fast-emit body; canonical walks carry W more v_cmp_ne_u32_sdwa since round 3:
+    # the lazy strand vote's position compare)
+    emit_cmp = ops["v_cmpx_ne_u32_sdwa"] if ops["v_cmpx_ne_u32_sdwa"] else ops["v_cmp_ne_u32_sdwa"]
+    if emit_cmp != W or ops["ds_write_b16"] + ops["ds_write_b8"] != W:
         continue
     if sum(v for o, v in ops.items() if o.startswith("ds_read")) != W or not any(o.startswith("buffer_load") for o in ops):
         continue  # (the block loop proper: W table look-ups, W list appends, the sequence loads of a later block)
