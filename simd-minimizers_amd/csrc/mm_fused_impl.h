@@ -10,8 +10,10 @@
 //            (s_tab[(out<<2)|in], 16 x uint2 = forward / reverse-complement contribution);
 //            keys are (hash_hi16 | pos16) for the leftmost minimum and the complemented key for
 //            the rightmost one; the two-stacks sliding minimum runs over blocks of W with the
-//            ring held in W registers (W is a template parameter); the strand vote is
-//            incremental.  A window that emits (adjacent dedup against the lane's own previous
+//            ring held in W registers (W is a template parameter; suffix minima kept at every second
+//            element only, see ring_turn); the strand vote is taken only in the steps where the two
+//            minima are different elements (w <= 36; the count of T|G bases is kept per block), per
+//            window otherwise.  A window that emits (adjacent dedup against the lane's own previous
 //            window, or the syncmer predicate) appends its 16-bit lane-relative position to the
 //            lane's private list in LDS with one exec-masked ds_write.  Reference semantics:
 //            src/sliding_min.rs:86-212, src/canonical.rs:12-31, src/minimizers.rs:117-128,
