@@ -549,13 +549,19 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // Kept per BLOCK (the value for the block's first window; see "lazy strand vote" in the steps); with
     // -DMM_VOTE_EAGER (rounds 1-3, A/B) per window: each step adds tg(in) - tg(leaving base) from packed 2-bit signed
     // fields.
+#ifndef MM_VOTE_NO_DEFER
+#define MM_VOTE_NO_DEFER 0  // (1: A/B, the branch of the lazy vote right behind its compare)
+#endif
 #ifdef MM_VOTE_EAGER
     constexpr bool kLazyVote = false;
 #else
 #ifndef MM_VOTE_LAZY_MAXW
-#define MM_VOTE_LAZY_MAXW 36  // (k=31 w=51 runs 4 % SLOWER with the lazy vote: 51 branch points, ties 5 x as frequent)
+#define MM_VOTE_LAZY_MAXW 35
 #endif
-    constexpr bool kLazyVote = CANON && W <= MM_VOTE_LAZY_MAXW;
+    // (not for w = 36, 37: those kernels are bounded to 128 registers - four waves per SIMD - and the pending step's
+    // two values push them further into scratch: w = 36 1.69 ms against 1.58, w = 37 2.27 against 1.62, where w = 35
+    // still gains 6 %; from w = 38 on the bound is 168 registers)
+    constexpr bool kLazyVote = CANON && (W <= MM_VOTE_LAZY_MAXW || W >= 38);
 #endif
     int dn = 0;
     const uint32_t l = k + (uint32_t)W - 1;
@@ -787,63 +793,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         // when every window of the block is inside the range and none is skipped.
         auto steps = [&](auto fe_tag) {
         constexpr bool FE = decltype(fe_tag)::value;
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-            const uint32_t e = e0 + (uint32_t)j;  // uniform
-            if (j + PF < W) tq[j + PF] = lookup(j + PF);
-            const uint32_t h = HASH_RC ? fw + rc : fw;
-#ifdef MM_STAGE
-            if (!MM_STAGE_GE(3)) {  // timing build: stages 1 / 2 end here
-                const uint2 t0 = tq[j];
-                if (MM_STAGE_GE(2)) {
-                    fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t0.x;
-                    if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t0.y;
-                    sink ^= h;
-                } else {
-                    sink += t0.x;
-                }
-                continue;
-            }
-#endif
-            const uint32_t kl = and_or3(h, kmask, e);
-            // window minimum (sparse-suffix two-stacks, see ring_step)
-            uint32_t sel = ring_step<W, false>(ring_l, pl, kl, j);
-            if (CANON && MM_STAGE_GE(4)) {
-                const uint32_t selr = ring_step<W, true>(ring_r, pr_, kl ^ kmask, j);
-                if (!kLazyVote) {
-                sel = select3((uint32_t)(dn >> 31), selr, sel);  // dn < 0: rightmost
-                } else {
-                // LAZY STRAND VOTE (round 3).  The vote only matters where the leftmost and the rightmost minimum are
-                // different elements - a tie of the 16 hash bits at the window's minimum, about one window in 7 000 -
-                // so the walk no longer keeps the count of T|G bases per window (bit-field extract, add, sign, select:
-                // 10 issue cycles per window).  It compares the two positions (one half-rate instruction), and the
-                // one wave-step in a hundred in which some lane differs rebuilds that window's count from the count at
-                // the block's start (dn) and the T|G bits of the block's entering / leaving bases below this step.
-                const unsigned long long differ = __builtin_amdgcn_uicmp(sel & 0xffffu, selr & 0xffffu, 33);  // (NE)
-                if (__builtin_expect(differ != 0ull, 0)) {
-                    int d = dn;
-#pragma unroll
-                    for (int g = 0; g <= (j >> 4); ++g) {
-                        const int jj = j - 16 * g;  // bases of group g below step j
-                        const uint32_t m = jj >= 16 ? 0xAAAAAAAAu : (0xAAAAAAAAu & ((1u << (2 * (jj > 0 ? jj : 0))) - 1u));
-                        if (m) d += (int)__builtin_popcount(xt[g] & m) - (int)__builtin_popcount(yt[g] & m);
-                    }
-                    sel = d < 0 ? selr : sel;  // rightmost on the reverse strand
-                }
-                }
-            }
-            // window i = e - W starts at element i + 1
-            const uint32_t i = e - (uint32_t)W;  // uniform
-#ifdef MM_STAGE
-            if (!MM_STAGE_GE(5)) {  // timing build: stages 3 / 4 end here (no emit)
-                sink ^= sel;
-                const uint2 t0 = tq[j];
-                fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t0.x;
-                if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t0.y;
-                if (CANON && !kLazyVote && MM_STAGE_GE(4)) dn += __builtin_amdgcn_sbfe((int)tgw[j >> 4], 2 * (j & 15), 2);
-                continue;
-            }
-#endif
+        // the emit of step jj (window i = e0 + jj - W, which starts at element i + 1) with its decided minimum
+        auto emit_step = [&](const int jj, uint32_t sel) {
+            const uint32_t e = e0 + (uint32_t)jj;   // uniform
+            const uint32_t i = e - (uint32_t)W;     // uniform
             if (FE) {
                 // Common path: compare, and under the resulting exec mask append the 16-bit value
                 // to the lane's list and advance its slot pointer (2 VALU + 2 SALU + 1 LDS).
@@ -944,7 +897,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 }
             } else {
                 bool flag;
-                const bool skipped = AMBI && ((aw[AMBI ? (j >> 5) : 0] >> (j & 31)) & 1u);
+                const bool skipped = AMBI && ((aw[AMBI ? (jj >> 5) : 0] >> (jj & 31)) & 1u);
                 if (MODE == 0) {
                     flag = (uint16_t)sel != (uint16_t)prev;
                     prev = skipped ? 0xffffffffu : sel;
@@ -974,10 +927,96 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 }
             }
 
+        };
+        // LAZY STRAND VOTE (round 3).  The vote only matters where the leftmost and the rightmost minimum are different
+        // elements - a tie of the 16 hash bits at the window's minimum, about one window in 7 000 - so the walk no longer
+        // keeps the count of T|G bases per window (bit-field extract, add, sign, select: 10 issue cycles per window).  It
+        // compares the two positions (one half-rate instruction into an SGPR pair), and the one wave-step in a hundred in
+        // which some lane's differ rebuilds that window's count from the count at the block's start (dn) and the T|G bits
+        // of the block's entering / leaving bases below the step.  The compare's branch is taken ONE STEP LATER, behind
+        // the next window's minima (the step's emit waits with it): a branch right behind its compare stalled the wave for
+        // the compare's way to the scalar unit, 7 % of the kernel (the kernel without the branch, wrong results: 1.563 ->
+        // 1.451 ms).
+        auto decide = [&](const int jj, const uint32_t sel, const uint32_t selr) -> uint32_t {
+            int d = dn;
+#pragma unroll
+            for (int g = 0; g <= (jj >> 4); ++g) {
+                const int nb = jj - 16 * g;  // bases of group g below step jj
+                const uint32_t m = nb >= 16 ? 0xAAAAAAAAu : (0xAAAAAAAAu & ((1u << (2 * (nb > 0 ? nb : 0))) - 1u));
+                if (m) d += (int)__builtin_popcount(xt[g] & m) - (int)__builtin_popcount(yt[g] & m);
+            }
+            return d < 0 ? selr : sel;  // rightmost on the reverse strand
+        };
+        uint32_t p_sel = 0, p_selr = 0;      // the step whose branch and emit are pending
+        unsigned long long p_differ = 0ull;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const uint32_t e = e0 + (uint32_t)j;  // uniform
+            if (j + PF < W) tq[j + PF] = lookup(j + PF);
+            const uint32_t h = HASH_RC ? fw + rc : fw;
+#ifdef MM_STAGE
+            if (!MM_STAGE_GE(3)) {  // timing build: stages 1 / 2 end here
+                const uint2 t0 = tq[j];
+                if (MM_STAGE_GE(2)) {
+                    fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t0.x;
+                    if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t0.y;
+                    sink ^= h;
+                } else {
+                    sink += t0.x;
+                }
+                continue;
+            }
+#endif
+            const uint32_t kl = and_or3(h, kmask, e);
+            // window minimum (sparse-suffix two-stacks, see ring_step)
+            uint32_t sel = ring_step<W, false>(ring_l, pl, kl, j);
+            bool deferred = false;
+            if (CANON && MM_STAGE_GE(4)) {
+                const uint32_t selr = ring_step<W, true>(ring_r, pr_, kl ^ kmask, j);
+                if (!kLazyVote) {
+                    sel = select3((uint32_t)(dn >> 31), selr, sel);  // dn < 0: rightmost
+                } else {
+                    const unsigned long long differ = __builtin_amdgcn_uicmp(sel & 0xffffu, selr & 0xffffu, 33);  // (NE)
+#ifdef MM_EXP_VOTE_NOBRANCH  // (timing experiment, wrong results: the compare without its branch)
+                    asm volatile("" ::"s"(differ));
+                    const unsigned long long differ_used = 0ull;
+#else
+                    const unsigned long long differ_used = differ;
+#endif
+                    if (MM_STAGE_GE(5) && !(MM_VOTE_NO_DEFER)) {
+                        if (j > 0) {  // the step before this one: its branch, then its emit
+                            if (__builtin_expect(p_differ != 0ull, 0)) p_sel = decide(j - 1, p_sel, p_selr);
+                            emit_step(j - 1, p_sel);
+                        }
+                        p_sel = sel;
+                        p_selr = selr;
+                        p_differ = differ_used;
+                        deferred = true;
+                    } else if (__builtin_expect(differ_used != 0ull, 0)) {
+                        sel = decide(j, sel, selr);
+                    }
+                }
+            }
+#ifdef MM_STAGE
+            if (!MM_STAGE_GE(5)) {  // timing build: stages 3 / 4 end here (no emit)
+                sink ^= sel;
+                const uint2 t0 = tq[j];
+                fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t0.x;
+                if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t0.y;
+                if (CANON && !kLazyVote && MM_STAGE_GE(4)) dn += __builtin_amdgcn_sbfe((int)tgw[j >> 4], 2 * (j & 15), 2);
+                continue;
+            }
+#endif
+            if (!deferred) emit_step(j, sel);
+
             const uint2 t = tq[j];
             fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t.x;
             if (HASH_RC) rc = __builtin_amdgcn_alignbit(rc, rc, rot_r) ^ t.y;
             if (CANON && !kLazyVote) dn += __builtin_amdgcn_sbfe((int)tgw[j >> 4], 2 * (j & 15), 2);
+        }
+        if (CANON && kLazyVote && MM_STAGE_GE(5) && !(MM_VOTE_NO_DEFER)) {  // the block's last step
+            if (__builtin_expect(p_differ != 0ull, 0)) p_sel = decide(W - 1, p_sel, p_selr);
+            emit_step(W - 1, p_sel);
         }
         };  // steps
         // The inline-assembly emit needs every window of the block inside the range and none skipped.

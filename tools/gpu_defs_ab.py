@@ -23,7 +23,7 @@ def chk(b):
     v = out[:c].to(torch.int64)
     return c, int((v * torch.arange(1, c + 1, device="cuda")).sum().item())
 cfgs = [(21, 11, False, 0), (21, 11, True, 0), (31, 51, True, 0), (15, 17, True, 1), (21, 25, True, 0), (21, 7, False, 0),
-        (31, 33, True, 0), (20, 12, True, 0), (21, 20, False, 0), (15, 17, True, 2), (31, 41, True, 0), (21, 37, True, 0)]
+        (31, 33, True, 0), (20, 12, True, 0), (21, 20, False, 0), (15, 17, True, 2), (31, 41, True, 0), (21, 37, True, 0), (31, 35, True, 0), (20, 36, True, 0)]
 A, B = sys.argv[1], sys.argv[2]
 if len(sys.argv) > 3: cfgs = [cfgs[int(x)] for x in sys.argv[3].split(",")]
 print(f"A = '{A}'   B = '{B}'")
