@@ -549,6 +549,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // Kept per BLOCK (the value for the block's first window; see "lazy strand vote" in the steps); with
     // -DMM_VOTE_EAGER (rounds 1-3, A/B) per window: each step adds tg(in) - tg(leaving base) from packed 2-bit signed
     // fields.
+#ifndef MM_RANGE_FE
+#define MM_RANGE_FE 1  // (0: A/B, partial walks over windows above 12 take the flag path)
+#endif
+    constexpr bool kRangeFE = MM_RANGE_FE && PARTIAL && !AMBI && MODE == 0 && !SK && !DIRECT && !kTwoBodies<W>;
 #ifndef MM_VOTE_NO_DEFER
 #define MM_VOTE_NO_DEFER 0  // (1: A/B, the branch of the lazy vote right behind its compare)
 #endif
@@ -794,7 +798,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         auto steps = [&](auto fe_tag) {
         constexpr bool FE = decltype(fe_tag)::value;
         // the emit of step jj (window i = e0 + jj - W, which starts at element i + 1) with its decided minimum
-        auto emit_step = [&](const int jj, uint32_t sel) {
+        auto emit_step = [&](const int jj, uint32_t sel, const unsigned long long valid) {  // valid: kRangeFE walks only
             const uint32_t e = e0 + (uint32_t)jj;   // uniform
             const uint32_t i = e - (uint32_t)W;     // uniform
             if (FE) {
@@ -840,6 +844,24 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                         : "vcc", "memory");
                     prev = sel;
 #endif
+                } else if (MODE == 0 && kRangeFE) {
+                    // PARTIAL walks over larger windows (the last tile of a sequence or range, reads): the same append
+                    // with the lane's range check in it - `valid`: the lanes whose window i is inside, i < rem_valid - instead of the flag
+                    // path for the whole tile, which ran 1.7 x as long as a full tile's walk and held up the look-back
+                    // of every tile behind it (24 contigs in one launch: 1.82 -> ms, round 3).
+#define MM_EMIT_RANGE(WR, SELB)                                                                                 \
+    asm volatile("v_cmp_ne_u32_sdwa vcc, %[sel], %[prev] src0_sel:" SELB " src1_sel:" SELB "\n\t"              \
+                 "s_and_b64 vcc, vcc, %[ok]\n\t"                                                               \
+                 "s_and_saveexec_b64 %[sv], vcc\n\t" WR " %[lp], %[sel]\n\t"                                  \
+                 "v_add_u32 %[lp], %[st], %[lp]\n\t"                                                           \
+                 "s_mov_b64 exec, %[sv]"                                                                        \
+                 : [lp] "+v"(lp32), [sv] "=&s"(sv)                                                              \
+                 : [sel] "v"(sel), [prev] "v"(prev), [st] "v"(stride_v), [ok] "s"(valid)                        \
+                 : "vcc", "scc", "memory")
+                    if (E8) MM_EMIT_RANGE("ds_write_b8", "BYTE_0");
+                    else MM_EMIT_RANGE("ds_write_b16", "WORD_0");
+#undef MM_EMIT_RANGE
+                    prev = sel;
                 } else if (MODE == 0 && E8) {
                     // (8-bit entries: every element index of the lane is below 256, the low bytes decide)
                     asm volatile(
@@ -937,7 +959,14 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         // the next window's minima (the step's emit waits with it): a branch right behind its compare stalled the wave for
         // the compare's way to the scalar unit, 7 % of the kernel (the kernel without the branch, wrong results: 1.563 ->
         // 1.451 ms).
-        auto decide = [&](const int jj, const uint32_t sel, const uint32_t selr) -> uint32_t {
+        auto decide = [&](const int jj, const uint32_t sel, const uint32_t selr, unsigned long long differ) -> uint32_t {
+            // (Lanes past the end of their range read zeros - poly-A, every hash equal, the two minima different at every
+            // step: without this test the last tile of a sequence walked 1.4 x as long as a full one and held up the
+            // look-back of everything behind it, 24 contigs in one launch 1.82 ms against 1.65 for whole tiles.)
+            if (PARTIAL) {
+                differ &= __ballot((int)(e0 + (uint32_t)jj - (uint32_t)W) < ctx.rem_valid);
+                if (differ == 0ull) return sel;
+            }
             int d = dn;
 #pragma unroll
             for (int g = 0; g <= (jj >> 4); ++g) {
@@ -948,7 +977,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             return d < 0 ? selr : sel;  // rightmost on the reverse strand
         };
         uint32_t p_sel = 0, p_selr = 0;      // the step whose branch and emit are pending
-        unsigned long long p_differ = 0ull;
+        unsigned long long p_differ = 0ull, p_valid = ~0ull;
 #pragma unroll
         for (int j = 0; j < W; ++j) {
             const uint32_t e = e0 + (uint32_t)j;  // uniform
@@ -971,6 +1000,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             // window minimum (sparse-suffix two-stacks, see ring_step)
             uint32_t sel = ring_step<W, false>(ring_l, pl, kl, j);
             bool deferred = false;
+            // (range-checked fast emit: the lanes whose window of this step is inside their range; lanes past it read
+            // zeros - poly-A, every hash equal - and must not send the lazy vote down its slow path at every step)
+            const unsigned long long valid =
+                (kRangeFE || (PARTIAL && CANON && kLazyVote)) ? __ballot((int)(e - (uint32_t)W) < ctx.rem_valid) : ~0ull;
             if (CANON && MM_STAGE_GE(4)) {
                 const uint32_t selr = ring_step<W, true>(ring_r, pr_, kl ^ kmask, j);
                 if (!kLazyVote) {
@@ -981,19 +1014,20 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                     asm volatile("" ::"s"(differ));
                     const unsigned long long differ_used = 0ull;
 #else
-                    const unsigned long long differ_used = differ;
+                    const unsigned long long differ_used = differ & valid;
 #endif
                     if (MM_STAGE_GE(5) && !(MM_VOTE_NO_DEFER)) {
                         if (j > 0) {  // the step before this one: its branch, then its emit
-                            if (__builtin_expect(p_differ != 0ull, 0)) p_sel = decide(j - 1, p_sel, p_selr);
-                            emit_step(j - 1, p_sel);
+                            if (__builtin_expect(p_differ != 0ull, 0)) p_sel = decide(j - 1, p_sel, p_selr, p_differ);
+                            emit_step(j - 1, p_sel, p_valid);
                         }
                         p_sel = sel;
                         p_selr = selr;
                         p_differ = differ_used;
+                        p_valid = valid;
                         deferred = true;
                     } else if (__builtin_expect(differ_used != 0ull, 0)) {
-                        sel = decide(j, sel, selr);
+                        sel = decide(j, sel, selr, differ_used);
                     }
                 }
             }
@@ -1007,7 +1041,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 continue;
             }
 #endif
-            if (!deferred) emit_step(j, sel);
+            if (!deferred) emit_step(j, sel, valid);
 
             const uint2 t = tq[j];
             fw = __builtin_amdgcn_alignbit(fw, fw, rot_l) ^ t.x;
@@ -1015,8 +1049,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             if (CANON && !kLazyVote) dn += __builtin_amdgcn_sbfe((int)tgw[j >> 4], 2 * (j & 15), 2);
         }
         if (CANON && kLazyVote && MM_STAGE_GE(5) && !(MM_VOTE_NO_DEFER)) {  // the block's last step
-            if (__builtin_expect(p_differ != 0ull, 0)) p_sel = decide(W - 1, p_sel, p_selr);
-            emit_step(W - 1, p_sel);
+            if (__builtin_expect(p_differ != 0ull, 0)) p_sel = decide(W - 1, p_sel, p_selr, p_differ);
+            emit_step(W - 1, p_sel, p_valid);
         }
         };  // steps
         // The inline-assembly emit needs every window of the block inside the range and none skipped.
@@ -1026,6 +1060,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         constexpr bool kCanFast = !DIRECT;
         if (kCanFast && !PARTIAL && !AMBI) {
             steps(BoolTag<true>{});
+        } else if (kRangeFE) {
+            steps(BoolTag<kRangeFE>{});
         } else if (kCanFast && kTwoBodies<W>) {
             bool ok = true;
             if (AMBI) {
