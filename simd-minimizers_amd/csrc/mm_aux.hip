@@ -183,8 +183,14 @@ __global__ __launch_bounds__(kBlockThreads) void window_ambiguity_kernel(
         const unsigned long long v =
             (unsigned long long)bit_view32(amb, amb_dwords, b) |
             ((unsigned long long)bit_view32(amb, amb_dwords, b + 32) << 32);
-        unsigned long long acc = 0;
-        for (uint32_t s = 0; s < l; ++s) acc |= v >> s;
+        // OR of v >> 0 .. v >> (l - 1) by doubling: five or six shifts instead of l
+        unsigned long long acc = v;
+        uint32_t cover = 1;
+        while (2u * cover <= l) {
+            acc |= acc >> cover;
+            cover *= 2u;
+        }
+        if (cover < l) acc |= acc >> (l - cover);
         r = (uint32_t)acc;
     } else {
         uint32_t any = 0;

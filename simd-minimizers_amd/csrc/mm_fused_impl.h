@@ -553,6 +553,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
 #define MM_RANGE_FE 1  // (0: A/B, partial walks over windows above 12 take the flag path)
 #endif
     constexpr bool kRangeFE = MM_RANGE_FE && PARTIAL && !AMBI && MODE == 0 && !SK && !DIRECT && !kTwoBodies<W>;
+#ifndef MM_AMBI_FE
+#define MM_AMBI_FE 1  // (0: A/B, blocks with skipped windows take the flag path)
+#endif
+    constexpr bool kAmbiFE = MM_AMBI_FE && AMBI && MODE == 0 && !SK && !DIRECT;
 #ifndef MM_VOTE_NO_DEFER
 #define MM_VOTE_NO_DEFER 0  // (1: A/B, the branch of the lazy vote right behind its compare)
 #endif
@@ -796,7 +800,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         // The W steps of the block.  FE (fast emit): the exec-masked append in inline assembly, legal
         // when every window of the block is inside the range and none is skipped.
         auto steps = [&](auto fe_tag) {
-        constexpr bool FE = decltype(fe_tag)::value;
+        constexpr int FEK = (int)decltype(fe_tag)::value;  // 0 flag path, 1 fast emit, 2 fast emit that knows skipped windows
+        constexpr bool FE = FEK != 0;
         // the emit of step jj (window i = e0 + jj - W, which starts at element i + 1) with its decided minimum
         auto emit_step = [&](const int jj, uint32_t sel, const unsigned long long valid) {  // valid: kRangeFE walks only
             const uint32_t e = e0 + (uint32_t)jj;   // uniform
@@ -805,7 +810,31 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 // Common path: compare, and under the resulting exec mask append the 16-bit value
                 // to the lane's list and advance its slot pointer (2 VALU + 2 SALU + 1 LDS).
                 unsigned long long sv;
-                if (MODE == 0 && SK) {
+                if (FEK == 2) {
+                    // Skip-ambiguous walks, blocks in which some lane has a skipped window (all blocks for windows
+                    // above 12, which carry one body): the same append with the skip in it instead of the flag path
+                    // (k=31 w=51 on 1 Gbp with Ns: 1.37 -> ms).  A skipped window turns its value into all ones - it then
+                    // never equals a real successor and never a predecessor but another skipped one, like the SIMD
+                    // collector's lanes (src/intrinsics/dedup.rs:147-155) - and its lane's slot pointer stands still, so
+                    // what the append writes for it is overwritten by the lane's next entry (or falls behind the list's
+                    // end).  `valid`: the lane's range check of partial walks (all ones otherwise).
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)aw[AMBI ? (jj >> 5) : 0], jj & 31, 1);
+                    const uint32_t selx = sel | m;
+                    const uint32_t st = stride_v & ~m;
+#define MM_EMIT_SKIP(WR, SELB)                                                                        \
+    asm volatile("v_cmp_ne_u32_sdwa vcc, %[sel], %[prev] src0_sel:" SELB " src1_sel:" SELB "\n\t"    \
+                 "s_and_b64 vcc, vcc, %[ok]\n\t"                                                     \
+                 "s_and_saveexec_b64 %[sv], vcc\n\t" WR " %[lp], %[sel]\n\t"                        \
+                 "v_add_u32 %[lp], %[st], %[lp]\n\t"                                                 \
+                 "s_mov_b64 exec, %[sv]"                                                              \
+                 : [lp] "+v"(lp32), [sv] "=&s"(sv)                                                    \
+                 : [sel] "v"(selx), [prev] "v"(prev), [st] "v"(st), [ok] "s"(valid)                   \
+                 : "vcc", "scc", "memory")
+                    if (E8) MM_EMIT_SKIP("ds_write_b8", "BYTE_0");
+                    else MM_EMIT_SKIP("ds_write_b16", "WORD_0");
+#undef MM_EMIT_SKIP
+                    prev = selx;
+                } else if (MODE == 0 && SK) {
                     // one more VALU under the mask: the packed (window, offset) entry
                     const uint32_t skc = i * ((1u << kSkShift<W>) - 1u);  // uniform
                     asm volatile(
@@ -1003,7 +1032,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             // (range-checked fast emit: the lanes whose window of this step is inside their range; lanes past it read
             // zeros - poly-A, every hash equal - and must not send the lazy vote down its slow path at every step)
             const unsigned long long valid =
-                (kRangeFE || (PARTIAL && CANON && kLazyVote)) ? __ballot((int)(e - (uint32_t)W) < ctx.rem_valid) : ~0ull;
+                (kRangeFE || (PARTIAL && CANON && kLazyVote) || (PARTIAL && kAmbiFE)) ? __ballot((int)(e - (uint32_t)W) < ctx.rem_valid)
+                                                                                    : ~0ull;
             if (CANON && MM_STAGE_GE(4)) {
                 const uint32_t selr = ring_step<W, true>(ring_r, pr_, kl ^ kmask, j);
                 if (!kLazyVote) {
@@ -1059,9 +1089,9 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         // test - for small W only, see kTwoBodies.
         constexpr bool kCanFast = !DIRECT;
         if (kCanFast && !PARTIAL && !AMBI) {
-            steps(BoolTag<true>{});
+            steps(IntTag<1>{});
         } else if (kRangeFE) {
-            steps(BoolTag<kRangeFE>{});
+            steps(IntTag<kRangeFE ? 1 : 0>{});
         } else if (kCanFast && kTwoBodies<W>) {
             bool ok = true;
             if (AMBI) {
@@ -1074,10 +1104,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 ok = __ballot(any != 0) == 0;
             }
             if (PARTIAL) ok = ok && (int)(b * (uint32_t)W) <= ctx.min_rem;  // windows < b * W all valid
-            if (ok) steps(BoolTag<kCanFast && kTwoBodies<W>>{});
-            else steps(BoolTag<false>{});
+            if (ok) steps(IntTag<(kCanFast && kTwoBodies<W>) ? 1 : 0>{});
+            else steps(IntTag<kAmbiFE ? 2 : 0>{});  // (skipped windows and the range check in the append itself)
         } else {
-            steps(BoolTag<false>{});
+            steps(IntTag<kAmbiFE ? 2 : 0>{});
         }
         if (MM_STAGE_GE(3)) {
             ring_turn<W, false>(ring_l);
