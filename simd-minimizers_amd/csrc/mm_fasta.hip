@@ -821,41 +821,63 @@ __global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_ker
     // Everything here is independent of the chunks before: the table holds every segment that may hold sequence, in
     // order, and the classes U / V / K are runs of it (see lookback_lines), so the look-back's answer only cuts the
     // front off.
-    const uint32_t nseg = E + 1u, rounds = (nseg + kBlockThreads - 1u) / kBlockThreads;  // <= 4
+    // (TWO consecutive segments per thread and round: the text of a 60-column FASTA file has about 270 segments per
+    // chunk, and the workgroup-wide scans of a round cost the same for 14 segments as for 256)
+    constexpr uint32_t kPerRound = 2u * kBlockThreads;
+    const uint32_t nseg = E + 1u, rounds = (nseg + kPerRound - 1u) / kPerRound;  // <= 2
     uint32_t ln_run = 0, lr_run = 0;  // latest line start / record start so far, as 1 + segment index (0 = none)
     unsigned long long run = 0;       // sequence bytes | table entries << 16 | record starts << 32 so far
     for (uint32_t rd = 0; rd < rounds; ++rd) {
-        const uint32_t l = rd * kBlockThreads + tid;
-        uint32_t start = 0, end = 0, a = 0, b = 0;
-        if (l < nseg) {
-            uint32_t prev = tx[-1];  // the byte in front of the segment's first byte
-            if (l > 0) {
-                const uint32_t pp = sh.list[l - 1];
-                prev = tx[pp];
-                const bool sep = prev == (uint32_t)'\n' || prev == (uint32_t)'\r';
-                start = pp + (sep ? 1u : 0u);
-            }
-            end = l < E ? (uint32_t)sh.list[l] : L;
-            if (prev == (uint32_t)'\n') {  // a line starts here
-                a = l + 1u;
-                if (start < L && tx[start] == (uint8_t)'>') b = l + 1u;
+        uint32_t start[2], end[2], am[2], bm[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t l = rd * kPerRound + 2u * tid + (uint32_t)h;
+            start[h] = end[h] = am[h] = bm[h] = 0;
+            if (l < nseg) {
+                uint32_t prev = tx[-1];  // the byte in front of the segment's first byte
+                if (l > 0) {
+                    const uint32_t pp = sh.list[l - 1];
+                    prev = tx[pp];
+                    const bool sep = prev == (uint32_t)'\n' || prev == (uint32_t)'\r';
+                    start[h] = pp + (sep ? 1u : 0u);
+                }
+                end[h] = l < E ? (uint32_t)sh.list[l] : L;
+                if (prev == (uint32_t)'\n') {  // a line starts here
+                    am[h] = l + 1u;
+                    if (start[h] < L && tx[start[h]] == (uint8_t)'>') bm[h] = l + 1u;
+                }
             }
         }
         uint32_t xa, xb, ta, tb;
-        block_prev_marks(a, b, sh.s, xa, xb, ta, tb);
-        const uint32_t ea = xa ? xa : ln_run, eb = xb ? xb : lr_run;  // latest marks before this segment
-        const uint32_t la = a ? a : ea, lb = b ? b : eb;              // ... up to and including it
-        const bool valid = l < nseg;
-        const bool is_rec = valid && b != 0u;
-        const bool cand = valid && end > start && !(lb != 0u && lb == la);  // not inside a header of this chunk
-        const unsigned long long v = (cand ? (unsigned long long)(end - start) | (1ull << 16) : 0ull) | (is_rec ? (1ull << 32) : 0ull);
+        block_prev_marks(am[1] ? am[1] : am[0], bm[1] ? bm[1] : bm[0], sh.s, xa, xb, ta, tb);
+        uint32_t ea = xa ? xa : ln_run, eb = xb ? xb : lr_run;  // latest marks before the thread's first segment
+        unsigned long long v[2];
+        bool cand[2], is_rec[2];
+        uint32_t first_a[2], first_b[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t l = rd * kPerRound + 2u * tid + (uint32_t)h;
+            const uint32_t la = am[h] ? am[h] : ea, lb = bm[h] ? bm[h] : eb;  // ... up to and including this segment
+            const bool valid = l < nseg;
+            is_rec[h] = valid && bm[h] != 0u;
+            cand[h] = valid && end[h] > start[h] && !(lb != 0u && lb == la);  // not inside a header of this chunk
+            v[h] = (cand[h] ? (unsigned long long)(end[h] - start[h]) | (1ull << 16) : 0ull) | (is_rec[h] ? (1ull << 32) : 0ull);
+            first_a[h] = am[h] && !ea;  // the chunk's first line start / record start
+            first_b[h] = bm[h] && !eb;
+            ea = la;
+            eb = lb;
+        }
         unsigned long long tot;
-        const unsigned long long ex = run + block_sum_excl64(v, sh.s64, tot);
-        const uint32_t o = (uint32_t)(ex & 0xffffu);
-        if (cand) sh.tab[(uint32_t)(ex >> 16) & 0xffffu] = o | (start << 16);
-        if (is_rec && ((uint32_t)(ex >> 32) & 0xffffu) < kLnMaxRec) sh.recs[(uint32_t)(ex >> 32) & 0xffffu] = o | (start << 16);
-        if (a && !ea) sh.u_end = (uint32_t)ex;  // the chunk's first line start: everything before it is class U
-        if (b && !eb) sh.v_end = (uint32_t)ex;  // the first record start: U and V end here
+        unsigned long long ex = run + block_sum_excl64(v[0] + v[1], sh.s64, tot);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t o = (uint32_t)(ex & 0xffffu);
+            if (cand[h]) sh.tab[(uint32_t)(ex >> 16) & 0xffffu] = o | (start[h] << 16);
+            if (is_rec[h] && ((uint32_t)(ex >> 32) & 0xffffu) < kLnMaxRec) sh.recs[(uint32_t)(ex >> 32) & 0xffffu] = o | (start[h] << 16);
+            if (first_a[h]) sh.u_end = (uint32_t)ex;  // everything before the first line start is class U
+            if (first_b[h]) sh.v_end = (uint32_t)ex;  // U and V end at the first record start
+            ex += v[h];
+        }
         run += tot;
         ln_run = ta ? ta : ln_run;
         lr_run = tb ? tb : lr_run;
