@@ -120,6 +120,7 @@ __device__ __forceinline__ uint32_t top_bit_pos1(uint32_t m) { return m ? 32u - 
 // lane that holds a mark) and a four-entry exchange between the waves.  a / b = the thread's own last newline /
 // record start as position + 1 relative to the iteration (0 = none); returns the exclusive maxima in xa / xb and
 // the workgroup's maxima in ta / tb.  s = 2 * kWavesPerBlock words of LDS.
+template <int WAVES = kWavesPerBlock>
 __device__ __forceinline__ void block_prev_marks(uint32_t a, uint32_t b, uint32_t *s, uint32_t &xa, uint32_t &xb,
                                                  uint32_t &ta, uint32_t &tb) {
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -136,13 +137,13 @@ __device__ __forceinline__ void block_prev_marks(uint32_t a, uint32_t b, uint32_
     wave_part(b, xb, lb);
     if (lane == 0) {
         s[wave] = la;
-        s[kWavesPerBlock + wave] = lb;
+        s[WAVES + wave] = lb;
     }
     __syncthreads();
     ta = tb = 0;
 #pragma unroll
-    for (int w = 0; w < kWavesPerBlock; ++w) {
-        const uint32_t va = s[w], vb = s[kWavesPerBlock + w];
+    for (int w = 0; w < WAVES; ++w) {
+        const uint32_t va = s[w], vb = s[WAVES + w];
         if (w < wave) {
             xa = va > xa ? va : xa;
             xb = vb > xb ? vb : xb;
@@ -526,14 +527,19 @@ __device__ __forceinline__ uint32_t lookback_context(unsigned long long *status,
 // with more than kLnMaxSeg - 1 candidates (lines shorter than 16 bytes on average) or more than kLnMaxRec record starts
 // raises error 3 and the host takes
 // the three-pass kernels for that text.
-constexpr uint32_t kLnChunk = 16384;                               // text bytes per chunk = workgroup
-constexpr uint32_t kLnWaveBytes = kLnChunk / kWavesPerBlock;       // 4 KB
+#ifndef MM_FASTA_LN_WAVES
+#define MM_FASTA_LN_WAVES 8  // (4: 16 KB chunks, six workgroups per CU; 8: 32 KB chunks, three - half as many links in the look-back chain)
+#endif
+constexpr int kLnWaves = MM_FASTA_LN_WAVES;                        // waves of a workgroup
+constexpr int kLnThreads = kLnWaves * kWave;
+constexpr uint32_t kLnWaveBytes = 4096;                            // 4 KB of text per wave
+constexpr uint32_t kLnChunk = kLnWaveBytes * kLnWaves;             // text bytes per chunk = workgroup
 constexpr uint32_t kLnRows = kLnWaveBytes / (16u * kWave);         // 4 rows of 1 KB per wave
 #ifndef MM_FASTA_MAXSEG
-#define MM_FASTA_MAXSEG 1024
+#define MM_FASTA_MAXSEG (256 * MM_FASTA_LN_WAVES)
 #endif
 constexpr uint32_t kLnMaxSeg = MM_FASTA_MAXSEG;                               // segments of a chunk (candidates + 1)
-constexpr uint32_t kLnMaxRec = 512;                                // record starts of a chunk
+constexpr uint32_t kLnMaxRec = 128u * kLnWaves;                               // record starts of a chunk
 constexpr uint32_t kLnPad = 16;                                    // bytes in front of the chunk's text in LDS
 constexpr uint32_t kLnMaxQ = kLnChunk / 16u + 2u;                  // output dwords a chunk can touch
 static_assert(kLnRows == 4, "the packed scans below hold four rows");
@@ -544,12 +550,12 @@ struct LnShared {
     uint32_t recs[kLnMaxRec];        // record starts: output offset | text position << 16
     uint16_t list[kLnMaxSeg];        // candidate positions, ascending
     uint16_t marks[kLnMaxQ];         // per output dword: 1 + the table entry that holds its first base (0 = none)
-    uint32_t s[2 * kWavesPerBlock];
-    unsigned long long s64[kWavesPerBlock];
-    uint32_t cnt[kWavesPerBlock];
+    uint32_t s[2 * kLnWaves];
+    unsigned long long s64[kLnWaves];
+    uint32_t cnt[kLnWaves];
     uint32_t ctx;
     uint32_t u_end, v_end;           // sequence bytes | table entries << 16 before the first line start / record start
-    uint32_t edge[kWavesPerBlock];   // the last output dword every wave holds (for its neighbour's funnel shift)
+    uint32_t edge[kLnWaves];   // the last output dword every wave holds (for its neighbour's funnel shift)
     unsigned long long off[2];
 };
 
@@ -562,13 +568,15 @@ struct LnShared {
 // start (always count) - its record starts, and what it does to the state (kind: 0 nothing, 1 ends outside a header
 // line, 2 ends inside one; whether it holds a record start).  The chunk that looks back evaluates the functions of
 // its predecessors from the nearest inclusive word forwards; the states along the way come from three ballots.
-//   aggregate: K 0..14 | V 15..29 | U 30..44 | records 45..55 | kind 56..57 | has record 58 | flag 62..63 (= 1)
+//   aggregate: K | V | U (kLnFB = 15 or 16 bits each) | records (11 bits) | kind (2) | has record (1) | flag 62..63 (= 1)
 //   inclusive: sequence bytes 0..31 | records 32..59 | inside header 60 | record started 61 | flag (= 2)
 // (texts are below 4 GB, a chunk holds fewer than 1024 segments: 28 bits hold the records.)
 struct LnPrefix {
     uint32_t h, started;
     unsigned long long bases, recs;
 };
+constexpr int kLnFB = kLnChunk <= 16384u ? 15 : 16;  // bits of a class count in the aggregate word
+static_assert(kLnChunk <= 32768u && kLnMaxSeg <= 2048u, "the aggregate word holds 16-bit class counts and 11-bit record counts");
 constexpr int kLnGroups = 16;  // 64-chunk groups kept in registers while looking for the nearest inclusive word
 #ifndef MM_FASTA_LB_BATCH
 #define MM_FASTA_LB_BATCH 4
@@ -578,9 +586,9 @@ constexpr int kLnBatch = MM_FASTA_LB_BATCH;  // groups loaded together
 // one thread, as soon as the chunk's classes are counted (chunk 0 publishes its inclusive word straight away)
 __device__ __forceinline__ void ln_publish(unsigned long long *status, uint32_t bid, uint32_t K, uint32_t V, uint32_t U,
                                            uint32_t nr, uint32_t kind, uint32_t has_rec) {
-    st_status(&status[bid], kFlagAgg | K | ((unsigned long long)V << 15) | ((unsigned long long)U << 30) |
-                                ((unsigned long long)nr << 45) | ((unsigned long long)kind << 56) |
-                                ((unsigned long long)has_rec << 58));
+    st_status(&status[bid], kFlagAgg | K | ((unsigned long long)V << kLnFB) | ((unsigned long long)U << (2 * kLnFB)) |
+                                ((unsigned long long)nr << (3 * kLnFB)) | ((unsigned long long)kind << (3 * kLnFB + 11)) |
+                                ((unsigned long long)has_rec << (3 * kLnFB + 13)));
 }
 
 __device__ __forceinline__ LnPrefix lookback_lines(unsigned long long *status, uint32_t bid, uint32_t K, uint32_t V, uint32_t U,
@@ -651,16 +659,17 @@ __device__ __forceinline__ LnPrefix lookback_lines(unsigned long long *status, u
                 sums = (wi & 0xffffffffull) | (((wi >> 32) & 0xfffffffull) << 32);
                 part = F ? ((1ull << F) - 1ull) : 0ull;
             }
-            const uint32_t wk = (uint32_t)(w >> 56) & 3u;
+            const uint32_t wk = (uint32_t)(w >> (3 * kLnFB + 11)) & 3u;
             const unsigned long long D = __ballot(wk != 0u) & part, Hd = __ballot(wk == 2u) & part,
-                                     Rc = __ballot(((w >> 58) & 1ull) != 0ull) & part;
+                                     Rc = __ballot(((w >> (3 * kLnFB + 13)) & 1ull) != 0ull) & part;
             const unsigned long long above = lane == 63 ? 0ull : ~((2ull << lane) - 1ull);
             const unsigned long long da = D & above;
             const uint32_t h_in = da ? (uint32_t)(Hd >> __builtin_ctzll(da)) & 1u : h;
             const uint32_t st_in = (st || (Rc & above)) ? 1u : 0u;
             if ((part >> lane) & 1ull) {
-                const uint32_t k = (uint32_t)w & 0x7fffu, v = (uint32_t)(w >> 15) & 0x7fffu, u = (uint32_t)(w >> 30) & 0x7fffu;
-                mine += (unsigned long long)(k + (st_in ? v + (h_in ? 0u : u) : 0u)) | (((w >> 45) & 0x7ffull) << 32);
+                constexpr uint32_t kFM = (1u << kLnFB) - 1u;
+                const uint32_t k = (uint32_t)w & kFM, v = (uint32_t)(w >> kLnFB) & kFM, u = (uint32_t)(w >> (2 * kLnFB)) & kFM;
+                mine += (unsigned long long)(k + (st_in ? v + (h_in ? 0u : u) : 0u)) | (((w >> (3 * kLnFB)) & 0x7ffull) << 32);
             }
             if (D) h = (uint32_t)(Hd >> __builtin_ctzll(D)) & 1u;
             if (Rc) st = 1u;
@@ -697,7 +706,7 @@ __device__ __forceinline__ unsigned long long block_sum_excl64(unsigned long lon
     __syncthreads();
     unsigned long long base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < kWavesPerBlock; ++w) {
+    for (int w = 0; w < kLnWaves; ++w) {
         const unsigned long long t = s[w];
         if (w < wave) base += t;
         tot += t;
@@ -724,7 +733,7 @@ __device__ __forceinline__ uint32_t pack16(uint32_t x0, uint32_t x1, uint32_t x2
 #ifndef MM_FASTA_WAVES
 #define MM_FASTA_WAVES 6  // 85 VGPRs and 26.8 KB of LDS: six workgroups per CU (the kernel is bound by latencies)
 #endif
-__global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_kernel(
+__global__ __launch_bounds__(kLnThreads, MM_FASTA_WAVES) void fasta_lines_kernel(
     const uint8_t *__restrict__ text, uint64_t n, unsigned long long *__restrict__ st_ctx,
     uint32_t *__restrict__ out32,
     uint64_t out_dwords, unsigned long long *__restrict__ rec_base, unsigned long long *__restrict__ rec_pos,
@@ -751,7 +760,7 @@ __global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_ker
     for (uint32_t r = 0; r < kLnRows; ++r) raw[r] = load_raw(text, n, c0 + w0 + r * (16u * kWave) + 16ull * lane);
     if (tid == 0) tx[-1] = c0 ? text[c0 - 1] : (uint8_t)'\n';
     if (tid < 8) sh.text[(kLnPad + kLnChunk) / 4u + tid] = 0x41414141u;
-    for (uint32_t i = tid; i < kLnMaxQ; i += kBlockThreads) sh.marks[i] = 0;
+    for (uint32_t i = tid; i < kLnMaxQ; i += kLnThreads) sh.marks[i] = 0;
     uint32_t cm[kLnRows];  // bit j = byte j of the lane's piece is a candidate
 #pragma unroll
     for (uint32_t r = 0; r < kLnRows; ++r) {
@@ -785,7 +794,7 @@ __global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_ker
     __syncthreads();
     uint32_t E = 0, before = 0;
 #pragma unroll
-    for (int w = 0; w < kWavesPerBlock; ++w) {
+    for (int w = 0; w < kLnWaves; ++w) {
         if (w < wave) before += sh.cnt[w];
         E += sh.cnt[w];
     }
@@ -823,7 +832,7 @@ __global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_ker
     // front off.
     // (TWO consecutive segments per thread and round: the text of a 60-column FASTA file has about 270 segments per
     // chunk, and the workgroup-wide scans of a round cost the same for 14 segments as for 256)
-    constexpr uint32_t kPerRound = 2u * kBlockThreads;
+    constexpr uint32_t kPerRound = 2u * kLnThreads;
     const uint32_t nseg = E + 1u, rounds = (nseg + kPerRound - 1u) / kPerRound;  // <= 2
     uint32_t ln_run = 0, lr_run = 0;  // latest line start / record start so far, as 1 + segment index (0 = none)
     unsigned long long run = 0;       // sequence bytes | table entries << 16 | record starts << 32 so far
@@ -849,7 +858,7 @@ __global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_ker
             }
         }
         uint32_t xa, xb, ta, tb;
-        block_prev_marks(am[1] ? am[1] : am[0], bm[1] ? bm[1] : bm[0], sh.s, xa, xb, ta, tb);
+        block_prev_marks<kLnWaves>(am[1] ? am[1] : am[0], bm[1] ? bm[1] : bm[0], sh.s, xa, xb, ta, tb);
         uint32_t ea = xa ? xa : ln_run, eb = xb ? xb : lr_run;  // latest marks before the thread's first segment
         unsigned long long v[2];
         bool cand[2], is_rec[2];
@@ -905,12 +914,12 @@ __global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_ker
     // common answer (nothing dropped; r0 = 0, put right by one funnel shift between neighbouring lanes when the
     // stores go out) and is repeated the slow way when the answer differs: the chunk's predecessors get the time of B
     // to publish, instead of the chunk waiting for them with nothing to do.
-    constexpr int kMaxRows = (int)((kLnMaxQ + kWave - 1) / kWave + kWavesPerBlock - 1) / kWavesPerBlock;  // 5
+    constexpr int kMaxRows = (int)((kLnMaxQ + kWave - 1) / kWave + kLnWaves - 1) / kLnWaves;  // 5
     uint32_t acc[kMaxRows];
     uint32_t row0 = 0, row1 = 0;
     // marks: a segment signs the first dword boundary it covers (dword q starts at chunk base max(0, 16 q - r))
     auto make_marks = [&](const uint32_t *tab, uint32_t T, uint32_t drop_b, uint32_t r) {
-        for (uint32_t t = tid; t < T; t += kBlockThreads) {
+        for (uint32_t t = tid; t < T; t += kLnThreads) {
             const uint32_t o = (tab[t] & 0xffffu) - drop_b, on = (tab[t + 1] & 0xffffu) - drop_b;
             const uint32_t q = o ? (o + r + 15u) >> 4 : 0u;
             const uint32_t bq = q ? 16u * q - r : 0u;
@@ -919,7 +928,7 @@ __global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_ker
     };
     // dwords [0, nq) of the layout with the first base at bit 2 r of dword 0
     auto gather = [&](const uint32_t *tab, uint32_t drop_b, uint32_t nb, uint32_t r, uint32_t nq) {
-        const uint32_t qrows = (nq + kWave - 1u) / kWave, per_wave = (qrows + kWavesPerBlock - 1u) / kWavesPerBlock;
+        const uint32_t qrows = (nq + kWave - 1u) / kWave, per_wave = (qrows + kLnWaves - 1u) / kLnWaves;
         row0 = (uint32_t)wave * per_wave;
         row1 = row0 + per_wave < qrows ? row0 + per_wave : qrows;
         if (row0 >= row1) {
@@ -1024,7 +1033,7 @@ __global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_ker
     const uint32_t r0 = (uint32_t)(G0 & 15ull);
     const uint32_t nq = nb ? (r0 + nb + 15u) >> 4 : 0u;  // output dwords this chunk writes to
     // record table: a record's bases start at the output offset reached at its header
-    for (uint32_t i = tid; i < nr; i += kBlockThreads) {
+    for (uint32_t i = tid; i < nr; i += kLnThreads) {
         const unsigned long long r = R0 + i;
         if (r < max_records) {
             rec_base[r] = G0 + ((sh.recs[i] & 0xffffu) - drop_b);
@@ -1039,7 +1048,7 @@ __global__ __launch_bounds__(kBlockThreads, MM_FASTA_WAVES) void fasta_lines_ker
     if (debug & 2u) return;
     uint32_t shift = 2u * r0;  // what the dwords in registers still have to move up by
     if (drop_b != 0u) {        // (uniform) the other answer: once more, with the layout as it is
-        for (uint32_t i = tid; i < kLnMaxQ; i += kBlockThreads) sh.marks[i] = 0;
+        for (uint32_t i = tid; i < kLnMaxQ; i += kLnThreads) sh.marks[i] = 0;
         __syncthreads();
         make_marks(sh.tab + drop_t, T, drop_b, r0);
         __syncthreads();
@@ -1103,7 +1112,7 @@ int launch_fasta_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed
         const char *de = mm_env("MM_FASTA_DEBUG");
         const uint32_t dbg = de ? (uint32_t)atoi(de) : 0u;
         if (hipMemsetAsync(a, 0, (oc + 1) * sizeof(unsigned long long), stream) != hipSuccess) return -1;
-        hipLaunchKernelGGL(fasta_lines_kernel, dim3((uint32_t)oc), dim3(kBlockThreads), 0, stream, d_text, n_bytes, a,
+        hipLaunchKernelGGL(fasta_lines_kernel, dim3((uint32_t)oc), dim3(kLnThreads), 0, stream, d_text, n_bytes, a,
                            reinterpret_cast<uint32_t *>(d_packed), out_dwords, d_rec_base,
                            d_rec_pos, max_records, d_counts, (uint32_t)oc, d_error, dbg);
         return hipGetLastError() == hipSuccess ? 0 : -1;
