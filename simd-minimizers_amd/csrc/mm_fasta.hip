@@ -509,7 +509,7 @@ __device__ __forceinline__ uint32_t lookback_context(unsigned long long *status,
 // the look-backs and ran no faster than the three passes: 2.07 and 1.77 ms for 1 GiB against 1.68 ms).
 //
 // FASTA text is long runs of sequence bytes between a few separators, so the work is split by what it is proportional
-// to.  A chunk is 16 KB of text, staged in LDS once:
+// to.  A chunk is kLnChunk = 32 KB of text (eight waves; MM_FASTA_LN_WAVES=4: 16 KB), staged in LDS once:
 //   A1 (per text byte, SWAR, ~0.13 VALU cycles / byte)  candidate separators = bytes below 0x0E ('\n', '\r' and the odd
 //       control character), four adds and logic operations per dword; their positions go to a sorted list in LDS
 //       (a wave owns 4 KB: 64 lanes x 16 bytes x 4 rows; one packed scan of the per-lane counts orders them);
