@@ -1608,7 +1608,10 @@ int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_b
     for (int attempt = 0; attempt < 2; ++attempt) {
         const int r = mm_fasta_pack_device_async(ws, d_text, n_bytes, d_packed, packed_capacity_bytes, d_rec_base,
                                                  d_rec_text_pos, max_records, d_counts);
-        if (r) return r;
+        if (r) {
+            ws->fasta_three_once = false;
+            return r;
+        }
         MM_HIP(hipMemcpyAsync(out_counts, d_counts, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ws->stream));
         MM_HIP(hipMemcpyAsync(ws->h_total + 1, ws->total + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                               ws->stream));
