@@ -140,6 +140,12 @@ int mm_workspace_kernel_time(mm_workspace_t *ws, double *total_ms, uint64_t *lau
                              int reset);
 /* Family used by the last run (mm_path_t). */
 int mm_workspace_last_path(const mm_workspace_t *ws);
+/* Window sizes w for which the library carries a PREBUILT fused kernel (every other w <= 128 is specialised at
+ * first use, larger ones take the generic family): canonical_windows 0 / 1 selects the forward / canonical
+ * instances, reads_mode 0 / 1 the sequence-mode / reads-mode ones.  Writes up to `capacity` sizes in ascending
+ * order to `out` (may be null) and returns how many there are.  No GPU needed.  The test-suite takes its list of
+ * instances to compare with the oracle from here, so that none can ship untested. */
+int mm_prebuilt_window_sizes(int canonical_windows, int reads_mode, uint32_t *out, int capacity);
 
 /* -------------------------------------------------------------------- run */
 

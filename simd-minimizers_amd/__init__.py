@@ -105,6 +105,8 @@ def lib():
         L.mm_workspace_enable_timing.argtypes = [vp, C.c_int]
         L.mm_workspace_kernel_time.argtypes = [vp, C.POINTER(C.c_double), u64p, C.c_int]
         L.mm_workspace_last_path.argtypes = [vp]
+        L.mm_prebuilt_window_sizes.argtypes = [C.c_int, C.c_int, u32p, C.c_int]
+        L.mm_prebuilt_window_sizes.restype = C.c_int
         L.mm_run_device_async.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                           C.c_uint64, vp, vp, C.c_uint64, vp]
         L.mm_run_device.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
@@ -158,7 +160,7 @@ EXPORTED_SYMBOLS = [
     "mm_plan_create",
     "mm_plan_destroy", "mm_plan_value_len", "mm_workspace_create", "mm_workspace_destroy",
     "mm_workspace_sync", "mm_workspace_check", "mm_workspace_force_generic", "mm_workspace_set_blocks_per_lane",
-    "mm_workspace_enable_timing", "mm_workspace_kernel_time", "mm_workspace_last_path",
+    "mm_workspace_enable_timing", "mm_workspace_kernel_time", "mm_workspace_last_path", "mm_prebuilt_window_sizes",
     "mm_run_device_async", "mm_run_device", "mm_run_host", "mm_run_host_ascii",
     "mm_values_u64_device_async", "mm_values_u64_host", "mm_values_u128_device_async",
     "mm_values_u128_host", "mm_run_batch_device", "mm_run_reads_device_async", "mm_run_reads_device",
@@ -172,6 +174,15 @@ EXPORTED_SYMBOLS = [
     "mm_device_group_create", "mm_device_group_destroy", "mm_device_group_size", "mm_run_sharded_host",
     "mm_run_batch_sharded_host",
 ]
+
+
+def prebuilt_window_sizes(canonical: bool, reads: bool = False) -> list:
+    """Window sizes with a prebuilt fused kernel (mm_prebuilt_window_sizes): what the tests sweep."""
+    L = lib()
+    n = L.mm_prebuilt_window_sizes(int(canonical), int(reads), None, 0)
+    buf = (C.c_uint32 * max(1, n))()
+    L.mm_prebuilt_window_sizes(int(canonical), int(reads), buf, n)
+    return [int(x) for x in buf[:n]]
 
 
 def _check(code: int):

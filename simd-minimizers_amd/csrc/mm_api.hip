@@ -109,7 +109,12 @@ struct mm_workspace {
     uint32_t *ticket = nullptr;
     unsigned long long *total = nullptr;    // [0] running total, [1] low word = error flag of the last run,
                                             // [2] low word = sticky error flag (mm_workspace_check)
-    unsigned long long *h_total = nullptr;  // pinned copy of both words
+    unsigned long long *h_total = nullptr;  // page-locked host copy of the words: [0] total, [1] error, [2] sticky
+    unsigned long long *h_total_dev = nullptr;  // the same words as the device addresses them: the fused kernel's last
+                                                // tile stores the run's total to [0], flag_error the code to [1]
+    // look-back status words of the fused family carry the epoch of their launch (kEpochShift, mm_common.h)
+    uint32_t status_epoch = 0;    // epoch of the last tagged launch
+    bool status_dirty = true;     // the buffer may hold words that are not tagged (fresh allocation, generic family)
     bool force_ticket = false;
     bool async_unchecked = false;  // an *_async run was issued since the last mm_workspace_check
     // split path (walk + expander on a second stream): dump slots, tile status, redo list, fork / join events
@@ -184,8 +189,12 @@ int grow(T *&ptr, uint64_t &have, uint64_t need, size_t elem) {
 // the slack of grow(), so that an under-sized request cannot hide behind it.
 int grow_status(mm_workspace *ws, uint64_t need) {
     static const bool tight = getenv("MM_STATUS_TIGHT") != nullptr;
-    if (!tight) return grow(ws->status, ws->status_words, need, sizeof(unsigned long long));
+    if (!tight) {
+        if (!(need <= ws->status_words && ws->status)) ws->status_dirty = true;  // a fresh allocation holds anything
+        return grow(ws->status, ws->status_words, need, sizeof(unsigned long long));
+    }
     if (ws->status && ws->status_words == need) return MM_OK;
+    ws->status_dirty = true;
     if (ws->status) MM_HIP(hipFree(ws->status));
     ws->status = nullptr;
     ws->status_words = 0;
@@ -197,6 +206,20 @@ int grow_status(mm_workspace *ws, uint64_t need) {
     }
     ws->status = reinterpret_cast<unsigned long long *>(p);
     ws->status_words = need;
+    return MM_OK;
+}
+
+// Epoch for the next launch of the fused family on this workspace's status words (kEpochShift, mm_common.h): the
+// kernel reads every word of another epoch as "not yet", so nothing is cleared between launches.  The buffer is
+// cleared when it may hold untagged words (fresh allocation, the generic family used it) and when the epochs wrap.
+int next_status_epoch(mm_workspace *ws, uint32_t *epoch) {
+    if (ws->status_dirty || ws->status_epoch >= mm::kEpochMax) {
+        if (ws->status)
+            MM_HIP(hipMemsetAsync(ws->status, 0, ws->status_words * sizeof(unsigned long long), ws->stream));
+        ws->status_dirty = false;
+        ws->status_epoch = 0;
+    }
+    *epoch = ++ws->status_epoch;
     return MM_OK;
 }
 
@@ -438,8 +461,20 @@ int mm_workspace_create(mm_workspace_t **out, int device, void *hip_stream) {
     }
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&ws->ticket), 64);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ws->total), 64);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ws->h_total), 64, hipHostMallocDefault);
+    if (e == hipSuccess)
+        e = hipHostMalloc(reinterpret_cast<void **>(&ws->h_total), 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) {
+        memset(ws->h_total, 0, 64);
+        void *dp = nullptr;
+        e = hipHostGetDevicePointer(&dp, ws->h_total, 0);
+        ws->h_total_dev = reinterpret_cast<unsigned long long *>(dp);
+    }
     if (e == hipSuccess) e = hipMemset(ws->total, 0, 64);  // [0] total, [1] per-run error, [2] sticky error
+    if (e == hipSuccess) {
+        // [3]: where the host keeps its copy of the error word (flag_error stores the code there as well)
+        const unsigned long long host_err = (unsigned long long)reinterpret_cast<uintptr_t>(ws->h_total_dev + 1);
+        e = hipMemcpy(ws->total + 3, &host_err, sizeof(host_err), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         mm_workspace_destroy(ws);
         return hip_fail(e, "workspace allocation");
@@ -568,6 +603,10 @@ int mm_workspace_kernel_time(mm_workspace_t *ws, double *total_ms, uint64_t *lau
 
 int mm_workspace_last_path(const mm_workspace_t *ws) { return ws ? ws->last_path : 0; }
 
+int mm_prebuilt_window_sizes(int canonical_windows, int reads_mode, uint32_t *out, int capacity) {
+    return mm::fused_prebuilt_windows(canonical_windows != 0, reads_mode != 0, out, capacity < 0 ? 0 : capacity);
+}
+
 // Ambiguity bits of a PackedNSeq as they cross the ABI (null d_amb = plain PackedSeq).
 struct AmbArgs {
     const void *d_amb;
@@ -605,7 +644,14 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
                                  uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
                                  uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
                                  uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_count,
-                                 bool append, const AmbArgs *amb = nullptr) {
+                                 bool append, const AmbArgs *amb = nullptr, bool *host_total_written = nullptr) {
+    // Stream operations of one run (round 4): the fused kernel alone.  Its look-back words are epoch-tagged (no
+    // clear), a run that does not append ignores the old total (no clear), and its last tile stores the total to
+    // d_count and - for the synchronous entry points, host_total_written != null - to the page-locked host word
+    // ws->h_total[0] as well (no copies).  The split path, the generic family and empty runs keep the cleared
+    // total + copy protocol of rounds 1-3.  The per-run error word total[1] is NOT cleared here any more: the entry
+    // points that read it clear it themselves.
+    if (host_total_written) *host_total_written = false;
     if (!plan || !ws) return MM_ERR_NULL;
     if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     if (d_out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;  // src/lib.rs:339
@@ -620,7 +666,12 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
     const uint64_t l = (uint64_t)plan->k + plan->w - 1;
     const uint64_t n_w = n_bases >= l ? n_bases - l + 1 : 0;
     if (win_end > n_w) win_end = n_w;
-    if (!append) MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
+    bool total_cleared = false, count_stored = false;
+    auto clear_total = [&]() -> int {  // (families that take *total as their carry-in; with it the per-run error word)
+        if (!append && !total_cleared) MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
+        total_cleared = true;
+        return MM_OK;
+    };
     if (win_begin < win_end) {
         if (!d_packed) return MM_ERR_NULL;
         mm::RunArgs a;
@@ -652,6 +703,7 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
         a.batch_n = 0;
         a.batch_tiles = 0;
         a.work_windows = win_end - win_begin;
+        a.append = append;
         if (amb) {
             r = prepare_window_ambiguity(ws, *amb, n_bases, (uint32_t)l, win_begin, win_end, &a.wamb_dwords);
             if (r) return r;
@@ -677,6 +729,8 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
             if (tiles) {
                 r = prepare_split(ws, tiles, dump_bytes);
                 if (r) return r;
+                r = clear_total();
+                if (r) return r;
                 a.out.status = nullptr;
                 lr = mm::launch_split(a, ws->split, ws->stream);
                 split = lr == 0;
@@ -688,7 +742,16 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
             if (r) return r;
             a.out.status = ws->status;
             a.status_avail = ws->status_words;
+            r = next_status_epoch(ws, &a.status_epoch);
+            if (r) return r;
+            a.out.count_out = reinterpret_cast<unsigned long long *>(d_count);
+            a.out.total_host = host_total_written ? ws->h_total_dev : nullptr;
             lr = mm::launch_fused(a, ws->stream);
+            if (lr == 0) {
+                count_stored = d_count != nullptr;
+                if (host_total_written) *host_total_written = true;
+            }
+            a.out.count_out = a.out.total_host = nullptr;
             if (lr == -2) {
                 // no prebuilt instance and the run-time specialisation is unavailable: generic family
                 g_last_error = std::string("fused kernel unavailable, generic family used: ") +
@@ -707,7 +770,10 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
             a.scratch = ws->scratch;
             r = grow_status(ws, mm::generic_status_words(a.generic_round_windows));
             if (r) return r;
+            r = clear_total();
+            if (r) return r;
             a.out.status = ws->status;
+            ws->status_dirty = true;  // (the generic family clears and writes untagged words)
             lr = mm::launch_generic(a, ws->stream);
         }
         if (lr != 0) {
@@ -715,8 +781,11 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
             return MM_ERR_HIP;
         }
         ws->last_path = fused ? (split ? MM_PATH_SPLIT : MM_PATH_FUSED) : MM_PATH_GENERIC;
+    } else {
+        const int r = clear_total();  // an empty run: the total is what it was (append) or 0
+        if (r) return r;
     }
-    if (d_count)
+    if (d_count && !count_stored)
         MM_HIP(hipMemcpyAsync(d_count, ws->total, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
                               ws->stream));
     return MM_OK;
@@ -841,6 +910,8 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
     for (int attempt = 0; attempt < 2; ++attempt) {
         a.use_ticket = (ws->force_ticket || mm::mm_env("MM_FORCE_TICKET")) ? 1 : 0;
         a.timing_start = a.timing_stop = nullptr;
+        r = next_status_epoch(ws, &a.status_epoch);
+        if (r) return r;
         MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
         MM_HIP(hipMemsetAsync(ws->batch_offsets, 0xFF, (n_seqs + 1) * sizeof(unsigned long long), ws->stream));
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -897,6 +968,8 @@ int mm_run_batch_device(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_se
         MM_HIP(hipHostMalloc(reinterpret_cast<void **>(&h), (n_seqs + 1) * sizeof(unsigned long long),
                              hipHostMallocDefault));
         int r = MM_OK;
+        // (the runs below do not clear the per-run error word themselves)
+        if (hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream) != hipSuccess) r = MM_ERR_HIP;
         for (uint64_t s = 0; s < n_seqs && r == MM_OK; ++s) {
             r = run_device_async_impl(plan, ws, d_packed[s], packed_bytes[s],
                                       base_offsets ? base_offsets[s] : 0, n_bases[s], 0, UINT64_MAX,
@@ -906,7 +979,6 @@ int mm_run_batch_device(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_se
                                ws->stream) != hipSuccess)
                 r = MM_ERR_HIP;
         }
-        if (n_seqs == 0) MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
         hipError_t e = hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long),
                                       hipMemcpyDeviceToHost, ws->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ws->stream);
@@ -994,6 +1066,8 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
         r = grow_status(ws, mm::fused_reads_status_words(a));
         if (r) return r;
         a.out.status = ws->status;
+        r = next_status_epoch(ws, &a.status_epoch);
+        if (r) return r;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (ws->timing) {
             MM_HIP(hipEventCreate(&e0));
@@ -1150,11 +1224,20 @@ static int run_device_sync(const mm_plan_t *plan, mm_workspace_t *ws, const void
                            uint64_t capacity, uint64_t *out_count, const AmbArgs *amb) {
     if (!ws) return MM_ERR_NULL;
     for (int attempt = 0; attempt < 2; ++attempt) {
+        // One stream operation per call when the fused kernel runs: its last tile stores the total straight into the
+        // page-locked word h_total[0] and a tile that raises an error stores the code into h_total[1] (flag_error),
+        // so the host only waits for the stream.  (Rounds 1-3: two clears, the kernel, a copy - about 33 us a call.)
+        bool host_written = false;
+        ws->h_total[0] = 0;
+        ws->h_total[1] = 0;
         int r = run_device_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin,
-                                      win_end, d_out_pos, d_out_sk, capacity, nullptr, false, amb);
+                                      win_end, d_out_pos, d_out_sk, capacity, nullptr, false, amb, &host_written);
         if (r) return r;
-        MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long),
-                              hipMemcpyDeviceToHost, ws->stream));
+        if (!host_written) {
+            // (split path, generic family, empty run: the device words, cleared by the run itself)
+            MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                  ws->stream));
+        }
         MM_HIP(hipStreamSynchronize(ws->stream));
         // (1: a look-back spin ran out - workgroups were not dispatched in index order.  Redo the run
         // with tile ids taken from an atomic ticket, which defines the order itself.)
@@ -1253,6 +1336,8 @@ static int run_host_pipelined(const mm_plan_t *plan, mm_workspace_t *ws, const u
     const uint64_t chunk = (n_w + n_chunks - 1) / n_chunks;
     uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
 
+    // (the chunk runs do not clear the per-run error word themselves; every chunk's copy of it is read below)
+    MM_HIP(hipMemsetAsync(ws->total + 1, 0, sizeof(unsigned long long), ws->stream));
     uint64_t sent = 0;        // bytes already on their way to the device
     uint64_t done_total = 0;  // running total after the last drained chunk
     bool failed = false, over = false;

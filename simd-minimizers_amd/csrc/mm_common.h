@@ -71,8 +71,13 @@ struct OutParams {
     uint32_t *ticket;            // dynamic block id counter, zeroed per launch
     uint32_t *error;             // error[0]: flag of this launch (1 = a look-back spin ran out, see
                                  // lookback_exclusive; 2 = LDS layout violated; 0xbad..... = bad batch
-                                 // table), cleared per run; error[2]: the same, sticky until
-                                 // mm_workspace_check() reads it (asynchronous callers)
+                                 // table), cleared by the entry point that reads it; error[2]: the same, sticky
+                                 // until mm_workspace_check() reads it (asynchronous callers); error[4..5]: 0 or the
+                                 // device address of a page-locked HOST word that receives the code as well
+                                 // (synchronous callers of the fused kernel read it without a copy, see flag_error)
+    // fused kernel only (round 4: one stream operation per run instead of four)
+    unsigned long long *count_out = nullptr;   // optional device word: receives the run's total like *total
+    unsigned long long *total_host = nullptr;  // optional page-locked host word (device address): likewise
 };
 
 // Raise an error from a kernel: the per-launch word the synchronous entry points read, and the sticky
@@ -80,6 +85,9 @@ struct OutParams {
 __device__ __forceinline__ void flag_error(uint32_t *error, uint32_t code) {
     error[0] = code;
     error[2] = code;
+    // (rare path: the address of the host's copy of error[0] travels in device memory so that no signature changes)
+    uint32_t *host = *reinterpret_cast<uint32_t *const volatile *>(error + 4);
+    if (host) __hip_atomic_store(host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, uint32_t r) {
@@ -119,6 +127,19 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
 constexpr unsigned long long kFlagAgg = 1ull << 62;
 constexpr unsigned long long kFlagIncl = 2ull << 62;
 constexpr unsigned long long kValMask = (1ull << 62) - 1;
+// Fused kernel (round 4): bits 61..46 of a status word carry the EPOCH of the launch that wrote it and the value
+// keeps 46 bits (7e13 outputs).  A word of another epoch reads as "not yet", so the words are not cleared between
+// launches: the workspace hands every launch the next epoch and clears the buffer once per 65 535 launches (and
+// when it is reallocated or lent to a kernel family that does not tag).  Epoch 0 with a cleared buffer is the
+// untagged protocol of the other families.
+constexpr int kEpochShift = 46;
+constexpr unsigned long long kEpochValMask = (1ull << kEpochShift) - 1;
+constexpr uint32_t kEpochMax = 0xffffu;
+// flag of a status word as launch `etag` (= epoch << kEpochShift) sees it: 0 unless the word is its own
+__device__ __forceinline__ uint32_t status_flag(unsigned long long s, unsigned long long etag) {
+    const unsigned long long x = s ^ etag;
+    return ((x >> kEpochShift) & kEpochMax) == 0ull ? (uint32_t)(s >> 62) : 0u;
+}
 constexpr uint32_t kMaxLookbackSpins = 1u << 22;
 
 __device__ __forceinline__ unsigned long long ld_status(unsigned long long *p) {

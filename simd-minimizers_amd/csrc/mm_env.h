@@ -31,4 +31,17 @@ inline const char *mm_env(const char *name) {
     return it->second.set ? it->second.value.c_str() : nullptr;
 }
 
+// Switches that change RESULTS (timing experiments: MM_DEBUG, MM_JIT_DEFS, MM_FASTA_DEBUG, ...) or only serve the
+// tuning scripts exist in the experiments build alone (-DMM_EXPERIMENTS -> libsimd_minimizers_amd_exp.so, loaded by
+// tools/ and two tests through MM_LIB_PATH).  The product library never reads them: a variable leaked into a
+// caller's environment cannot change what it computes.
+inline const char *mm_exp_env(const char *name) {
+#ifdef MM_EXPERIMENTS
+    return mm_env(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 }  // namespace mm

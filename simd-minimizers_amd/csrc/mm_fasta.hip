@@ -1109,7 +1109,7 @@ int launch_fasta_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed
     if (one_pass) {
         const uint64_t oc = fasta_onepass_chunks(n_bytes);
         if (oc >= (1ull << 31)) return -1;
-        const char *de = mm_env("MM_FASTA_DEBUG");
+        const char *de = mm_exp_env("MM_FASTA_DEBUG");  // (experiments build only: wrong results by design)
         const uint32_t dbg = de ? (uint32_t)atoi(de) : 0u;
         if (hipMemsetAsync(a, 0, (oc + 1) * sizeof(unsigned long long), stream) != hipSuccess) return -1;
         hipLaunchKernelGGL(fasta_lines_kernel, dim3((uint32_t)oc), dim3(kLnThreads), 0, stream, d_text, n_bytes, a,

@@ -21,6 +21,26 @@ namespace {
 using KernelFn = FusedKernelFn;
 using Instance = FusedInstance;
 
+// MM_DEBUG (timing experiments that give WRONG RESULTS by design, and the test hook 32) exists only in the experiments
+// build of the library (-DMM_EXPERIMENTS, libsimd_minimizers_amd_exp.so): the product never reads it, and its
+// prebuilt kernels ignore FusedParams::debug (MM_DBG in mm_fused_impl.h).  In the experiments build a non-zero value
+// also routes every launch through the run-time specialisation, whose kernels are compiled with -DMM_EXPERIMENTS.
+uint32_t debug_switches() {
+#ifdef MM_EXPERIMENTS
+    const char *dbg = mm_exp_env("MM_DEBUG");
+    return dbg ? (uint32_t)atoi(dbg) : 0u;
+#else
+    return 0u;
+#endif
+}
+bool force_jit_wanted() {
+#ifdef MM_EXPERIMENTS
+    return mm_exp_env("MM_JIT_FORCE") != nullptr || debug_switches() != 0u;
+#else
+    return false;
+#endif
+}
+
 const Instance *find_instance(uint32_t w, int canonical_windows, int hasher_canonical) {
     using Getter = const Instance *(*)(int *);
     static const Getter kGroups[] = {fused_instances_a, fused_instances_b, fused_instances_c, fused_instances_d, fused_instances_e, fused_instances_f, fused_instances_g, fused_instances_h, fused_instances_i,
@@ -43,7 +63,7 @@ double emit_density(uint32_t w, uint32_t mode) {
 // Entries per lane list: 1.3 x the expected number of emitted windows + 8 (> 5 sigma on random
 // sequence; denser tiles take the in-kernel redo path).
 uint32_t list_capacity(uint32_t w, uint32_t mode, uint32_t S) {
-    static const uint32_t extra = getenv("MM_CAP_EXTRA") ? (uint32_t)atoi(getenv("MM_CAP_EXTRA")) : 0u;  // experiments
+    static const uint32_t extra = mm_exp_env("MM_CAP_EXTRA") ? (uint32_t)atoi(mm_exp_env("MM_CAP_EXTRA")) : 0u;  // experiments
     uint32_t cap = (uint32_t)(1.3 * emit_density(w, mode) * S) + 8u + extra;
     return cap > S + w ? S + w : cap;
 }
@@ -62,7 +82,7 @@ uint32_t list_capacity(uint32_t w, uint32_t mode, uint32_t S) {
 // words the host reserves and clears per tile status (kStatusStride of the prebuilt kernels; experiments
 // with run-time specialised kernels of another stride set MM_STATUS_STRIDE_HOST to at least that stride)
 uint64_t status_stride_host() {
-    static const uint64_t v = getenv("MM_STATUS_STRIDE_HOST") ? (uint64_t)atoi(getenv("MM_STATUS_STRIDE_HOST")) : kStatusStride;
+    static const uint64_t v = mm_exp_env("MM_STATUS_STRIDE_HOST") ? (uint64_t)atoi(mm_exp_env("MM_STATUS_STRIDE_HOST")) : kStatusStride;
     return v < kStatusStride ? kStatusStride : v;
 }
 
@@ -165,7 +185,7 @@ thread_local std::string t_jit_error;
 KernelRef resolve_kernel(uint32_t w, int canonical_windows, int hasher_canonical, uint32_t mode, bool sk) {
     KernelRef kr;
     if (mode > 2) return kr;
-    const bool force_jit = mm_env("MM_JIT_FORCE") != nullptr;  // tuning experiments
+    const bool force_jit = force_jit_wanted();  // tuning experiments (experiments build only)
     const Instance *inst = force_jit ? nullptr : find_instance(w, canonical_windows, hasher_canonical);
     if (inst) {
         kr.host = inst->fn[(mode == 0 && sk) ? 3 : mode];
@@ -183,7 +203,7 @@ int launch_kernel(const KernelRef &kr, uint32_t grid, uint32_t lds_bytes, hipStr
             hipFuncSetAttribute(reinterpret_cast<const void *>(kr.host),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return -1;
-        if (mm_env("MM_PRINT_OCC")) {  // occupancy experiments: what the runtime computes from the kernel's resources
+        if (mm_exp_env("MM_PRINT_OCC")) {  // occupancy experiments: what the runtime computes from the kernel's resources
             int nb = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kr.host),
                                                                (int)kFusedThreads, lds_bytes);
@@ -386,11 +406,12 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.redo_list = nullptr;
     p.redo_n = nullptr;
     p.use_ticket = a.use_ticket ? 1u : 0u;
-    {
-        const char *dbg = mm_env("MM_DEBUG");
-        p.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
-    }
-    if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (g.nblocks + 8) * status_stride_host(), stream) != hipSuccess)
+    p.debug = debug_switches();
+    p.epoch = a.status_epoch;
+    p.append = a.append ? 1u : 0u;
+    // (a tagged launch reads every word of another epoch as "not yet": nothing to clear, see kEpochShift)
+    if (a.status_epoch == 0 &&
+        hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (g.nblocks + 8) * status_stride_host(), stream) != hipSuccess)
         return -1;
     // (the ticket is only read in ticket mode: one stream operation less per run otherwise)
     if (a.use_ticket && hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
@@ -401,7 +422,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     }
     if (const char *pad = mm_env("MM_LDS_PAD")) g_lds_pad = (uint32_t)atoi(pad);  // occupancy experiments
     p.trace = nullptr;
-    if (const char *tr = mm_env("MM_TRACE")) {
+    if (const char *tr = mm_exp_env("MM_TRACE")) {
         // timing experiment: per-tile timestamps dumped to the file MM_TRACE (synchronous)
         unsigned long long *d_tr = nullptr;
         const size_t bytes = sizeof(unsigned long long) * 10 * g.nblocks;
@@ -432,7 +453,7 @@ namespace {
 KernelRef resolve_walk_kernel(uint32_t w, int canonical_windows, int hasher_canonical, uint32_t mode, bool sk) {
     KernelRef kr;
     if (mode > 2) return kr;
-    const bool force_jit = mm_env("MM_JIT_FORCE") != nullptr;
+    const bool force_jit = force_jit_wanted();
     int n = 0;
     const WalkInstance *inst = walk_instances(&n);
     for (int i = 0; i < n && !force_jit; ++i)
@@ -504,10 +525,9 @@ int launch_split(const RunArgs &a, const SplitBuffers &b, hipStream_t stream) {
     p.batch_n = a.batch_n;
     p.out = a.out;
     p.use_ticket = 0;
-    {
-        const char *dbg = mm_env("MM_DEBUG");
-        p.debug = dbg ? (uint32_t)atoi(dbg) : 0u;
-    }
+    p.debug = debug_switches();
+    p.epoch = 0;
+    p.append = 1;  // (the redo pass takes its offsets from the redo list; the walk itself has no look-back)
     p.trace = nullptr;
     p.dump = b.dump;
     p.dump_stride = stride;
@@ -548,7 +568,7 @@ int launch_split(const RunArgs &a, const SplitBuffers &b, hipStream_t stream) {
     if (r) return r;
     // timing experiments: MM_SPLIT_SERIAL=1 starts the expander only when the walk has finished (each kernel
     // alone on the chip), MM_SPLIT_NO_EXPAND=1 leaves it out (wrong results: the walk and its dump alone)
-    static const bool serial = getenv("MM_SPLIT_SERIAL") != nullptr, no_expand = getenv("MM_SPLIT_NO_EXPAND") != nullptr;
+    static const bool serial = mm_exp_env("MM_SPLIT_SERIAL") != nullptr, no_expand = mm_exp_env("MM_SPLIT_NO_EXPAND") != nullptr;
     if (serial) {
         if (hipEventRecord(b.ev_fork, stream) != hipSuccess) return -1;
         if (hipStreamWaitEvent(b.aux, b.ev_fork, 0) != hipSuccess) return -1;
@@ -558,7 +578,7 @@ int launch_split(const RunArgs &a, const SplitBuffers &b, hipStream_t stream) {
     if (hipStreamWaitEvent(stream, b.ev_join, 0) != hipSuccess) return -1;
     // tiles whose lists overflowed (low-complexity sequence): walked again by the fused kernel in redo mode,
     // one workgroup per entry of the redo list (the grid covers the worst case; the others exit at once)
-    static const bool no_redo = getenv("MM_SPLIT_NO_REDO") != nullptr;  // timing experiment
+    static const bool no_redo = mm_exp_env("MM_SPLIT_NO_REDO") != nullptr;  // timing experiment
     if (!no_redo) {
         p.redo_list = reinterpret_cast<const RedoEntry *>(b.redo_list);
         r = launch_kernel(redo_kr, (uint32_t)g.nblocks, g.lds_bytes, stream, p, nullptr, nullptr);
@@ -586,6 +606,18 @@ const FusedReadsInstance *find_reads_instance(uint32_t w, int canonical_windows,
     return nullptr;
 }
 }  // namespace
+
+int fused_prebuilt_windows(bool canonical, bool reads, uint32_t *out, int capacity) {
+    int n = 0;
+    for (uint32_t w = 1; w <= kJitMaxW; ++w) {
+        const bool have = reads ? find_reads_instance(w, canonical, canonical) != nullptr
+                                : find_instance(w, canonical, canonical) != nullptr;
+        if (!have) continue;
+        if (out && n < capacity) out[n] = w;
+        ++n;
+    }
+    return n;
+}
 
 bool fused_reads_supported(uint32_t w, int canonical_windows, int hasher_canonical, uint32_t mode) {
     if (mode > 2) return false;
@@ -653,6 +685,8 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.list_cap = cap;
     p.use_ticket = a.use_ticket ? 1u : 0u;
     p.debug = 0;
+    p.epoch = a.status_epoch;
+    p.append = 0;
     p.n_reads = (uint32_t)a.n_reads;
     p.reads_per_lane = R;
     p.read_stride = a.read_stride;
@@ -672,7 +706,8 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.redo_list = nullptr;
     p.redo_n = nullptr;
     p.out = a.out;
-    if (hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (nblocks + 8) * status_stride_host(), stream) != hipSuccess)
+    if (a.status_epoch == 0 &&
+        hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (nblocks + 8) * status_stride_host(), stream) != hipSuccess)
         return -1;
     // (the ticket is only read in ticket mode: one stream operation less per run otherwise)
     if (a.use_ticket && hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;

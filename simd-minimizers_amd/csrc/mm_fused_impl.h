@@ -74,6 +74,13 @@
 
 namespace mm {
 
+// MM_DEBUG switches (wrong results by design) exist only in kernels compiled with -DMM_EXPERIMENTS
+#ifdef MM_EXPERIMENTS
+#define MM_DBG(p) ((p).debug)
+#else
+#define MM_DBG(p) 0u
+#endif
+
 constexpr size_t kStatusStride = MM_STATUS_STRIDE;
 
 // Byte distance between consecutive entries of one lane's list: 258 u16 slots per plane
@@ -106,9 +113,12 @@ struct FusedParams {
     uint32_t win_end;
     uint32_t list_cap;   // entries per lane list
     uint32_t use_ticket; // 1: tile id from an atomic ticket (safe mode), 0: blockIdx.x
-    uint32_t debug;      // timing experiments only (MM_DEBUG env): 1 no look-back, 2 no copy-out,
-                         // 4 no phase 1, 8 copy-out without stores, 16 half-size lists, 32 test hook:
-                         // tile 0 reports a look-back time-out
+    uint32_t debug;      // timing experiments (MM_DEBUG env; read only by kernels compiled with -DMM_EXPERIMENTS,
+                         // i.e. by the experiments library's run-time specialisation - the product's kernels ignore
+                         // it): 1 no look-back, 2 no copy-out, 4 no phase 1, 8 copy-out without stores, 16 half-size
+                         // lists, 32 test hook: tile 0 reports a look-back time-out
+    uint32_t epoch;      // tag of this launch's look-back status words (kEpochShift, mm_common.h); 0: cleared words
+    uint32_t append;     // 1: *out.total holds the outputs before this launch (carry-in of tile 0), 0: starts at 0
     // reads mode (READS kernels): one lane per read, reads at a fixed stride in the buffer
     uint32_t n_reads;
     uint32_t reads_per_lane;            // READS: consecutive reads one lane walks one after the other (1..4)
@@ -1133,8 +1143,9 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
 // a no-progress round of lookback_overlapped sleeps up to 64 x 3.5 us: give up after about a second
 constexpr uint32_t kMaxIdleRounds = 1u << 12;
 
-__device__ __forceinline__ void publish_aggregate(unsigned long long *status, uint32_t bid, uint32_t total) {
-    st_status(&status[(size_t)bid * kStatusStride], kFlagAgg | ((unsigned long long)total & kValMask));
+__device__ __forceinline__ void publish_aggregate(unsigned long long *status, uint32_t bid, uint32_t total,
+                                                  unsigned long long etag) {
+    st_status(&status[(size_t)bid * kStatusStride], kFlagAgg | etag | (unsigned long long)total);
 }
 
 // Look-back of a tile run by wave 0 alone while the other waves of the workgroup may still be in
@@ -1142,11 +1153,13 @@ __device__ __forceinline__ void publish_aggregate(unsigned long long *status, ui
 // publishes the tile's aggregate itself).  The wave scans the predecessors without blocking on the
 // nearest missing one, consumes what is there (nearest first), and publishes the inclusive prefix
 // when the prefix and the tile's own total are both known.
-// Status words and bounds as in lookback_exclusive (mm_common.h).  Returns the exclusive prefix.
+// Status words and bounds as in lookback_exclusive (mm_common.h), tagged with the launch's epoch (`etag`, see
+// kEpochShift: a word of another launch reads as "not yet").  Returns the exclusive prefix.
 template <int SLEEP>
 __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long long *status, uint32_t bid,
                                                                   unsigned long long carry_in, uint32_t *error,
-                                                                  uint32_t *done, const uint32_t *wave_tot) {
+                                                                  uint32_t *done, const uint32_t *wave_tot,
+                                                                  const unsigned long long etag) {
     const int lane = threadIdx.x & (kWave - 1);
     bool have_excl = (bid == 0);
     unsigned long long excl = (bid == 0) ? carry_in : 0ull;
@@ -1157,13 +1170,14 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
         bool progress = false;
         if (!have_excl) {
             const long long idx = j - lane;
-            const unsigned long long s = idx >= 0 ? ld_status(&status[(size_t)idx * kStatusStride]) : kFlagIncl;
-            const unsigned long long zmask = __ballot((s >> 62) == 0);
-            const unsigned long long pmask = __ballot((s >> 62) == 2);
+            const unsigned long long s = idx >= 0 ? ld_status(&status[(size_t)idx * kStatusStride]) : (kFlagIncl | etag);
+            const uint32_t fl = status_flag(s, etag);
+            const unsigned long long zmask = __ballot(fl == 0);
+            const unsigned long long pmask = __ballot(fl == 2);
             const int first_zero = zmask ? __builtin_ctzll(zmask) : kWave;
             const int first_p = pmask ? __builtin_ctzll(pmask) : kWave;
             const int take = first_p < first_zero ? first_p + 1 : first_zero;  // lanes [0, take) count
-            unsigned long long v = lane < take ? (s & kValMask) : 0ull;
+            unsigned long long v = lane < take ? (s & kEpochValMask) : 0ull;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
             excl += v;
@@ -1199,106 +1213,22 @@ __device__ __forceinline__ unsigned long long lookback_overlapped(unsigned long 
                     if (lane == 0) s0 = ld_status(&status[(size_t)j * kStatusStride]);
                     s0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(s0 >> 32)) << 32) |
                          (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)s0);
-                    if ((s0 >> 62) != 0) break;
+                    if (status_flag(s0, etag) != 0) break;
                 }
             } else {
                 __builtin_amdgcn_s_sleep(MM_LB_SLEEP_SHORT);
             }
         }
     }
-    if (lane == 0) st_status(&status[(size_t)bid * kStatusStride], kFlagIncl | ((excl + block_total) & kValMask));
+    if (lane == 0)
+        st_status(&status[(size_t)bid * kStatusStride], kFlagIncl | etag | ((excl + block_total) & kEpochValMask));
     return excl;
 }
 
-// One-round-trip look-back (round 2).  Every tile publishes its count (count + 1, one 4-byte word;
-// 0 = not yet); the tiles are grouped in chunks of 1024, and the output offset of a tile is the base
-// of its chunk + the counts of the tiles before it in the chunk: at most 1023 INDEPENDENT loads, 16
-// per lane of the look-back wave, all in flight together - instead of a chain of dependent 64-wide
-// hops back to the nearest tile that already knows its own offset (lookback_overlapped above).  The
-// base of chunk c + 1 is published by the last tile of chunk c.
-// MEASURED SLOWER than the chain in this kernel (3.1 Gbp, MI355X: canonical k=21 w=11 1.88 against
-// 1.85 ms, forward 1.41 against 1.35 ms): both have to wait until every earlier tile has finished its
-// walk, and the chain waits for that with ONE lane polling ONE word, where this one keeps re-reading
-// whatever is missing.  Compiled only with -DMM_LB_CHUNKED (A/B through MM_JIT_DEFS).
-constexpr uint32_t kLbChunk = 1024;
-constexpr unsigned long long kLbBaseValid = 1ull << 63;
-#ifndef MM_LB_POLL_SLEEP
-#define MM_LB_POLL_SLEEP 24
-#endif
-__device__ __forceinline__ uint32_t *lb_counts(unsigned long long *status) { return reinterpret_cast<uint32_t *>(status); }
-__device__ __forceinline__ unsigned long long *lb_bases(unsigned long long *status, uint32_t n_tiles) {
-    return status + ((n_tiles + 1u) >> 1);
-}
-__device__ __forceinline__ void publish_count(unsigned long long *status, uint32_t bid, uint32_t total) {
-    __hip_atomic_store(&lb_counts(status)[bid], total + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long lookback_chunked(unsigned long long *status, uint32_t bid, uint32_t n_tiles,
-                                                               unsigned long long carry_in, uint32_t *error,
-                                                               uint32_t *done, const uint32_t *wave_tot) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const uint32_t chunk = bid / kLbChunk, g = bid % kLbChunk;
-    uint32_t *cnt = lb_counts(status) + (size_t)chunk * kLbChunk;
-    constexpr int NL = 8;
-    uint32_t sum = 0;
-    for (uint32_t i0 = 0; i0 < g; i0 += (uint32_t)(kWave * NL)) {
-        uint32_t v[NL];
-#pragma unroll
-        for (int u = 0; u < NL; ++u) {
-            const uint32_t idx = i0 + (uint32_t)(kWave * u) + (uint32_t)lane;
-            v[u] = idx < g ? __hip_atomic_load(&cnt[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
-        }
-        for (uint32_t spins = 0;; ++spins) {
-            bool missing = false;
-#pragma unroll
-            for (int u = 0; u < NL; ++u) missing = missing || v[u] == 0u;
-            if (__ballot(missing) == 0ull) break;
-            if (spins > kMaxIdleRounds * 16u) {
-                flag_error(error, 1u);  // dispatch-order violation: the host redoes the launch in ticket mode
-                break;
-            }
-            __builtin_amdgcn_s_sleep(MM_LB_POLL_SLEEP);
-#pragma unroll
-            for (int u = 0; u < NL; ++u) {
-                const uint32_t idx = i0 + (uint32_t)(kWave * u) + (uint32_t)lane;
-                if (v[u] == 0u) v[u] = __hip_atomic_load(&cnt[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NL; ++u) sum += v[u] == 0u ? 0u : v[u] - 1u;
-    }
-    const uint32_t before = __builtin_amdgcn_readlane(wave_scan_dpp(sum), kWave - 1);
-    unsigned long long base = carry_in;
-    if (chunk != 0) {
-        unsigned long long s0 = 0;
-        for (uint32_t spins = 0;; ++spins) {
-            if (lane == 0) s0 = ld_status(&lb_bases(status, n_tiles)[chunk]);
-            s0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(s0 >> 32)) << 32) |
-                 (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)s0);
-            if (s0 & kLbBaseValid) break;
-            if (spins > kMaxIdleRounds * 16u) {
-                flag_error(error, 1u);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(MM_LB_POLL_SLEEP);
-        }
-        base = s0 & ~kLbBaseValid;
-    }
-    const unsigned long long excl = base + before;
-    if (g == kLbChunk - 1u && bid + 1u < n_tiles) {
-        // the last tile of a chunk owes the next chunk its base: wait for the other waves of this tile
-        uint32_t block_total = 0;
-        for (uint32_t spins = 0;; ++spins) {
-            const uint32_t dn = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t *>(done));
-            if (dn == (uint32_t)kFusedWaves) break;
-            if (spins > (1u << 24)) break;
-            __builtin_amdgcn_s_sleep(4);
-        }
-#pragma unroll
-        for (int v = 0; v < kFusedWaves; ++v) block_total += reinterpret_cast<const volatile uint32_t *>(wave_tot)[v];
-        if (lane == 0) st_status(&lb_bases(status, n_tiles)[chunk + 1u], kLbBaseValid | (excl + block_total));
-    }
-    return excl;
-}
+// (A one-round-trip look-back - per-tile counts in chunks of 1024 + a per-chunk base, up to 1023 independent loads
+// per tile instead of a chain of 64-wide hops - was built in round 2 and measured slower twice, 1.88 / 1.41 ms against
+// 1.85 / 1.35 and 1.723 against 1.698: both wait for the same event, and the chain waits with ONE lane polling ONE
+// word.  Removed in round 4; DESIGN.md appendix A.)
 
 // Phase 2, the copy-out of one wave: the 64 lists of its lanes (LDS, entry c of lane t at c * stride + eb * t)
 // go to the output in lane order (= window order) from slot run0 on.  `vbt` = value of list entry 0 of the
@@ -1546,7 +1476,6 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     __shared__ uint32_t s_done;  // waves 1.. that have finished phase 1
     __shared__ uint32_t s_wave_tot[kFusedWaves];
     __shared__ unsigned long long s_excl;
-    __shared__ unsigned long long s_carry;  // outputs before this launch (append mode), read before any tile ends
 
     // kernels that also carry the skip-ambiguous walk: canonical windows, positions only (the
     // reference offers run_skip_ambiguous_windows on canonical builders without super-k-mers,
@@ -1570,7 +1499,6 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         st_end = max(st_end, lds_end(&s_done, sizeof(s_done)));
         st_end = max(st_end, lds_end(s_wave_tot, sizeof(s_wave_tot)));
         st_end = max(st_end, lds_end(&s_excl, sizeof(s_excl)));
-        st_end = max(st_end, lds_end(&s_carry, sizeof(s_carry)));
         if ((uint32_t)reinterpret_cast<uintptr_t>(smem) < st_end) {
             if (tid == 0) flag_error(p.out.error, 2u);
             return;
@@ -1588,16 +1516,16 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         s_bid = redo ? p.redo_list[blockIdx.x].tile : (p.use_ticket ? atomicAdd(p.out.ticket, 1u) : blockIdx.x);
         s_overflow = redo ? 1u : 0u;
         s_done = 0;
-        s_carry = *p.out.total;
     }
     if (tid < 16) s_tab[tid] = p.ht.t_in_out[tid];
     else if (tid < 20) s_tab[tid] = p.ht.t_in[tid - 16];
     else if (tid < 36) s_tab[tid] = p.ht.t_in2[tid - 20];
     __syncthreads();
     const uint32_t bid = __builtin_amdgcn_readfirstlane(s_bid);  // keep tile scalars in SGPRs
+    const unsigned long long etag = (unsigned long long)p.epoch << kEpochShift;
     // test hook (MM_DEBUG=32): report a look-back time-out although none happened, so that the error
     // plumbing of the asynchronous entry points (mm_workspace_check) can be exercised
-    if ((p.debug & 32u) && bid == 0 && tid == 0) flag_error(p.out.error, 1u);
+    if ((MM_DBG(p) & 32u) && bid == 0 && tid == 0) flag_error(p.out.error, 1u);
     if (p.trace && tid == 0) {
         uint32_t hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -1698,7 +1626,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
             set_min_rem(act);
             ctx.list_used = my_count;
             uint32_t c = 0;
-            if (act && !(p.debug & 4u)) {
+            if (act && !(MM_DBG(p) & 4u)) {
                 bool over = false;
                 const uint32_t tot = (kAmbi && p.wamb)
                                          ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi, kE8>(p, ctx, over)
@@ -1722,7 +1650,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         set_min_rem(lane_active);
         if (redo) {
             my_count = reinterpret_cast<const uint16_t *>(p.dump + (size_t)bid * p.dump_stride)[tid];
-        } else if (lane_active && !(p.debug & 4u)) {
+        } else if (lane_active && !(MM_DBG(p) & 4u)) {
             bool over = false;
             if (kAmbi && p.wamb)
                 my_count = (partial || !kTwoBodies<W>)
@@ -1745,38 +1673,23 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         s_wave_tot[wave] = wave_total;
         // LDS, in order behind the store above.  The wave that finishes phase 1 last publishes the
         // tile's aggregate at once (successors wait for that, never for this tile's look-back).
-#ifndef MM_LB_CHUNKED
-        if (atomicAdd(&s_done, 1u) == (uint32_t)(kFusedWaves - 1) && bid != 0 && !(p.debug & 1u) && !redo) {
+        if (atomicAdd(&s_done, 1u) == (uint32_t)(kFusedWaves - 1) && bid != 0 && !(MM_DBG(p) & 1u) && !redo) {
             uint32_t tot = 0;
 #pragma unroll
             for (int v = 0; v < kFusedWaves; ++v) tot += reinterpret_cast<volatile uint32_t *>(s_wave_tot)[v];
-            publish_aggregate(p.out.status, bid, tot);
+            publish_aggregate(p.out.status, bid, tot, etag);
         }
-#else
-        if (atomicAdd(&s_done, 1u) == (uint32_t)(kFusedWaves - 1) && !(p.debug & 1u)) {
-            uint32_t tot = 0;
-#pragma unroll
-            for (int v = 0; v < kFusedWaves; ++v) tot += reinterpret_cast<volatile uint32_t *>(s_wave_tot)[v];
-            publish_count(p.out.status, bid, tot);
-        }
-#endif
     }
     if (wave == 0) {
         // Wave 0 runs the look-back (non-blocking, see lookback_overlapped) as soon as its own lanes
         // are done; the wave that finishes last has published the tile's aggregate.
-#ifndef MM_LB_CHUNKED
-        const unsigned long long carry = (bid == 0) ? *p.out.total : 0ull;
+        // (the outputs before this launch are read only by appending runs: a run that starts at 0 needs no cleared word)
+        const unsigned long long carry = (bid == 0 && p.append) ? *p.out.total : 0ull;
         const unsigned long long ex =
             redo ? p.redo_list[blockIdx.x].prefix
-                 : ((p.debug & 1u) ? (unsigned long long)bid * (NB / 6u)
+                 : ((MM_DBG(p) & 1u) ? (unsigned long long)bid * (NB / 6u)
                                    : lookback_overlapped<(CANON ? MM_LB_SLEEP_CANON : MM_LB_SLEEP)>(
-                                         p.out.status, bid, carry, p.out.error, &s_done, s_wave_tot));
-#else
-        const unsigned long long carry = s_carry;  // base of chunk 0: every tile of that chunk needs it
-        const unsigned long long ex =
-            (p.debug & 1u) ? (unsigned long long)bid * (NB / 6u)
-                           : lookback_chunked(p.out.status, bid, gridDim.x, carry, p.out.error, &s_done, s_wave_tot);
-#endif
+                                         p.out.status, bid, carry, p.out.error, &s_done, s_wave_tot, etag));
         if (lane == 0) s_excl = ex;
         if (p.trace && lane == 0) p.trace[10 * (size_t)bid + 2] = wall_clock64();
     }
@@ -1789,7 +1702,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         if (v < wave) wave_base += t;
         block_total += t;
     }
-    const bool overflow = s_overflow != 0 && !(p.debug & 16u);  // 16: timing experiment with half-size lists
+    const bool overflow = s_overflow != 0 && !(MM_DBG(p) & 16u);  // 16: timing experiment with half-size lists
     const unsigned long long run0 = s_excl + wave_base;  // first output slot of this wave
     const uint32_t excl = incl - my_count;
     if (READS) {
@@ -1802,7 +1715,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     if (batch && tid == 0 && local_tile == 0 && !redo) p.batch_offsets[batch_s] = s_excl;
 
     if (!overflow) {
-        copy_out_wave<kE8, SK, READS>(smem, p.out, p.debug, wave, lane,
+        copy_out_wave<kE8, SK, READS>(smem, p.out, MM_DBG(p), wave, lane,
                                       (READS ? 0u : (uint32_t)bw0) - (MODE == 0 ? 1u : 0u), S, (uint32_t)kSkShift<W>,
                                       run0, wave_total, my_count, excl);
     } else if (READS) {
@@ -1832,6 +1745,10 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     }
     if (tid == 0 && bid == gridDim.x - 1 && !redo) {
         *p.out.total = s_excl + block_total;
+        // (the caller's count word and the host's page-locked copy, so that a run costs ONE stream operation)
+        if (p.out.count_out) *p.out.count_out = s_excl + block_total;
+        if (p.out.total_host)
+            __hip_atomic_store(p.out.total_host, s_excl + block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (READS) p.read_offsets[p.n_reads] = s_excl + block_total;
         if (batch) p.batch_offsets[p.batch_n] = s_excl + block_total;
     }
@@ -1923,7 +1840,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS_WALK) void walk_kernel
         {
             // ------------------------------------------------------------ the walk, into the lane lists
             uint32_t my_count = 0;
-            if (lane_active && !(p.debug & 4u)) {
+            if (lane_active && !(MM_DBG(p) & 4u)) {
                 bool over = false;
                 if (kAmbi && p.wamb)
                     my_count = (partial || !kTwoBodies<W>)

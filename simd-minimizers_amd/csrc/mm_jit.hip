@@ -131,8 +131,11 @@ bool compile(const std::string &name, std::vector<char> &code, std::string &lowe
     }
     hiprtcAddNameExpression(prog, name.c_str());
     const std::string threads = "-DMM_FUSED_THREADS=" + std::to_string(kFusedThreads);
-    std::vector<std::string> extra;  // MM_JIT_DEFS: extra -D options (tuning experiments)
-    if (const char *d = mm_env("MM_JIT_DEFS")) {
+    std::vector<std::string> extra;  // MM_JIT_DEFS: extra -D options (tuning experiments; experiments build only)
+#ifdef MM_EXPERIMENTS
+    extra.push_back("-DMM_EXPERIMENTS");  // (kernels that read FusedParams::debug)
+#endif
+    if (const char *d = mm_exp_env("MM_JIT_DEFS")) {
         std::string cur;
         for (const char *c = d;; ++c) {
             if (*c == ' ' || *c == '\0') {
@@ -200,7 +203,13 @@ hipFunction_t jit_fused_kernel(uint32_t w, bool canon, bool hash_rc, int mode, b
         return nullptr;
     }
     const std::string name = fused_kernel_name(w, canon, hash_rc, mode, sk, reads, walk);
-    const char *defs = mm_env("MM_JIT_DEFS");
+    const char *user_defs = mm_exp_env("MM_JIT_DEFS");
+#ifdef MM_EXPERIMENTS
+    const std::string defs_s = std::string("-DMM_EXPERIMENTS ") + (user_defs ? user_defs : "");
+    const char *defs = defs_s.c_str();
+#else
+    const char *defs = user_defs;  // (always null: the product compiles the source as it is)
+#endif
     const std::string key = std::to_string(device) + ":" + name + "|" + (defs ? defs : "");
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_functions.find(key);

@@ -31,6 +31,11 @@ struct RunArgs {
     uint64_t work_windows;  // windows of the whole run (0 = unknown): short runs get shorter lanes (more tiles)
     int use_ticket; // tile ids from an atomic ticket instead of blockIdx.x (safe mode)
     uint64_t status_avail = 0;  // 8-byte words allocated behind out.status (0 = not known to the launcher)
+    // Epoch tag of this launch's look-back status words (fused family; kEpochShift in mm_common.h).  Non-zero: the
+    // caller guarantees that no word behind out.status carries this tag yet, and the launcher clears nothing.
+    // 0: the launcher clears the words it uses (the protocol of rounds 1-3).
+    uint32_t status_epoch = 0;
+    bool append = false;        // *out.total holds the outputs before this launch (else the run starts at 0)
     // generic path
     void *scratch;
     uint64_t generic_round_windows;
@@ -52,6 +57,8 @@ uint32_t fused_batch_nblk(const RunArgs &a, const uint64_t *n_windows, uint64_t 
 // fused_unavailable_reason() says why)
 int launch_fused(const RunArgs &a, hipStream_t stream);
 const char *fused_unavailable_reason();
+// window sizes with a prebuilt instance (sequence mode / reads mode), ascending; returns their number
+int fused_prebuilt_windows(bool canonical, bool reads, uint32_t *out, int capacity);
 
 // ---- split path of the fused family (walk_kernel in mm_fused_impl.h + mm_split.hip): the walk dumps its lists
 // and exits, persistent expander workgroups on a second stream turn them into positions
@@ -89,6 +96,7 @@ struct ReadsArgs {
     uint32_t wamb_dwords;
     OutParams out;
     int use_ticket;
+    uint32_t status_epoch = 0;  // as in RunArgs
     hipEvent_t timing_start, timing_stop;
 };
 bool fused_reads_supported(uint32_t w, int canonical_windows, int hasher_canonical, uint32_t mode = 0);

@@ -8,12 +8,21 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-PREBUILT_W = list(range(1, 17)) + list(range(17, 34, 2)) + [41, 51]
+_PREBUILT = {}
+
+
+def _prebuilt(canonical):
+    """window sizes with a prebuilt instance, from the library itself (mm_prebuilt_window_sizes)"""
+    if canonical not in _PREBUILT:
+        import simd_minimizers_amd as sm
+        _PREBUILT[canonical] = sm.prebuilt_window_sizes(canonical)
+        assert len(_PREBUILT[canonical]) >= 35
+    return _PREBUILT[canonical]
 
 
 def _plan(rng):
-    w = int(rng.choice(PREBUILT_W))
     canonical = bool(rng.integers(0, 2))
+    w = int(rng.choice(_prebuilt(canonical)))
     mode = int(rng.choice([0, 0, 0, 1, 2]))
     if mode == 2 and w % 2 == 0:
         mode = 1

@@ -73,9 +73,11 @@ def test_model_anchors_1mbp(sm, oracle, gpu):
 
 
 # ------------------------------------------------------------------- sweeps
-# window sizes with a fused-kernel instance (mm_fused_inst_*.hip): 1..16, odd 17..33, 41, 51
-FUSED_W = {True: [1, 2, 3, 4, 5, 7, 8, 11, 12, 16, 17, 19, 31, 33, 41, 51],
-           False: [1, 2, 3, 4, 5, 7, 8, 11, 13, 16, 17, 19, 31, 33, 41, 51]}
+# Window sizes with a prebuilt fused-kernel instance come from the LIBRARY (mm_prebuilt_window_sizes), so that an
+# instance cannot ship without being compared with the oracle.  The sizes below get the full
+# list of k; the others a shorter one (every size still runs every length and slice offset of the sweep).
+DEEP_W = {True: [1, 2, 3, 4, 5, 7, 8, 11, 12, 16, 17, 19, 31, 33, 41, 51],
+          False: [1, 2, 3, 4, 5, 7, 8, 11, 13, 16, 17, 19, 31, 33, 41, 51]}
 
 
 def _sweep_inputs(rng, oracle, sm):
@@ -94,12 +96,15 @@ def test_sweep_minimizers(sm, oracle, gpu, canonical, force_generic):
     ks = [1, 2, 3, 4, 5, 21, 31, 32, 33, 63, 64, 65] + [int(x) for x in rng.integers(6, 100, size=3)]
     ws = [1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65] + [int(x) for x in rng.integers(6, 100, size=3)]
     if not force_generic:
-        ws = FUSED_W[canonical]
+        ws = sm.prebuilt_window_sizes(canonical)
+        assert set(DEEP_W[canonical]) <= set(ws) and len(ws) >= 35
     gpu.force_generic(force_generic)
     try:
         for k in ks:
             for w in ws:
                 if canonical and (k + w - 1) % 2 == 0:
+                    continue
+                if not force_generic and w not in DEEP_W[canonical] and k not in (1, 2, 5, 21, 32, 64, 65):
                     continue
                 b = _builder(sm, k, w, canonical, 0)
                 for ps, data, off, n in _sweep_inputs(rng, oracle, sm):
@@ -679,7 +684,6 @@ def test_maximum_length(sm, oracle, gpu):
     assert code == sm.ERR["LEN_TOO_LARGE"]
 
 
-FUSED_W_ALL = list(range(1, 17)) + list(range(17, 34, 2)) + [41, 51]
 
 
 def _check_reads(sm, oracle, k, w, canonical, mode, n_reads, stride, read_len, lens, base_offset, seed):
@@ -751,7 +755,7 @@ def test_reads_mode(sm, oracle, gpu):
         del os.environ["MM_JIT"]
     # every window size with an instance
     for canonical in (True, False):
-        for w in FUSED_W_ALL:
+        for w in sm.prebuilt_window_sizes(canonical, reads=True):
             k = 20 if (canonical and w % 2 == 0) else 21
             _check_reads(sm, oracle, k, w, canonical, 0, 300, 153, 151, None, 1, 10 + w)
             assert gpu.last_path() == 1

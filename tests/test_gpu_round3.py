@@ -163,25 +163,8 @@ def test_status_words_cover_the_tuned_grid(sm, gpu):
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_sticky_error_cleared_by_synchronous_redo(sm, oracle, gpu, monkeypatch):
-    """a look-back time-out that a synchronous entry point repeats itself must not come back
-    from the next mm_workspace_check()."""
-    import torch
-    n, k, w = 1_000_003, 21, 11
-    data = oracle.gen_packed(8, n)
-    want = oracle.run(data, n, k, w, canonical=True)
-    d = torch.from_numpy(data).cuda()
-    out = torch.zeros(n // 3, dtype=torch.int32, device="cuda")
-    ws = sm.Workspace(0, torch.cuda.current_stream().cuda_stream)
-    b = sm.canonical_minimizers(k, w).workspace(ws)
-    monkeypatch.setenv("MM_DEBUG", "32")  # tile 0 reports a time-out: the run is repeated in ticket mode, where
-    with pytest.raises(sm.MinimizerError):  # the hook fires again -> a loud failure, never a silent one
-        b.run_device(d, n, out)
-    monkeypatch.delenv("MM_DEBUG")
-    c = b.run_device(d, n, out)
-    assert c == len(want) and np.array_equal(_dev(out, c), want)
-    ws.check()  # nothing asynchronous happened on this workspace: the word the redo raised is gone
-    ws.close()
+# (test_sticky_error_cleared_by_synchronous_redo: part of tests/test_gpu_round2.py::test_async_status_is_observable
+# since round 4 - the MM_DEBUG=32 hook lives in the experiments build, which that test loads in a child process)
 
 
 def test_fasta_packer_refuses_fastq(sm, gpu):

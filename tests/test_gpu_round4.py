@@ -1,0 +1,281 @@
+"""Round-4 GPU tests (all through the C ABI, bit-exact against the oracle):
+
+* every PREBUILT kernel binary - each window size the library reports, canonical and forward, the four flavours
+  (minimizers, closed / open syncmers, minimizers + super-k-mer indices) and the reads-mode instances - on an input
+  of several tiles with a ragged last one (shape of src/test.rs:18-51);
+* tie-heavy sequences (two-letter alphabets, tandem repeats with mutations, homopolymer runs): the lazy strand
+  vote's slow path and the list-overflow redo, against the oracle, with window ranges that end inside tiles
+  (was tools/gpu_vote_stress.py);
+* the one-pass FASTA packer against the three-pass kernels on random texts
+  (was tools/gpu_fasta_stress.py);
+* the epoch-tagged look-back words (no clears between launches): interleaved geometries, plans and entry points on
+  ONE workspace, and the wrap of the 16-bit epoch;
+* one stream operation per run: counts through the kernel's own stores (device word and page-locked host word).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(out, c):
+    return out[:c].cpu().numpy().view(np.uint32)
+
+
+def _range_expect(oracle, data, n, k, w, canonical, a, e):
+    """positions a run over windows [a, e) returns: the per-window stream of that range, deduplicated against the
+    window before it (src/collect.rs:265-271 applied at the seam)"""
+    per_window = oracle.window_positions(data, n, k, w, oracle.default_hasher(canonical), canonical)
+    sub = per_window[a:e]
+    keep = np.ones(len(sub), dtype=bool)
+    keep[1:] = sub[1:] != sub[:-1]
+    if a > 0 and len(sub):
+        keep[0] = sub[0] != per_window[a - 1]
+    return sub[keep]
+
+
+def test_every_prebuilt_instance_vs_oracle(sm, oracle, gpu):
+    import torch
+    n = 250_007  # a few tiles of every geometry and a ragged last one
+    data = oracle.gen_packed(77, n + 64)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    sk = torch.zeros(n, dtype=torch.int32, device="cuda")
+    checked = 0
+    for canonical in (True, False):
+        sizes = sm.prebuilt_window_sizes(canonical)
+        assert len(sizes) >= 35
+        for w in sizes:
+            k = 20 if (canonical and w % 2 == 0) else 21
+            for mode in (0, 1, 2):
+                if mode == 2 and w % 2 == 0:
+                    continue  # open syncmers need odd w (src/syncmers.rs:24-29)
+                b = sm.Builder(k, w, canonical, mode)
+                want = oracle.run(data, n, k, w, canonical=canonical, mode=mode, base_offset=1)
+                c = b.run_device(d, n, out, base_offset=1)
+                assert gpu.last_path() == sm.PATH_FUSED
+                assert c == len(want) and np.array_equal(_dev(out, c), want), (w, canonical, mode)
+                checked += 1
+            want, wsk = oracle.run(data, n, k, w, canonical=canonical, base_offset=1, super_kmers=True)
+            c = sm.Builder(k, w, canonical, 0).run_device(d, n, out, out_sk=sk, base_offset=1)
+            assert c == len(want) and np.array_equal(_dev(out, c), want) and np.array_equal(_dev(sk, c), wsk), (w, canonical)
+            checked += 1
+    assert checked >= 2 * 35 * 3
+
+
+def test_every_prebuilt_instance_window_ranges(sm, oracle, gpu):
+    """window ranges that begin and end inside tiles (the shard-sized runs of the multi-GPU path), every instance"""
+    import torch
+    n = 180_011
+    data = oracle.gen_packed(78, n + 64)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    rng = np.random.default_rng(4)
+    for canonical in (True, False):
+        for w in sm.prebuilt_window_sizes(canonical):
+            k = 20 if (canonical and w % 2 == 0) else 21
+            nw = n - (k + w - 1) + 1
+            a, e = sorted(int(x) for x in rng.integers(1, nw, size=2))
+            want = _range_expect(oracle, data, n, k, w, canonical, a, e)
+            c = sm.Builder(k, w, canonical, 0).run_device(d, n, out, win_begin=a, win_end=e)
+            assert c == len(want) and np.array_equal(_dev(out, c), want), (w, canonical, a, e)
+
+
+def _tie_heavy(rng, n):
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    yield "two letters A/C", np.frombuffer(b"AC", dtype=np.uint8)[rng.integers(0, 2, n)]
+    yield "two letters A/T", np.frombuffer(b"AT", dtype=np.uint8)[rng.integers(0, 2, n)]
+    yield "two letters G/T", np.frombuffer(b"GT", dtype=np.uint8)[rng.integers(0, 2, n)]
+    unit = acgt[rng.integers(0, 4, 37)]
+    rep = np.tile(unit, n // 37 + 1)[:n].copy()
+    mut = rng.integers(0, 200, n) == 0
+    rep[mut] = acgt[rng.integers(0, 4, int(mut.sum()))]
+    yield "37-base repeat, 0.5 % mutations", rep
+    r = acgt[rng.integers(0, 4, n)].copy()
+    r[(np.arange(n) // 5000) % 3 == 0] = ord("A")
+    yield "random with 5 kbp poly-A runs", r
+
+
+def test_tie_heavy_sequences_vs_oracle(sm, oracle, gpu):
+    """The lazy strand vote decides only where the leftmost and the rightmost minimum differ (a tie of the 16 hash
+    bits): about one window in 7 000 of a random sequence, most windows of these."""
+    import torch
+    rng = np.random.default_rng(11)
+    n = 1_200_011
+    slow_path_windows = 0
+    for name, ascii_seq in _tie_heavy(rng, n):
+        data = oracle.pack_ascii(ascii_seq.tobytes())
+        data = np.concatenate([data, np.zeros(64, dtype=np.uint8)])
+        d = torch.from_numpy(data).cuda()
+        out = torch.zeros(n, dtype=torch.int32, device="cuda")
+        for (k, w, mode) in ((21, 11, 0), (20, 12, 0), (15, 17, 1), (15, 17, 2), (31, 33, 0), (31, 51, 0), (20, 36, 0)):
+            b = sm.Builder(k, w, True, mode)
+            want = oracle.run(data, n, k, w, canonical=True, mode=mode)
+            c = b.run_device(d, n, out)
+            assert c == len(want) and np.array_equal(_dev(out, c), want), (name, k, w, mode)
+            if mode == 0:
+                nw = n - (k + w - 1) + 1
+                a, e = 12_345, nw // 3 + 777
+                wr = _range_expect(oracle, data, n, k, w, True, a, e)
+                c = b.run_device(d, n, out, win_begin=a, win_end=e)
+                assert c == len(wr) and np.array_equal(_dev(out, c), wr), (name, k, w, "range")
+                # how often the two minima differ on this input (the vote's slow path): forward-leftmost != canonical
+                fwd = oracle.window_positions(data, n, k, w, oracle.default_hasher(True), False)
+                can = oracle.window_positions(data, n, k, w, oracle.default_hasher(True), True)
+                slow_path_windows += int((fwd != can).sum())
+    assert slow_path_windows > 100_000  # the inputs did reach the slow path, massively
+
+
+def _random_fasta(rng, n):
+    t = np.frombuffer(b"ACGTacgtNn", dtype=np.uint8)[rng.integers(0, 10, n)].copy()
+    i = np.arange(n)
+    width = int(rng.choice([7, 20, 31, 60, 61, 70, 80, 150, 1000, 100000]))
+    crlf = rng.integers(0, 4) == 0
+    step = width + (2 if crlf else 1)
+    t[i % step == step - 1] = 10
+    if crlf:
+        t[i % step == step - 2] = 13
+    every = int(rng.choice([0, 1, 2, 3, 17, 1000]))
+    if every:
+        t[i % (step * every) == 0] = ord(">")
+    if rng.integers(0, 3) == 0:  # stray control characters and '>' inside lines
+        m = rng.integers(0, 5000, n) == 0
+        t[m] = np.array([9, 0, 11, 62, 13], dtype=np.uint8)[rng.integers(0, 5, int(m.sum()))]
+    if rng.integers(0, 4):
+        t[0] = ord(">")
+    return t
+
+
+def test_fasta_packers_agree_on_random_texts(sm, oracle, gpu, monkeypatch):
+    """one-pass packer == three-pass kernels (packed bytes, record tables, counts) on random texts around chunk
+    multiples (tests/test_gpu_fasta.py holds both against the oracle's reader)"""
+    import torch
+    rng = np.random.default_rng(7)
+    L = sm.lib()
+    ws = sm.Workspace(0, torch.cuda.current_stream().cuda_stream)
+
+    def run(t_dev, flav):
+        monkeypatch.setenv("MM_FASTA_ONEPASS", flav)
+        n = t_dev.numel()
+        packed = torch.zeros(n // 4 + 64, dtype=torch.uint8, device="cuda")
+        cap = n // 2 + 2
+        rb = torch.zeros(cap + 1, dtype=torch.int64, device="cuda")
+        rp = torch.zeros(cap, dtype=torch.int64, device="cuda")
+        cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+        out = (C.c_uint64 * 2)()
+        sm._check(L.mm_fasta_pack_device(ws.h, C.c_void_p(t_dev.data_ptr()), n, C.c_void_p(packed.data_ptr()),
+                                         packed.numel() // 4 * 4, C.c_void_p(rb.data_ptr()), C.c_void_p(rp.data_ptr()),
+                                         cap, C.c_void_p(cnt.data_ptr()), out))
+        nb, nr = int(out[0]), int(out[1])
+        return nb, nr, packed[: (nb + 3) // 4].cpu().numpy(), rb[: nr + 1].cpu().numpy(), rp[:nr].cpu().numpy()
+
+    compared = 0
+    for it in range(40):
+        base = int(rng.choice([16384, 32768, 65536, 1 << 20, 1 << 22]))
+        n = max(1, base * int(rng.integers(1, 4)) + int(rng.integers(-40, 40)))
+        t = _random_fasta(rng, n)
+        td = torch.from_numpy(t).cuda()
+        a, b = run(td, "0"), run(td, "1")
+        assert a[0] == b[0] and a[1] == b[1], (it, n, a[:2], b[:2])
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]), (it, n)
+        compared += 1
+    monkeypatch.delenv("MM_FASTA_ONEPASS", raising=False)
+    ws.close()
+    assert compared == 40
+
+
+def test_epoch_tagged_status_words(sm, oracle, gpu):
+    """The look-back status words are not cleared between launches (each launch tags its words with its epoch): runs
+    of different geometry, plan and entry point interleaved on ONE workspace must not see one another's words."""
+    import torch
+    ws = sm.Workspace(0, torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(3)
+    n = 1_500_013
+    data = oracle.gen_packed(9, n + 64)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    plans = [(21, 11, True, 0), (21, 11, False, 0), (31, 51, True, 0), (15, 17, True, 1), (5, 3, False, 0)]
+    wants = {p: oracle.run(data, n, p[0], p[1], canonical=p[2], mode=p[3]) for p in plans}
+    for it in range(60):
+        p = plans[int(rng.integers(0, len(plans)))]
+        ws.set_blocks_per_lane(int(rng.choice([0, 0, 1, 2, 7, 13])))  # the tiles (and their words) move
+        b = sm.Builder(*p).workspace(ws)
+        if it % 3 == 0:
+            c = b.run_device(d, n, out)
+        else:
+            b.run_device(d, n, out, sync=False, d_count=cnt)
+            c = int(cnt.item())
+        assert c == len(wants[p]) and np.array_equal(_dev(out, c), wants[p]), (it, p)
+        if it % 7 == 0:  # reads mode and a batch launch share the same words
+            offs = torch.zeros(41, dtype=torch.int64, device="cuda")
+            tot = sm.run_reads_device(sm.Builder(21, 11, True, 0).workspace(ws), d, 40, 150, 150, out, offs)
+            ho = offs.cpu().numpy()
+            for r in (0, 17, 39):
+                wr = oracle.run(data, 150, 21, 11, canonical=True, base_offset=150 * r)
+                assert np.array_equal(_dev(out, tot)[ho[r]:ho[r + 1]], wr), (it, r)
+    ws.set_blocks_per_lane(0)
+    ws.check()
+    ws.close()
+
+
+def test_epoch_wraps(sm, oracle, gpu):
+    """65 535 epochs fit the tag: the launch after that clears the words and starts over.  A long run, more than
+    65 536 short ones, the long run again - its tiles meet words that carry their own epoch number from the first
+    time, were it not for the clear."""
+    import torch
+    ws = sm.Workspace(0, torch.cuda.current_stream().cuda_stream)
+    n = 2_000_003
+    data = oracle.gen_packed(12, n + 64)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n // 3, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    b = sm.canonical_minimizers(21, 11).workspace(ws)
+    want = oracle.run(data, n, 21, 11, canonical=True)
+    c = b.run_device(d, n, out)
+    assert c == len(want) and np.array_equal(_dev(out, c), want)
+    small = oracle.run(data, 3000, 21, 11, canonical=True)
+    for i in range(65_600):
+        b.run_device(d, 3000, out, sync=False, d_count=cnt)
+        if i % 8192 == 0:
+            assert int(cnt.item()) == len(small)
+    for _ in range(3):
+        out.zero_()
+        c = b.run_device(d, n, out)
+        assert c == len(want) and np.array_equal(_dev(out, c), want)
+    ws.check()
+    ws.close()
+
+
+def test_counts_without_copies(sm, oracle, gpu):
+    """The kernel's last tile stores the run's total to the caller's device word and to the workspace's page-locked
+    host word: synchronous and asynchronous runs, appending batches, empty runs and capacity errors agree with the
+    oracle's counts."""
+    import torch
+    ws = sm.Workspace(0, torch.cuda.current_stream().cuda_stream)
+    data = oracle.gen_packed(2, 400_000 + 64)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(200_000, dtype=torch.int32, device="cuda")
+    cnt = torch.full((1,), -5, dtype=torch.int64, device="cuda")
+    for n in (0, 5, 30, 31, 32, 1000, 77_777, 400_000):
+        for canonical in (True, False):
+            b = sm.Builder(21, 11, canonical, 0).workspace(ws)
+            want = oracle.run(data, n, 21, 11, canonical=canonical)
+            assert b.run_device(d, n, out) == len(want), (n, canonical)
+            cnt.fill_(-5)
+            b.run_device(d, n, out, sync=False, d_count=cnt)
+            assert int(cnt.item()) == len(want), (n, canonical)
+    # a capacity that is too small: the true count comes back with the error, nothing is written past the capacity
+    b = sm.canonical_minimizers(21, 11).workspace(ws)
+    want = oracle.run(data, 400_000, 21, 11, canonical=True)
+    small = torch.full((1000 + 8,), -7, dtype=torch.int32, device="cuda")
+    cnt64 = C.c_uint64()
+    code = sm.lib().mm_run_device(b.plan().h, ws.h, C.c_void_p(d.data_ptr()), d.numel(), 0, 400_000, 0, sm.U64_MAX,
+                                  C.c_void_p(small.data_ptr()), None, 1000, C.byref(cnt64))
+    assert code == sm.ERR["CAPACITY"] and cnt64.value == len(want)
+    assert np.array_equal(small[:1000].cpu().numpy().view(np.uint32), want[:1000]) and int(small[1000].item()) == -7
+    ws.check()
+    ws.close()
