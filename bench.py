@@ -9,12 +9,17 @@ sliding min -> strand vote -> dedup/collect) over synthetic input that is alread
 
     python bench.py --gpus N --steps K --warmup W [--workload headline|contigs|strong]
 
-  headline  (default) every rank owns one 3.1 Gbp sequence, canonical k=21 w=11 (BASELINE config 3;
-            independent genomes shard with no data-path collective: weak scaling)
+  strong    ONE 3.1 Gbp sequence, canonical k=21 w=11 (BASELINE config 3), cut into N window ranges (absolute
+            positions, exact seam, no data-path collective): `value` = 3.1e9 x steps / max-over-ranks time.
+            THE DEFAULT: north_star's experiment ("throughput on a synthetic 3.1 Gbp packed sequence ... at 1, 2,
+            4 and 8 GPUs").  At N = 1 this IS the headline configuration (one range = the whole sequence, the
+            same call, `scaling` "weak" by the contract's definition is moot for one GPU and reads "strong").
+  headline  every rank owns one 3.1 Gbp sequence of its own (independent genomes: weak scaling, linear by
+            construction).  At N > 1 its figure rides in `extra` of the default line.
   contigs   BASELINE config 4: 24 CHM13-like contigs, canonical k=31 w=51, placed on the N ranks
             greedily longest first, ONE batch launch per rank and step; afterwards the position
-            buffers are gathered to rank 0 (RCCL over xGMI), timed separately (strong scaling)
-  strong    one 3.1 Gbp sequence cut into N window ranges (absolute positions, exact seam)
+            buffers are gathered to rank 0 (RCCL over xGMI), timed separately (strong scaling).  At N > 1 its
+            figure rides in `extra` of the default line.
 
 With N > 1 and no launcher in the environment the script starts its N ranks itself (child processes,
 before anything in this process touches a GPU); under torchrun it uses the ranks it is given.  The
@@ -44,6 +49,25 @@ CPU_SAMPLE_CHUNK = 256 * 1024 * 1024
 CPU_SAMPLE_SECONDS = 12.0
 CPU_SAMPLE_MAX_CHUNKS = 12
 METRIC = "Gbases/s (whole node) for canonical minimizers k=21 w=11 on 3.1 Gbp; HBM GB/s %peak"
+
+
+# --------------------------------------------------------------------------- workload plan (pure: tests/test_distributed.py)
+def resolve_workload(workload, gpus):
+    """`--workload` left to its default: the strong split of ONE 3.1 Gbp sequence (at N = 1 that is the headline
+    call itself, reported under its historical name)."""
+    if workload:
+        return workload
+    return "headline" if gpus == 1 else "strong"
+
+
+def strong_plan(n_bases, world, k=K, w=W):
+    """Window range of every rank of the strong split and the bases the whole job covers: the ranges tile the
+    windows of ONE sequence exactly, so the bases sum to n_bases whatever N is."""
+    from simd_minimizers_amd import sharding
+    nw = n_bases - (k + w - 1) + 1
+    ranges = sharding.shard_windows(nw, world)
+    assert ranges[0][0] == 0 and ranges[-1][1] == nw and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    return {"ranges": ranges, "windows": nw, "total_bases": n_bases, "scaling": "strong"}
 
 
 # --------------------------------------------------------------------------- launcher
@@ -281,7 +305,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=20,
                     help="untimed steps; the GPU needs about a dozen 2 ms launches after idle to reach steady clocks")
-    ap.add_argument("--workload", choices=["headline", "contigs", "strong"], default="headline")
+    ap.add_argument("--workload", choices=["headline", "contigs", "strong"], default=None,
+                    help="default: the strong split of ONE 3.1 Gbp sequence (at --gpus 1: the headline configuration)")
     ap.add_argument("--bases", type=int, default=N_BASES, help="bases per GPU (headline) / in total (strong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
@@ -291,6 +316,7 @@ def main():
                          "host buffers in, one dense host result out, one host thread per device, no torch.distributed). "
                          "PCIe-inclusive by construction: a separate line, never the headline `value`")
     args = ap.parse_args()
+    args.workload = resolve_workload(args.workload, args.gpus)
     if args.single_process:
         sys.exit(single_process(args))
 
@@ -416,7 +442,8 @@ def main():
         out = torch.empty(cap, dtype=torch.int32, device=dev)
         d_count = torch.zeros(1, dtype=torch.int64, device=dev)
         my_bases, total_bases = n, n * world
-        scaling = "weak"
+        # (one GPU: the default series N = 1, 2, 4, 8 keeps the TOTAL at 3.1 Gbp - its first point is this very call)
+        scaling = "weak" if world > 1 else "strong"
         kernel_name = "mm::fused_kernel<11, true, true, 0, false, false>"
         workload = (f"canonical minimizers k={k} w={w}, one {n} bp PackedSeq per GPU "
                     f"(generator G seed {SEED}+rank), device-resident input and output")
@@ -430,8 +457,8 @@ def main():
         k, w = K, W
         b = sm.canonical_minimizers(k, w).workspace(ws)
         d_packed = generate(n, SEED)
-        nw = n - (k + w - 1) + 1
-        wb, we = sharding.shard_windows(nw, world)[rank]
+        plan_s = strong_plan(n, world, k, w)
+        wb, we = plan_s["ranges"][rank]
         cap = int((we - wb) * 2.3 / (w + 1)) + 4096
         out = torch.empty(cap, dtype=torch.int32, device=dev)
         d_count = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -520,6 +547,61 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         assert int(ok.item()) == 1, "a rank produced an implausible number of minimizers"
 
+    # ---------------------------------------------------------------- N > 1, default workload: the other two figures
+    # (untimed region; the same barrier + max-over-ranks protocol, a handful of steps each)
+    multi_extra = []
+    if distributed and args.workload == "strong" and not args.no_extra:
+        def timed_all_ranks(fn, steps_x):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            tx = time.perf_counter()
+            for _ in range(steps_x):
+                fn()
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            tt = torch.tensor([time.perf_counter() - tx], dtype=torch.float64, device=rdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item()) / steps_x
+
+        steps_x = max(3, min(10, args.steps))
+        # weak: every rank walks the whole 3.1 Gbp sequence by itself (independent genomes; linear by construction)
+        out_full = torch.empty(int(n * 2.3 / (w + 1)) + 4096, dtype=torch.int32, device=dev)
+        t_weak = timed_all_ranks(lambda: b.run_device(d_packed, n, out_full, sync=False, d_count=d_count), steps_x)
+        del out_full
+        multi_extra.append({"config": f"weak: one {n} bp sequence per GPU, {world} GPUs", "scaling": "weak",
+                            "ms_per_step": round(t_weak * 1e3, 4), "Gbases_per_s": round(n * world / t_weak / 1e9, 1)})
+        # contigs (BASELINE config 4): 24 CHM13-like contigs placed greedily, one batch launch per rank, then the gather
+        try:
+            if n != N_BASES:
+                raise RuntimeError("skipped: reduced --bases")
+            kc, wc = 31, 51
+            bc = sm.canonical_minimizers(kc, wc).workspace(ws)
+            lengths_c = list(sharding.CHM13_CONTIG_LENGTHS)
+            mine_c = sharding.assign_contigs(lengths_c, world)[rank]
+            d_c = [generate(lengths_c[i], sharding.CHM13_CONTIG_SEED0 + i) for i in mine_c]
+            lens_c = [lengths_c[i] for i in mine_c]
+            out_c = torch.empty(int(sum(lens_c) * 2.3 / (wc + 1)) + 4096, dtype=torch.int32, device=dev)
+            offs_c = [0]
+
+            def step_c():
+                offs_c[:] = sm.run_batch_device(bc, d_c, lens_c, out_c)
+            t_c = timed_all_ranks(step_c, steps_x)
+            dist.barrier()
+            tg = time.perf_counter()
+            _, _, _, counts_c, gathered_c = sharding.run_contig_batch_sharded(lambda idx: (out_c, offs_c), lengths_c, gather_to=0)
+            torch.cuda.synchronize(dev)
+            g_ms = (time.perf_counter() - tg) * 1e3
+            multi_extra.append({"config": f"C4 canonical minimizers k=31 w=51, 24 CHM13-like contigs on {world} GPUs, one "
+                                          "batch launch per GPU and step", "scaling": "strong",
+                                "ms_per_step": round(t_c * 1e3, 4), "Gbases_per_s": round(sum(lengths_c) / t_c / 1e9, 1),
+                                "gather_ms": round(g_ms, 3), "positions": int(sum(counts_c)),
+                                "gather": f"per-contig counts all-reduced, position buffers sent point-to-point to rank 0 ({backend})"})
+            del d_c, out_c, gathered_c
+        except Exception as e:  # must never take the default line down
+            multi_extra.append({"config": "C4 contigs", "error": str(e)[:200]})
+
     # ---------------------------------------------------------------- gather (config 4), separately timed
     if args.workload == "contigs":
         times = []
@@ -548,6 +630,31 @@ def main():
                    "all_ms": [round(x, 4) for x in allms],
                    "protocol": "warm-up + 5 repeats, median (bench/src/bin/paper.rs:536-556); kernel time by HIP events"}
         if args.workload == "headline":
+            # One rank's share of the strong split at N = 8, timed ALONE on this GPU exactly like the timed loop above
+            # (wall clock around `steps` asynchronous calls): shard_efficiency = t_full / (8 x t_shard) is what a
+            # strong 1 -> 8 scaling curve of this kernel can reach at best - the part of it one GPU can measure.
+            try:
+                sb, se = strong_plan(n, 8, k, w)["ranges"][3]
+
+                def shard_step():
+                    b.run_device(d_packed, n, out, win_begin=sb, win_end=se, sync=False, d_count=d_count)
+                for _ in range(max(5, args.warmup)):
+                    shard_step()
+                torch.cuda.synchronize(dev)
+                ts = time.perf_counter()
+                for _ in range(args.steps):
+                    shard_step()
+                torch.cuda.synchronize(dev)
+                t_shard = (time.perf_counter() - ts) / args.steps
+                med_s, _ = timed_kernel_ms(shard_step)
+                shard_row = {"config": f"1/8 window range of the headline sequence ([{sb}, {se}): rank 3 of 8), alone on one GPU",
+                             "windows": se - sb, "outputs": int(d_count.item()), "ms_per_step": round(t_shard * 1e3, 4),
+                             "kernel_ms": round(med_s, 4), "Gbases_per_s": round((se - sb) / t_shard / 1e9, 1),
+                             "shard_efficiency": round((dt / args.steps) / (8 * t_shard), 4),
+                             "what": "shard_efficiency = ms_per_step of the full sequence / (8 x ms_per_step of the shard)"}
+                extras.append(shard_row)
+            except Exception as e:
+                extras.append({"config": "1/8 window range", "error": str(e)[:200]})
             try:
                 import ctypes as C
 
@@ -567,7 +674,33 @@ def main():
                         e2e.append((time.perf_counter() - te) * 1e3)
                 assert cnt.value == n_out
                 m = statistics.median(e2e)
-                end_to_end = {"ms": round(m, 2), "Gbases_per_s": round(n / m / 1e6, 1),
+                # the link itself, measured beside it (this figure moved 39.6 -> 71.4 ms between two driver boxes):
+                # 512 MiB each way between the same page-locked buffers and the device, best of 3
+                link = {}
+                try:
+                    nb = min(512 << 20, hp.nbytes)
+                    dbuf = torch.empty(nb, dtype=torch.uint8, device=dev)
+                    hview = torch.from_numpy(hp[:nb])  # (page-locked by mm_host_alloc: the runtime copies it directly)
+                    for name, kind in (("h2d_GBps", 1), ("d2h_GBps", 2)):
+                        best = None
+                        for _ in range(3):
+                            torch.cuda.synchronize(dev)
+                            tl = time.perf_counter()
+                            if kind == 1:
+                                dbuf.copy_(hview)
+                            else:
+                                hview.copy_(dbuf)
+                            torch.cuda.synchronize(dev)
+                            el = time.perf_counter() - tl
+                            best = el if best is None or el < best else best
+                        link[name] = round(nb / best / 1e9, 1)
+                    # (what the call moves: the packed bytes in, the positions out, full duplex at best)
+                    link["floor_ms_at_these_rates"] = round(max((n / 4) / (link["h2d_GBps"] * 1e9),
+                                                                (4 * n_out) / (link["d2h_GBps"] * 1e9)) * 1e3, 2)
+                    del dbuf
+                except Exception as e:
+                    link = {"error": str(e)[:120]}
+                end_to_end = {"ms": round(m, 2), "Gbases_per_s": round(n / m / 1e6, 1), "link": link,
                               "what": "mm_run_host: H2D of the packed bytes + kernel + D2H of the positions, "
                                       "page-locked caller buffers (mm_host_alloc), pipelined in 16 chunks; "
                                       "median of 3 after 1 warm-up; PCIe-bound, never part of `value`"}
@@ -586,6 +719,9 @@ def main():
             traffic, valu, prov = recorded_counters(kern_s * 1e3, live_clock)
         config = {"workload": workload, "k": k, "w": w, "bases_per_gpu": my_bases, "outputs_per_gpu": n_out,
                   "kernel": kernel_name, "parallelism": f"shard{world}"}
+        if args.workload == "strong":
+            config["windows_per_rank"] = [e - a for a, e in plan_s["ranges"]]
+            config["bases_total"] = plan_s["total_bases"]
         if gather_ms is not None:
             config["gather_ms"] = round(gather_ms, 3)
             config["gather"] = ("all-reduce of the per-contig counts + dist.gather of the device-resident position "
@@ -618,8 +754,8 @@ def main():
             line["median_of_5"] = median5
         if end_to_end is not None:
             line["end_to_end"] = end_to_end
-        if extras:
-            line["extra"] = extras
+        if extras or multi_extra:
+            line["extra"] = extras + multi_extra
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()

@@ -59,10 +59,17 @@ def _as_tensor(x, dev):
 
 
 def gather_positions(local, counts: Sequence[int], gather_to: int, group=None):
-    """Variable-size gather of position buffers to ONE rank: every rank sends its (padded) buffer to
-    the root only - over xGMI these are N-1 point-to-point transfers into the root on separate links,
-    not an all-gather that would move every shard to everybody.  Returns the list of per-rank int32
-    tensors (trimmed to their counts) on the root, None elsewhere."""
+    """Per-rank views of gather_positions_cat's buffer (None off the root)."""
+    r = gather_positions_cat(local, counts, gather_to, group)
+    return None if r is None else r[1]
+
+
+def gather_positions_cat(local, counts: Sequence[int], gather_to: int, group=None):
+    """Variable-size gather of position buffers to ONE rank: every rank sends exactly its `counts[rank]` positions
+    to the root only - over xGMI these are N-1 point-to-point transfers into the root on separate links, not an
+    all-gather that would move every shard to everybody - and the root receives them straight into their slices of
+    ONE buffer of sum(counts) positions (no padding to the largest shard, no per-rank staging buffers).  Returns
+    (buffer, list of per-rank int32 views of it) on the root, None elsewhere."""
     import torch
     import torch.distributed as dist
 
@@ -70,15 +77,25 @@ def gather_positions(local, counts: Sequence[int], gather_to: int, group=None):
     rank = dist.get_rank(group)
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    m = max(1, max(int(c) for c in counts))
-    t = _as_tensor(local, dev)
-    buf = torch.zeros(m, dtype=torch.int32, device=dev)
-    buf[: t.numel()] = t
-    parts = [torch.zeros_like(buf) for _ in range(world)] if rank == gather_to else None
-    dist.gather(buf, parts, dst=gather_to, group=group)
+    counts = [int(c) for c in counts]
+    t = _as_tensor(local, dev)[: counts[rank]].contiguous()
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     if rank != gather_to:
+        if counts[rank] > 0:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, t, peer(gather_to), group)]):
+                req.wait()
         return None
-    return [p[: int(c)] for p, c in zip(parts, counts)]
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    cat = torch.empty(max(1, offs[-1]), dtype=torch.int32, device=dev)
+    parts = [cat[offs[r]: offs[r + 1]] for r in range(world)]
+    ops = [dist.P2POp(dist.irecv, parts[r], peer(r), group) for r in range(world) if r != gather_to and counts[r] > 0]
+    parts[gather_to].copy_(t)
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return cat[: offs[-1]], parts
 
 
 def run_sharded(compute: Callable[[int, int], np.ndarray], n_windows: int, group=None,
@@ -111,9 +128,9 @@ def run_sharded(compute: Callable[[int, int], np.ndarray], n_windows: int, group
     counts = [int(c.item()) for c in counts_t]
     gathered = None
     if gather_to is not None:
-        parts = gather_positions(local, counts, gather_to, group)
-        if parts is not None:
-            cat = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int32)
+        got = gather_positions_cat(local, counts, gather_to, group)
+        if got is not None:
+            cat = got[0]  # rank order == window order: the buffer IS the result
             gathered = cat if on_device else cat.cpu().numpy().view(np.uint32)
     return local, counts, gathered
 

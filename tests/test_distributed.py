@@ -197,3 +197,19 @@ def test_bench_launcher_fails_loudly():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env2, capture_output=True,
                         text=True, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE=2" in r2.stderr and '"n_gpus"' not in r2.stdout
+
+
+def test_bench_default_is_the_strong_split():
+    """the line a driver-run `bench.py --gpus N` prints must be north_star's experiment - ONE
+    3.1 Gbp sequence cut N ways, total work fixed - not N independent sequences.  (The N > 1 line itself is checked
+    on the GPU box: tests/test_gpu_round4.py::test_bench_world2_line_is_strong.)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.resolve_workload(None, 1) == "headline"
+    for n_gpus in (2, 4, 8):
+        assert bench.resolve_workload(None, n_gpus) == "strong"
+        p = bench.strong_plan(bench.N_BASES, n_gpus)
+        assert p["scaling"] == "strong" and p["total_bases"] == 3_100_000_000
+        assert sum(e - a for a, e in p["ranges"]) == p["windows"] == 3_100_000_000 - 31 + 1
+        assert max(e - a for a, e in p["ranges"]) - min(e - a for a, e in p["ranges"]) <= n_gpus
+    assert bench.resolve_workload("contigs", 8) == "contigs" and bench.resolve_workload("headline", 8) == "headline"

@@ -279,3 +279,25 @@ def test_counts_without_copies(sm, oracle, gpu):
     assert np.array_equal(small[:1000].cpu().numpy().view(np.uint32), want[:1000]) and int(small[1000].item()) == -7
     ws.check()
     ws.close()
+
+
+def test_bench_world2_line_is_strong(sm, gpu):
+    """`bench.py --gpus 2` with no workload flag prints the strong split: ONE sequence, two window ranges, `bases`
+    summing to the sequence (two ranks share this GPU over gloo: a functional check of the line, not a measurement)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["MM_BENCH_BACKEND"] = "gloo"
+    n = 200_000_000
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--bases", str(n), "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    cfg = line["config"]
+    assert cfg["bases_total"] == n and sum(cfg["windows_per_rank"]) == n - 31 + 1 and len(cfg["windows_per_rank"]) == 2
+    assert abs(line["value"] - n * 3 / (line["ms_per_step"] * 3e-3) / 1e9) < 0.01 * line["value"]
+    kinds = [e.get("scaling") for e in line.get("extra", [])]
+    assert "weak" in kinds  # the weak figure rides along
