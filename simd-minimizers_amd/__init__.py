@@ -105,8 +105,9 @@ def lib():
         L.mm_workspace_enable_timing.argtypes = [vp, C.c_int]
         L.mm_workspace_kernel_time.argtypes = [vp, C.POINTER(C.c_double), u64p, C.c_int]
         L.mm_workspace_last_path.argtypes = [vp]
-        L.mm_prebuilt_window_sizes.argtypes = [C.c_int, C.c_int, u32p, C.c_int]
-        L.mm_prebuilt_window_sizes.restype = C.c_int
+        if hasattr(L, "mm_prebuilt_window_sizes"):  # (absent from the round-3 library kept for A/B runs under tools/ab/)
+            L.mm_prebuilt_window_sizes.argtypes = [C.c_int, C.c_int, u32p, C.c_int]
+            L.mm_prebuilt_window_sizes.restype = C.c_int
         L.mm_run_device_async.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                           C.c_uint64, vp, vp, C.c_uint64, vp]
         L.mm_run_device.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,

@@ -254,6 +254,17 @@ bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_c
 // lower end of the lane lengths tune_whole_rounds may choose from (blocks per lane)
 static uint32_t whole_rounds_lo(uint32_t nblk) { return nblk * 85u / 100u > 6u ? nblk * 85u / 100u : 6u; }
 
+// upper bound of the tiles a tapered launch adds to a uniform one (for the status words reserved ahead of the launch)
+static uint64_t taper_extra_tiles() {
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        (void)hipGetLastError();
+        cus = 512;
+    }
+    return 8ull * (uint64_t)cus + 64ull;  // one round of at most 8 workgroups per CU, the rounding of the levels, the remainder
+}
+
 uint64_t fused_status_words(const RunArgs &a) {
     // Sized for the shortest lanes tune_whole_rounds can pick (it may shorten them to 85 % of the default,
     // floor, but not below 6 blocks: 8 -> 6 blocks are 1.33 x the tiles), with the same integer arithmetic;
@@ -270,6 +281,7 @@ uint64_t fused_status_words(const RunArgs &a) {
             if (t > tiles) tiles = t;
         }
     }
+    if (!a.batch_tile_seq && a.nblk == 0) tiles += taper_extra_tiles();  // (the tapered tail, plan_taper)
     return (tiles + 8) * status_stride_host();
 }
 uint32_t fused_tile_windows(const RunArgs &a) { return geometry(a).NB; }
@@ -286,22 +298,31 @@ static uint32_t g_lds_pad = 0;
 // left alone (at most 4 % to win), as are batches (their tile table is built from the default).
 // tiles(S) = tiles of the run with S windows per lane; returns the chosen blocks per lane (g.nblk if
 // nothing is to be gained)
+// workgroups of this kernel the chip holds at once (occupancy x CUs); false if the runtime cannot say
+static bool resident_slots(const KernelRef &kr, uint32_t lds_bytes, int *per_cu_out, int *cus_out) {
+    int per_cu = 0, cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    const hipError_t e =
+        kr.host ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kr.host),
+                                                               kFusedThreads, lds_bytes)
+                : hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kr.mod, kFusedThreads, lds_bytes);
+    if (e != hipSuccess || per_cu < 1 || cus < 1) {
+        (void)hipGetLastError();
+        return false;
+    }
+    *per_cu_out = per_cu;
+    *cus_out = cus;
+    return true;
+}
+
 template <class TilesFn>
 static uint32_t whole_rounds_nblk(const RunArgs &a, const KernelRef &kr, const Geometry &g, TilesFn tiles_of) {
     static const bool off = getenv("MM_NO_ROUNDS") != nullptr;
     if (off || a.nblk != 0 || g.nblocks <= 512) return g.nblk;
-    int per_cu = 0, cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return g.nblk;
-    const hipError_t e =
-        kr.host ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kr.host),
-                                                               kFusedThreads, g.lds_bytes)
-                : hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kr.mod, kFusedThreads, g.lds_bytes);
-    if (e != hipSuccess || per_cu < 1 || cus < 1) {
-        (void)hipGetLastError();
-        return g.nblk;
-    }
+    int per_cu = 0, cus = 0;
+    if (!resident_slots(kr, g.lds_bytes, &per_cu, &cus)) return g.nblk;
     const double slots = 0.98 * per_cu * cus;  // (a round that is 99 % full spills into the next one)
     const double kOverheadBlocks = 2.4;  // warm-up, look-back and copy-out of a tile, in W-blocks of walking
     if ((double)g.nblocks / slots >= 24.0 || (double)g.nblocks / slots <= 1.0) return g.nblk;
@@ -361,6 +382,57 @@ uint32_t fused_batch_nblk(const RunArgs &a, const uint64_t *n_windows, uint64_t 
     return nb == g.nblk ? 0u : nb;
 }
 
+// Tapered tail (FusedParams::taper_*).  With uniform tiles every workgroup slot of the chip finishes its last tile at
+// some point of one slot cycle, so the slots idle for half a cycle on average at the end of a launch: 19 us of the 208
+// a 387 M-window shard of the strong split takes (per-tile trace, tools/gpu_small_trace.py; profiles/r04_small_runs.txt),
+// 14 of the 99 us of BASELINE config 2.  The tiles of the LAST round therefore shrink linearly in dispatch order, from
+// the default lane length down to kTaperMinBlocks blocks, `slots / levels` tiles per level: slots free up evenly over
+// a cycle in steady state, so a tile that starts later is shorter by as much and they all end together.  (A first
+// design - one round of half-length and one of quarter-length tiles - measured SLOWER, 0.218 against 0.213 ms: the
+// look-back completes tiles in order, so a short tile that ends before its longer predecessors waits for them while
+// it holds the slot its successor needs.)  Half a round of work takes a whole round of tiles: about 1.2 blocks of
+// per-tile overhead more per slot.  Single sequences and window ranges with default lanes only (a caller who pins
+// the lane length gets exactly that; batches keep their tile table).  MM_NO_TAPER=1 switches it off (A/B; results
+// are identical either way).
+constexpr uint32_t kTaperMinBlocks = 4;
+struct Taper {
+    uint32_t first = 0xffffffffu, per_level = 1, min_nblk = kTaperMinBlocks;
+    unsigned long long start = 0;
+    uint64_t tiles = 0;  // tiles of the whole launch
+};
+
+static Taper plan_taper(const RunArgs &a, const KernelRef &kr, const Geometry &g) {
+    Taper t;
+    t.tiles = g.nblocks;
+    const bool off = mm_env("MM_NO_TAPER") != nullptr;
+    if (off || a.batch_tile_seq || a.nblk != 0 || g.nblk < kTaperMinBlocks + 4u) return t;
+    int per_cu = 0, cus = 0;
+    if (!resident_slots(kr, g.lds_bytes, &per_cu, &cus)) return t;
+    uint64_t slots = (uint64_t)per_cu * cus;
+    // (tests: pretend the chip holds this many workgroups, so that runs of a few tiles already taper)
+    if (const char *e = mm_env("MM_TAPER_SLOTS")) slots = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : slots;
+    const uint64_t nwin = a.win_end - a.win_begin;
+    const uint64_t lmax = g.nblk - kTaperMinBlocks;          // levels 1 .. lmax: g.nblk - 1 .. kTaperMinBlocks blocks
+    const uint64_t per_level = (slots + lmax - 1) / lmax;
+    const uint64_t blk_w = (uint64_t)kFusedThreads * a.w;    // windows of one block of one tile
+    const uint64_t cap_w = per_level * blk_w * (lmax * g.nblk - lmax * (lmax + 1) / 2);  // windows the levels hold
+    // (a run has to hold the tapered round and at least half a round of whole tiles before it: shorter ones keep
+    // uniform tiles - geometry() shortens their lanes, tune_whole_rounds picks the length that fills whole rounds)
+    uint64_t min_pct = 50;
+    if (const char *e = mm_env("MM_TAPER_MIN_PCT")) min_pct = (uint64_t)atoi(e);  // (tuning: % of a round of whole tiles)
+    if (nwin < cap_w + slots * (uint64_t)g.NB * min_pct / 100) return t;
+    const uint64_t f1 = (nwin - cap_w) / g.NB;
+    const uint64_t rest = nwin - f1 * g.NB;  // in [cap_w, cap_w + NB): the levels, then a few more tiles of the last level
+    const uint64_t extra = (rest - cap_w + blk_w * kTaperMinBlocks - 1) / (blk_w * kTaperMinBlocks);
+    const uint64_t tiles = f1 + per_level * lmax + extra;
+    if (tiles >= (1ull << 31) || per_level >= (1ull << 31)) return t;
+    t.first = (uint32_t)f1;
+    t.per_level = (uint32_t)per_level;
+    t.start = f1 * (uint64_t)g.NB;
+    t.tiles = tiles;
+    return t;
+}
+
 int launch_fused(const RunArgs &a, hipStream_t stream) {
     Geometry g = geometry(a);
     if (g.nblocks == 0) return 0;
@@ -368,7 +440,37 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     const KernelRef kr = resolve_kernel(a.w, a.canonical_windows, (int)a.ht.canonical, a.mode,
                                         a.out.sk != nullptr);
     if (!kr) return -2;
-    {
+    // A run long enough for the tapered tail keeps the default (longest) lanes: the taper removes what the whole-rounds
+    // tuner is there to avoid, and longer lanes pay less per-tile overhead (k=21 w=11 on 775 Mbp: 0.382 ms with the
+    // default lanes and the taper, 0.396 with the tuner's lanes and the taper, 0.391 with neither).
+    // A run of 0.6 to 1 round of the chip's slots with the default lanes gets exactly one round: every slot one tile,
+    // lanes as long as that takes (geometry()'s own rule for short runs assumes 1024 slots; the kernels of the large
+    // windows hold 768 or 512, the forward ones 1792).  Measured (tools/gpu_size_curve.py, profiles/r04_small_runs.txt):
+    // k=31 w=51 on 268 Mbp 0.227 -> 0.180 ms, forward k=21 w=11 on 67 Mbp 0.0398 -> 0.0368; BELOW about half a round
+    // the rule loses (k=31 w=51 on 134 Mbp: 0.151 ms with 768 tiles of 14 blocks against 0.111 with 1 028 of 10), so
+    // shorter runs keep geometry()'s lanes.
+    if (a.nblk == 0 && !a.batch_tile_seq && !mm_env("MM_NO_ONE_ROUND")) {
+        RunArgs full = a;
+        full.work_windows = 0;  // (the default lanes of a long run)
+        const Geometry gd = geometry(full);
+        int per_cu = 0, cus = 0;
+        const uint64_t nwin = a.win_end - a.win_begin, blk_w = (uint64_t)kFusedThreads * a.w;
+        if (resident_slots(kr, gd.lds_bytes, &per_cu, &cus)) {
+            const uint64_t slots = (uint64_t)per_cu * cus;
+            if (nwin <= slots * (uint64_t)gd.NB && nwin * 10u >= slots * (uint64_t)gd.NB * 6u) {
+                uint32_t nb = (uint32_t)((nwin + slots * blk_w - 1) / (slots * blk_w));
+                nb = nb < 6u ? 6u : (nb > gd.nblk ? gd.nblk : nb);
+                g.nblk = nb;
+                g.S = a.w * nb;
+                g.list_cap = list_capacity(a.w, a.mode, g.S);
+                g.lds_bytes = g.list_cap * stride_of(a);
+                g.NB = kFusedThreads * g.S;
+                g.nblocks = (nwin + g.NB - 1) / g.NB;
+            }
+        }
+    }
+    const bool tapers = plan_taper(a, kr, g).first != 0xffffffffu && !mm_env("MM_TUNE_ALWAYS");
+    if (!tapers) {
         const Geometry untuned = g;
         tune_whole_rounds(a, kr, g);
         // never launch (or clear) more tile status words than the caller allocated: keep the default lanes
@@ -379,6 +481,12 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         }
         if (a.status_avail && (g.nblocks + 8) * status_stride_host() > a.status_avail) return -1;
     }
+    Taper taper = plan_taper(a, kr, g);
+    if (a.status_avail && (taper.tiles + 8) * status_stride_host() > a.status_avail) {
+        taper = Taper();  // (a caller that reserved less than fused_status_words asked for: uniform tiles)
+        taper.tiles = g.nblocks;
+    }
+    g.nblocks = taper.tiles;
 
     FusedParams p;
     p.seq = a.seq;
@@ -409,6 +517,10 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.debug = debug_switches();
     p.epoch = a.status_epoch;
     p.append = a.append ? 1u : 0u;
+    p.taper_first = taper.first;
+    p.taper_per_level = taper.per_level;
+    p.taper_min_nblk = taper.min_nblk;
+    p.taper_start = taper.start;
     // (a tagged launch reads every word of another epoch as "not yet": nothing to clear, see kEpochShift)
     if (a.status_epoch == 0 &&
         hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (g.nblocks + 8) * status_stride_host(), stream) != hipSuccess)
@@ -526,6 +638,10 @@ int launch_split(const RunArgs &a, const SplitBuffers &b, hipStream_t stream) {
     p.out = a.out;
     p.use_ticket = 0;
     p.debug = debug_switches();
+    p.taper_first = 0xffffffffu;
+    p.taper_per_level = 1;
+    p.taper_min_nblk = 0;
+    p.taper_start = 0;
     p.epoch = 0;
     p.append = 1;  // (the redo pass takes its offsets from the redo list; the walk itself has no look-back)
     p.trace = nullptr;
@@ -687,6 +803,10 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.debug = 0;
     p.epoch = a.status_epoch;
     p.append = 0;
+    p.taper_first = 0xffffffffu;
+    p.taper_per_level = 1;
+    p.taper_min_nblk = 0;
+    p.taper_start = 0;
     p.n_reads = (uint32_t)a.n_reads;
     p.reads_per_lane = R;
     p.read_stride = a.read_stride;

@@ -118,6 +118,15 @@ struct FusedParams {
                          // it): 1 no look-back, 2 no copy-out, 4 no phase 1, 8 copy-out without stores, 16 half-size
                          // lists, 32 test hook: tile 0 reports a look-back time-out
     uint32_t epoch;      // tag of this launch's look-back status words (kEpochShift, mm_common.h); 0: cleared words
+    // Tapered tail (round 4; one sequence or window range, not batches / reads): the last tiles of a launch walk
+    // ever shorter lanes.  Tiles [0, taper_first) have p.nblk blocks per lane; tile taper_first + j belongs to level
+    // l = min(1 + j / taper_per_level, p.nblk - taper_min_nblk) and walks p.nblk - l blocks per lane; the tapered
+    // tiles follow one another from window offset taper_start (relative to win_begin) on.  taper_first = 0xffffffff:
+    // no taper.
+    uint32_t taper_first;
+    uint32_t taper_per_level;
+    uint32_t taper_min_nblk;
+    unsigned long long taper_start;
     uint32_t append;     // 1: *out.total holds the outputs before this launch (carry-in of tile 0), 0: starts at 0
     // reads mode (READS kernels): one lane per read, reads at a fixed stride in the buffer
     uint32_t n_reads;
@@ -1534,7 +1543,27 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         p.trace[10 * (size_t)bid + 4] = ((unsigned long long)xcc << 32) | hw;
     }
 
-    const uint32_t S = (uint32_t)W * p.nblk;
+    // Lane length of THIS tile.  The tail of a launch is tapered (FusedParams::taper_*, plan_taper in mm_fused.hip):
+    // with uniform tiles the chip's workgroup slots finish their last tile spread over one whole slot cycle and idle
+    // for half of it on average (a 387 M-window shard of the strong split: 19 of 208 us).  The tiles of the last
+    // round therefore shrink linearly in dispatch order - a slot that frees up later gets a shorter tile - so that
+    // all of them end at about the same time (which is also what the in-order look-back wants: a short tile that ended
+    // early would only wait for its longer predecessors).  All tile-uniform scalars.
+    uint32_t nblk_t = p.nblk;
+    unsigned long long tile_off = 0;  // first window of the tile relative to the range's first (single-sequence runs)
+    bool tapered = false;
+    if (!READS && bid >= p.taper_first) {
+        const uint32_t j = bid - p.taper_first, lmax = p.nblk - p.taper_min_nblk;
+        uint32_t l = 1u + j / p.taper_per_level;
+        l = l < lmax ? l : lmax;
+        nblk_t = p.nblk - l;
+        // blocks per lane of the tapered tiles before this one: the full levels 1 .. l-1, then this level's share
+        const unsigned long long before = (unsigned long long)p.taper_per_level * ((unsigned long long)(l - 1u) * p.nblk - (unsigned long long)(l - 1u) * l / 2u) +
+                                          (unsigned long long)(j - (l - 1u) * p.taper_per_level) * nblk_t;
+        tile_off = p.taper_start + before * (kFusedThreads * (uint32_t)W);
+        tapered = true;
+    }
+    const uint32_t S = (uint32_t)W * nblk_t;
     const uint32_t NB = kFusedThreads * S;
     // (one 32 x 32 -> 64-bit product: stays on the scalar unit, so everything derived from the tile
     // origin - the buffer descriptors of the sequence loads above all - lives in SGPRs)
@@ -1574,7 +1603,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         p.trace[10 * (size_t)bid + 8] = ((unsigned long long)win_end << 32) | local_tile;
         p.trace[10 * (size_t)bid + 9] = batch_s;
     }
-    const uint64_t bw0 = READS ? 0ull : (uint64_t)win_begin + (uint64_t)local_tile * NB;  // first window of the tile
+    const uint64_t bw0 = READS ? 0ull : (uint64_t)win_begin + (tapered ? tile_off : (uint64_t)local_tile * NB);  // first window of the tile
     const uint32_t nvalid = READS ? NB
         : (uint32_t)(((uint64_t)win_end - bw0) < NB ? ((uint64_t)win_end - bw0) : NB);
     const bool partial = READS || nvalid < NB;
@@ -1584,7 +1613,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     ctx.list = smem + kEB * (uint32_t)tid;
     ctx.list_bytes = p.list_cap * kStride;
     ctx.dst = 0;
-    ctx.nblk = p.nblk;
+    ctx.nblk = nblk_t;
     ctx.seq_d = seq_d;
     ctx.seq_dwords = seq_dwords;
     bool lane_active = false;

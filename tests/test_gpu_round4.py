@@ -301,3 +301,52 @@ def test_bench_world2_line_is_strong(sm, gpu):
     assert abs(line["value"] - n * 3 / (line["ms_per_step"] * 3e-3) / 1e9) < 0.01 * line["value"]
     kinds = [e.get("scaling") for e in line.get("extra", [])]
     assert "weak" in kinds  # the weak figure rides along
+
+
+def test_tapered_tail(sm, oracle, gpu, monkeypatch):
+    """The last tiles of a launch walk half- and quarter-length lanes (plan_taper, mm_fused.hip).  MM_TAPER_SLOTS
+    pretends the chip holds only a few workgroups, so that runs of a handful of tiles taper: every flavour, window
+    ranges, lengths around the level boundaries, against the oracle; and a run large enough to taper on the real chip
+    against the oracle's threaded port."""
+    import torch
+    rng = np.random.default_rng(17)
+    n = 3_000_019
+    data = oracle.gen_packed(41, n + 64)
+    d = torch.from_numpy(data).cuda()
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    sk = torch.zeros(n, dtype=torch.int32, device="cuda")
+    checked = 0
+    for slots in (1, 2, 5):
+        monkeypatch.setenv("MM_TAPER_SLOTS", str(slots))
+        for (k, w, canonical, mode) in ((21, 11, True, 0), (21, 11, False, 0), (31, 51, True, 0), (15, 17, True, 1),
+                                        (15, 17, True, 2), (21, 8, False, 0), (20, 32, True, 0), (5, 16, False, 0)):
+            b = sm.Builder(k, w, canonical, mode)
+            for m in (n, int(rng.integers(n // 3, n)), int(rng.integers(200_000, n // 3))):
+                want = oracle.run(data, m, k, w, canonical=canonical, mode=mode)
+                c = b.run_device(d, m, out)
+                assert c == len(want) and np.array_equal(_dev(out, c), want), (slots, k, w, canonical, mode, m)
+                checked += 1
+            if mode == 0:
+                want, wsk = oracle.run(data, n, k, w, canonical=canonical, super_kmers=True)
+                c = b.run_device(d, n, out, out_sk=sk)
+                assert c == len(want) and np.array_equal(_dev(out, c), want) and np.array_equal(_dev(sk, c), wsk)
+                nw = n - (k + w - 1) + 1
+                a, e = sorted(int(x) for x in rng.integers(1, nw, size=2))
+                wr = _range_expect(oracle, data, n, k, w, canonical, a, e)
+                c = b.run_device(d, n, out, win_begin=a, win_end=e)
+                assert c == len(wr) and np.array_equal(_dev(out, c), wr), (slots, k, w, canonical, a, e)
+                checked += 2
+    monkeypatch.delenv("MM_TAPER_SLOTS")
+    assert checked >= 3 * (8 * 3 + 5 * 2)
+    # the real chip: 150 Mbp canonical k=21 w=11 tapers (threshold about 80 Mbp), element by element
+    n2 = 150_000_001
+    big = oracle.gen_packed(42, n2 + 64)
+    want = oracle.run_fast(big, n2, 21, 11, canonical=True, threads=min(32, os.cpu_count() or 1))
+    db = torch.from_numpy(big).cuda()
+    ob = torch.zeros(int(n2 * 0.2), dtype=torch.int32, device="cuda")
+    for env in (None, "1"):  # tapered and uniform tiles give the same positions
+        if env:
+            monkeypatch.setenv("MM_NO_TAPER", env)
+        c = sm.canonical_minimizers(21, 11).run_device(db, n2, ob)
+        assert c == len(want) and np.array_equal(_dev(ob, c), want), env
+    monkeypatch.delenv("MM_NO_TAPER")
