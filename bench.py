@@ -403,9 +403,16 @@ def main():
 
                 def step():
                     offs[:] = sm.run_batch_device(b, d, list(contigs), out)
-            for _ in range(12):  # (the first configuration also brings the clocks up from idle)
-                step()
-            torch.cuda.synchronize(dev)
+            # warm-up by TIME, not by count: the chip needs some tens of milliseconds of work to reach its steady
+            # clocks, and twelve steps of a 0.1 ms configuration are 1.2 ms (round 3 printed C2 22 % below its
+            # steady state for that reason alone: 2 113 against 2 550 Gbases/s on the same box, tools/gpu_size_curve.py)
+            tw = time.perf_counter()
+            while True:
+                for _ in range(12):
+                    step()
+                torch.cuda.synchronize(dev)
+                if time.perf_counter() - tw > 0.06:
+                    break
             med, _ = timed_kernel_ms(step)
             ws.check()
             n_out = int(cnt.item()) if contigs is None else int(offs[-1])
