@@ -465,7 +465,12 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         uint32_t q[5];
         uint32_t sh;  // 2 * (first base & 15): bit of the first base in q[0]
     };
+#ifdef MM_EXP_ONE_STREAM  // timing experiment (wrong results): what a walk WITHOUT the hash-out load stream would cost
+    WideBuf Wa[2];
+    WideBuf(&Wr)[2] = Wa;
+#else
     WideBuf Wa[2], Wr[2];  // [0] working buffer of the current group, [1] landing buffer of the next one
+#endif
     uint32_t gp_in = 0, gp_out = 0;  // first base (tile-relative) of the next group to load
     auto wide_load = [&](uint32_t gpos, WideBuf &w) {
         const uint32_t off = (gpos >> 4) << 2;
@@ -543,7 +548,9 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             gp_in = (uint32_t)(pos_in + W);
             gp_out = (uint32_t)(pos_out + W);
             wide_load(gp_in, Wa[1]);
+#ifndef MM_EXP_ONE_STREAM
             wide_load(gp_out, Wr[1]);
+#endif
             gp_in += (uint32_t)(MG * W);
             gp_out += (uint32_t)(MG * W);
         }
@@ -721,11 +728,17 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             if (kn == 0) {
                 // (the landing buffer [1] is shifted into the working buffer [0]; then it takes the next load)
                 sh_in = wide_normalise(Wa[0], Wa[1]);
+#ifdef MM_EXP_ONE_STREAM
+                sh_out = sh_in;
+                wide_load(gp_in, Wa[1]);
+                MM_BUMP(gp_in, MG * W);
+#else
                 sh_out = wide_normalise(Wr[0], Wr[1]);
                 wide_load(gp_in, Wa[1]);
                 wide_load(gp_out, Wr[1]);
                 MM_BUMP(gp_in, MG * W);
                 MM_BUMP(gp_out, MG * W);
+#endif
             }
             switch (kn) {
 #define MM_WIDE_CASE(K)                                                   \
