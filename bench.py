@@ -253,7 +253,11 @@ def recorded_counters(kernel_ms, live_clock_ghz=None):
 
 # --------------------------------------------------------------------------- one process, several devices
 def single_process(args):
-    """`--single-process --gpus N`: the several-device entry point a C / Rust caller uses."""
+    """`--single-process --gpus N`: the several-device entry points a C / Rust caller uses, driven from THIS process
+    through the C ABI's device group (no torch.distributed).  `value`: mm_run_sharded_device - the sequence resident on
+    every device (mm_device_group_upload, once, untimed), one asynchronous launch per device over its window range, the
+    positions left on the devices - with the device-to-device gather (mm_device_group_gather) timed
+    beside it; `extra`: the host-buffer call mm_run_sharded_host (H2D + kernel + D2H per shard: PCIe-bound)."""
     import numpy as np
     import torch
 
@@ -263,38 +267,67 @@ def single_process(args):
         sys.exit("bench.py --single-process: no GPU")
     # fewer devices than --gpus: entries share devices (a functional check, labelled as such)
     devices = [i % n_dev for i in range(args.gpus)]
-    n = min(args.bases, 1 << 30)  # host buffers: 256 MB packed in, ~0.7 GB of positions out
+    n = min(args.bases, N_BASES)
     ws = sm.default_workspace(0)
     d = sm.generate_device(n, SEED)
     torch.cuda.synchronize()
     hp, hp_owner = sm.pinned_array(((n + 3) // 4 + 64,), np.uint8)
     hp[:] = d.cpu().numpy()
-    del d
     g = sm.DeviceGroup(devices)
     b = sm.canonical_minimizers(K, W)
-    cap = int(n * 2.3 / (W + 1)) + 4096
-    ho, ho_owner = sm.pinned_array((cap,), np.uint32)  # the caller's result buffer, page-locked and touched
-    ho[:] = 0
-    for _ in range(max(1, args.warmup // 4)):
-        pos, _ = g.run(b, hp, n, out=ho)
+    g.upload(hp[: (n + 3) // 4 + 1])
+    for _ in range(max(3, args.warmup)):
+        counts = g.run_device(b, n)
     t0 = time.perf_counter()
-    steps = max(1, args.steps // 4)
-    for _ in range(steps):
-        pos, _ = g.run(b, hp, n, out=ho)
-    dt = time.perf_counter() - t0
-    pos = pos.copy()
-    one, _ = sm.DeviceGroup([0]).run(b, hp, n, capacity=cap)
-    assert np.array_equal(pos, one), "sharded result differs from the one-device result"
+    for _ in range(args.steps):
+        counts = g.run_device(b, n)
+    dt = (time.perf_counter() - t0) / args.steps
+    total = sum(counts)
+    dst = torch.empty(total + 1024, dtype=torch.int32, device="cuda:%d" % devices[0])
+    gms = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        got = g.gather(0, dst)
+        gms.append((time.perf_counter() - tg) * 1e3)
+    assert got == total
+    # the shards laid end to end must be the one-device result
+    out1 = torch.empty(total + 1024, dtype=torch.int32, device="cuda:0")
+    c1 = b.workspace(ws).run_device(d, n, out1)
+    assert c1 == total and bool(torch.equal(out1[:c1].cpu(), dst[:total].cpu())), "sharded result differs from the one-device result"
+    del out1, dst, d
+    torch.cuda.empty_cache()
+    extra = []
+    try:  # the host-buffer call, PCIe-inclusive (at most 1 Gbp: host memory)
+        nh = min(n, 1 << 30)
+        cap = int(nh * 2.3 / (W + 1)) + 4096
+        ho, ho_owner = sm.pinned_array((cap,), np.uint32)
+        ho[:] = 0
+        g.run(b, hp, nh, out=ho)
+        th = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            pos, _ = g.run(b, hp, nh, out=ho)
+        dth = (time.perf_counter() - th) / reps
+        extra.append({"config": f"mm_run_sharded_host: ONE {nh} bp PackedSeq in page-locked host memory, H2D + kernel + D2H per "
+                                "shard, one dense host result (PCIe-bound)", "ms_per_step": round(dth * 1e3, 3),
+                      "Gbases_per_s": round(nh / dth / 1e9, 2), "outputs": int(len(pos))})
+    except Exception as e:
+        extra.append({"config": "mm_run_sharded_host", "error": str(e)[:200]})
     print(json.dumps({
-        "metric": "Gbases/s, canonical minimizers k=21 w=11 through mm_run_sharded_host (host buffers, PCIe-inclusive)",
-        "value": round(n * steps / dt / 1e9, 3), "unit": "Gbases/s", "n_gpus": args.gpus, "steps": steps,
-        "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "metric": "Gbases/s, canonical minimizers k=21 w=11 through mm_run_sharded_device (device-resident shards, one process)",
+        "value": round(n / dt / 1e9, 3), "unit": "Gbases/s", "n_gpus": args.gpus, "steps": args.steps,
+        "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"ONE {n} bp PackedSeq in host memory cut into {args.gpus} window ranges by "
-                               "mm_run_sharded_host (one host thread and one workspace per entry, exact seam, one dense "
-                               "host result); H2D + kernel + D2H per shard: PCIe-bound",
-                   "devices": devices, "distinct_devices": len(set(devices)), "outputs": int(len(pos)),
-                   "parallelism": f"device_group{args.gpus}"}}), flush=True)
+        "config": {"workload": f"ONE {n} bp PackedSeq resident on every device of the group (mm_device_group_upload, untimed), cut "
+                               f"into {args.gpus} window ranges by mm_run_sharded_device: one asynchronous launch per entry from "
+                               "one host thread, positions left on the devices, absolute, exact seam",
+                   "devices": devices, "distinct_devices": len(set(devices)), "outputs": int(total),
+                   "outputs_per_entry": counts, "parallelism": f"device_group{args.gpus}",
+                   "gather_ms": round(statistics.median(gms), 3),
+                   "gather": "mm_device_group_gather: device-to-device copies of the shards into one buffer on entry 0's "
+                             "device (hipMemcpyPeerAsync; xGMI between distinct GPUs), median of 4"},
+        "extra": extra}), flush=True)
     return 0
 
 

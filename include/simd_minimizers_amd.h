@@ -358,8 +358,9 @@ int mm_device_group_create(mm_device_group_t **out, const int *devices, int n_de
 void mm_device_group_destroy(mm_device_group_t *group);
 int mm_device_group_size(const mm_device_group_t *group);
 /* One sequence cut into n equal window ranges, one per entry of the group: absolute positions, exact seam (a
- * range's first position equal to the last one before it is dropped, src/collect.rs:265-271; syncmers have no
- * such rule).  Same result as mm_run_host.  MM_ERR_CAPACITY: *out_count holds the need (before seam drops). */
+ * range starts by comparing with the window before it, which is the reference's rule for joining lanes,
+ * src/collect.rs:265-271; syncmers have no such rule).  Same result as mm_run_host.  MM_ERR_CAPACITY: *out_count
+ * holds the need. */
 int mm_run_sharded_host(const mm_plan_t *plan, mm_device_group_t *group, const uint8_t *packed,
                         uint64_t base_offset, uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk /* or NULL */,
                         uint64_t capacity, uint64_t *out_count);
@@ -370,6 +371,36 @@ int mm_run_batch_sharded_host(const mm_plan_t *plan, mm_device_group_t *group, u
                               const uint8_t *const *packed, const uint64_t *base_offsets /* or NULL */,
                               const uint64_t *n_bases, uint32_t *out_pos, uint32_t *out_sk /* or NULL */,
                               uint64_t capacity, uint64_t *out_offsets /* [n_seqs + 1] */);
+
+/* ---- device-resident shards (round 4).  north_star's multi-GPU shape: the sequence already lives in HBM, every
+ * device walks its window range with one asynchronous launch, the positions STAY on their devices, and "at most" a
+ * gather moves them to one device over xGMI.  No host buffers, no PCIe transfer, no host thread per device.
+ *
+ * The sequence: mm_device_group_upload copies the caller's packed bytes to every device of the group ONCE (kept
+ * until the next upload or the group's end); mm_device_group_adopt takes device pointers the caller already
+ * holds instead - d_packed[i] on the device of entry i, each addressing the same packed_bytes of the same
+ * sequence, not owned by the group.  (Every entry addresses the whole sequence so that positions are absolute;
+ * an entry only READS the bytes of its own window range and a halo of k + w - 1 bases.) */
+int mm_device_group_upload(mm_device_group_t *group, const uint8_t *packed, uint64_t packed_bytes);
+int mm_device_group_adopt(mm_device_group_t *group, const void *const *d_packed /* [size] */, uint64_t packed_bytes);
+/* Builder::run over the resident sequence, cut into mm_device_group_size(group) equal window ranges (absolute
+ * positions, exact seam: range i starts by comparing with the window before it, src/collect.rs:265-271, so the
+ * shards laid end to end ARE the single-device result).  One asynchronous launch per entry, issued from the
+ * calling thread; the call returns when all have finished.  The positions (and super-k-mer indices when
+ * want_superkmers != 0) are left in result buffers the group owns and grows, one per entry: see
+ * mm_device_group_result.  counts[i] (may be NULL) receives entry i's count, *total (may be NULL) their sum. */
+int mm_run_sharded_device(const mm_plan_t *plan, mm_device_group_t *group, uint64_t base_offset, uint64_t n_bases,
+                          int want_superkmers, uint64_t *counts /* [size] or NULL */, uint64_t *total);
+/* Entry i's shard of the last mm_run_sharded_device: device pointers on that entry's device (valid until the next
+ * run on the group), its count and its window range.  Any out pointer may be NULL. */
+int mm_device_group_result(const mm_device_group_t *group, int entry, uint32_t **d_pos, uint32_t **d_sk,
+                           uint64_t *count, uint64_t *win_begin, uint64_t *win_end);
+/* The optional exchange: the shards of the last run, dense and in window order, into d_dst_pos (and d_dst_sk) on
+ * the device of entry `root` - device-to-device copies (hipMemcpyPeerAsync: over xGMI between the GPUs of a node),
+ * all in flight together; no RCCL dependency.  *total receives the number of positions; MM_ERR_CAPACITY when they
+ * do not fit `capacity` (nothing is copied then). */
+int mm_device_group_gather(mm_device_group_t *group, int root, uint32_t *d_dst_pos, uint32_t *d_dst_sk /* or NULL */,
+                           uint64_t capacity, uint64_t *total);
 
 /* Diagnostics: the shader clock while other work runs on the device.  _begin starts a handful of sleeping
  * single-wave workgroups on a stream of the workspace's own that sample the shader cycle counter against the

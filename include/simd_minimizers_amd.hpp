@@ -325,6 +325,39 @@ class DeviceGroup {
         pos.resize(offsets.back());
     }
 
+    // ---- device-resident shards (round 4): the sequence lives in HBM on every device of the group, every device
+    // walks its window range with one asynchronous launch, the positions stay where they were made
+    void upload(PackedSeq seq) { check(mm_device_group_upload(g_, seq.data, (seq.offset + seq.len + 3) / 4)); }
+    void adopt(const std::vector<const void *> &d_packed, uint64_t packed_bytes) {
+        check(mm_device_group_adopt(g_, d_packed.data(), packed_bytes));
+    }
+    // per-entry counts of Builder::run over the resident sequence (n_bases bases from base_offset on)
+    template <bool CANONICAL, int SYNCMER>
+    std::vector<uint64_t> run_device(const Builder<CANONICAL, SYNCMER> &b, uint64_t n_bases, uint64_t base_offset = 0,
+                                     bool super_kmers = false) const {
+        mm_plan_t *plan = b.make_plan();
+        std::vector<uint64_t> counts((size_t)size());
+        const int r = mm_run_sharded_device(plan, g_, base_offset, n_bases, super_kmers ? 1 : 0, counts.data(), nullptr);
+        mm_plan_destroy(plan);
+        check(r);
+        return counts;
+    }
+    struct Shard {
+        uint32_t *d_pos = nullptr, *d_sk = nullptr;  // device pointers on the entry's device
+        uint64_t count = 0, win_begin = 0, win_end = 0;
+    };
+    Shard result(int entry) const {
+        Shard s;
+        check(mm_device_group_result(g_, entry, &s.d_pos, &s.d_sk, &s.count, &s.win_begin, &s.win_end));
+        return s;
+    }
+    // the shards, dense and in window order, into device memory of entry `root` (device-to-device copies)
+    uint64_t gather(int root, uint32_t *d_dst_pos, uint64_t capacity, uint32_t *d_dst_sk = nullptr) const {
+        uint64_t total = 0;
+        check(mm_device_group_gather(g_, root, d_dst_pos, d_dst_sk, capacity, &total));
+        return total;
+    }
+
   private:
     mm_device_group_t *g_ = nullptr;
 };

@@ -98,6 +98,12 @@ def lib():
         L.mm_device_group_size.argtypes = [vp]
         L.mm_run_sharded_host.argtypes = [vp, vp, u8p, C.c_uint64, C.c_uint64, u32p, u32p, C.c_uint64, u64p]
         L.mm_run_batch_sharded_host.argtypes = [vp, vp, C.c_uint64, C.POINTER(u8p), u64p, u64p, u32p, u32p, C.c_uint64, u64p]
+        if hasattr(L, "mm_run_sharded_device"):  # (absent from the round-3 library kept for A/B runs under tools/ab/)
+            L.mm_device_group_upload.argtypes = [vp, u8p, C.c_uint64]
+            L.mm_device_group_adopt.argtypes = [vp, C.POINTER(vp), C.c_uint64]
+            L.mm_run_sharded_device.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int, u64p, u64p]
+            L.mm_device_group_result.argtypes = [vp, C.c_int, C.POINTER(u32p), C.POINTER(u32p), u64p, u64p, u64p]
+            L.mm_device_group_gather.argtypes = [vp, C.c_int, vp, vp, C.c_uint64, u64p]
         L.mm_clock_probe_begin.argtypes = [vp, C.c_uint64]
         L.mm_clock_probe_end.argtypes = [vp, C.POINTER(C.c_double)]
         L.mm_workspace_force_generic.argtypes = [vp, C.c_int]
@@ -174,6 +180,8 @@ EXPORTED_SYMBOLS = [
     "mm_clock_probe_begin", "mm_clock_probe_end",
     "mm_device_group_create", "mm_device_group_destroy", "mm_device_group_size", "mm_run_sharded_host",
     "mm_run_batch_sharded_host",
+    "mm_device_group_upload", "mm_device_group_adopt", "mm_run_sharded_device", "mm_device_group_result",
+    "mm_device_group_gather",
 ]
 
 
@@ -389,6 +397,10 @@ class DeviceGroup:
         l = builder.k + builder.w - 1
         cap = max(1, n_bases - l + 1) if capacity is None else capacity
         if out is not None:
+            # (the library writes uint32 positions straight into it)
+            if not (isinstance(out, np.ndarray) and out.dtype == np.uint32 and out.ndim == 1 and out.flags.c_contiguous
+                    and out.flags.writeable):
+                raise ValueError("out must be a writeable, C-contiguous, one-dimensional uint32 array")
             cap = min(cap, out.size) if capacity is not None else out.size
         pos = out if out is not None else np.empty(cap, dtype=np.uint32)
         sk = np.empty(cap, dtype=np.uint32) if builder._sk is not None else None
@@ -401,6 +413,48 @@ class DeviceGroup:
             raise MinimizerError(code, f"output capacity {cap} < {cnt.value}")
         _check(code)
         return pos[:cnt.value], (sk[:cnt.value] if sk is not None else None)
+
+    # ---- device-resident shards (mm_device_group_upload / _adopt, mm_run_sharded_device, _result, _gather)
+    def upload(self, packed: np.ndarray):
+        """The packed sequence to every device of the group, once (kept until the next upload / adopt)."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        _check(lib().mm_device_group_upload(self.h, packed.ctypes.data_as(C.POINTER(C.c_uint8)), packed.size))
+
+    def adopt(self, device_tensors):
+        """Device buffers the caller already holds (one per entry, on that entry's device, same bytes)."""
+        self._adopted = list(device_tensors)  # keep them alive
+        ptrs = (C.c_void_p * len(self._adopted))(*[t.data_ptr() for t in self._adopted])
+        _check(lib().mm_device_group_adopt(self.h, ptrs, int(self._adopted[0].numel())))
+
+    def run_device(self, builder: "Builder", n_bases: int, base_offset: int = 0):
+        """``mm_run_sharded_device``: one asynchronous launch per entry over its window range of the resident
+        sequence; the positions stay on the devices.  Returns the per-entry counts."""
+        n = len(self)
+        counts = (C.c_uint64 * n)()
+        total = C.c_uint64()
+        _check(lib().mm_run_sharded_device(builder.plan().h, self.h, base_offset, n_bases,
+                                           1 if builder._sk is not None else 0, counts, C.byref(total)))
+        return [int(c) for c in counts]
+
+    def result(self, entry: int):
+        """(device address of the positions, of the super-k-mer indices or 0, count, win_begin, win_end) of an entry."""
+        dp, ds = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+        cnt, wb, we = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().mm_device_group_result(self.h, entry, C.byref(dp), C.byref(ds), C.byref(cnt), C.byref(wb), C.byref(we)))
+        addr = lambda p: C.cast(p, C.c_void_p).value or 0
+        return addr(dp), addr(ds), int(cnt.value), int(wb.value), int(we.value)
+
+    def gather(self, root: int, d_dst_pos, d_dst_sk=None):
+        """``mm_device_group_gather``: the shards, dense and in window order, into device tensors on the root entry's
+        device (device-to-device copies; xGMI between the GPUs of a node).  Returns the number of positions."""
+        total = C.c_uint64()
+        code = lib().mm_device_group_gather(self.h, root, C.c_void_p(d_dst_pos.data_ptr()),
+                                            C.c_void_p(d_dst_sk.data_ptr()) if d_dst_sk is not None else None,
+                                            int(d_dst_pos.numel()), C.byref(total))
+        if code == ERR["CAPACITY"]:
+            raise MinimizerError(code, f"gather capacity {int(d_dst_pos.numel())} < {total.value}")
+        _check(code)
+        return int(total.value)
 
     def run_batch(self, builder: "Builder", seqs, n_bases, base_offsets=None, capacity=None):
         """Independent host sequences placed greedily on the entries (``mm_run_batch_sharded_host``): (positions,

@@ -1763,6 +1763,18 @@ int mm_generate_device_async(mm_workspace_t *ws, uint64_t seed, uint64_t first_b
 // exchange is host-side, so nothing crosses between the devices (no RCCL): results go to host memory.
 struct mm_device_group {
     std::vector<mm_workspace_t *> ws;
+    // device-resident shards (mm_device_group_upload / _adopt, mm_run_sharded_device)
+    std::vector<void *> d_seq;     // the packed sequence as entry i's device addresses it
+    std::vector<char> own_seq;     // uploaded by the group (freed with it) / adopted from the caller
+    uint64_t seq_bytes = 0;
+    struct Shard {
+        uint32_t *d_pos = nullptr, *d_sk = nullptr;  // result buffers on the entry's device, grown as needed
+        uint64_t cap_pos = 0, cap_sk = 0;
+        uint64_t count = 0, win_begin = 0, win_end = 0;
+        bool has_sk = false;
+    };
+    std::vector<Shard> shard;
+    bool ran = false;
 };
 
 namespace {
@@ -1771,7 +1783,6 @@ struct ShardResult {
     int rc = MM_OK;
     std::string err;
     uint64_t count = 0;
-    uint32_t first = 0, last = 0;
 };
 
 // Positions [from, from + n) of the workspace's staging buffers to the caller's arrays at `to`.
@@ -1800,14 +1811,83 @@ int mm_device_group_create(mm_device_group_t **out, const int *devices, int n_de
         }
         g->ws.push_back(ws);
     }
+    g->d_seq.assign(g->ws.size(), nullptr);
+    g->own_seq.assign(g->ws.size(), 0);
+    g->shard.resize(g->ws.size());
+    // device-to-device copies of mm_device_group_gather go straight over xGMI where the pair allows it (a refusal
+    // is not an error: hipMemcpyPeerAsync then stages through the host)
+    for (size_t i = 0; i < g->ws.size(); ++i)
+        for (size_t j = 0; j < g->ws.size(); ++j)
+            if (g->ws[i]->device != g->ws[j]->device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, g->ws[i]->device, g->ws[j]->device) == hipSuccess && can &&
+                    hipSetDevice(g->ws[i]->device) == hipSuccess)
+                    (void)hipDeviceEnablePeerAccess(g->ws[j]->device, 0);
+                (void)hipGetLastError();
+            }
     *out = g;
     return MM_OK;
 }
 
+static void group_drop_sequence(mm_device_group *g) {
+    for (size_t i = 0; i < g->d_seq.size(); ++i)
+        if (g->d_seq[i] && g->own_seq[i]) {
+            hipSetDevice(g->ws[i]->device);
+            hipFree(g->d_seq[i]);
+        }
+    g->d_seq.assign(g->ws.size(), nullptr);
+    g->own_seq.assign(g->ws.size(), 0);
+    g->seq_bytes = 0;
+}
+
 void mm_device_group_destroy(mm_device_group_t *g) {
     if (!g) return;
+    for (size_t i = 0; i < g->shard.size() && i < g->ws.size(); ++i) {
+        hipSetDevice(g->ws[i]->device);
+        hipStreamSynchronize(g->ws[i]->stream);
+        if (g->shard[i].d_pos) hipFree(g->shard[i].d_pos);
+        if (g->shard[i].d_sk) hipFree(g->shard[i].d_sk);
+    }
+    if (!g->d_seq.empty()) group_drop_sequence(g);
     for (mm_workspace_t *ws : g->ws) mm_workspace_destroy(ws);
     delete g;
+}
+
+int mm_device_group_upload(mm_device_group_t *g, const uint8_t *packed, uint64_t packed_bytes) {
+    if (!g || g->ws.empty() || !packed || packed_bytes == 0) return MM_ERR_NULL;
+    group_drop_sequence(g);
+    // (+ 64 bytes of zeros: the walk's loads run a few dwords ahead of the last base)
+    for (size_t i = 0; i < g->ws.size(); ++i) {
+        MM_HIP(hipSetDevice(g->ws[i]->device));
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, packed_bytes + 64);
+        if (e != hipSuccess) {
+            g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+            group_drop_sequence(g);
+            return MM_ERR_ALLOC;
+        }
+        g->d_seq[i] = p;
+        g->own_seq[i] = 1;
+        // all copies in flight together (page-locked sources copy asynchronously; pageable ones serialise)
+        MM_HIP(hipMemsetAsync(static_cast<uint8_t *>(p) + packed_bytes, 0, 64, g->ws[i]->stream));
+        MM_HIP(hipMemcpyAsync(p, packed, packed_bytes, hipMemcpyHostToDevice, g->ws[i]->stream));
+    }
+    for (size_t i = 0; i < g->ws.size(); ++i) {
+        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(hipStreamSynchronize(g->ws[i]->stream));
+    }
+    g->seq_bytes = packed_bytes;
+    return MM_OK;
+}
+
+int mm_device_group_adopt(mm_device_group_t *g, const void *const *d_packed, uint64_t packed_bytes) {
+    if (!g || g->ws.empty() || !d_packed || packed_bytes == 0) return MM_ERR_NULL;
+    for (size_t i = 0; i < g->ws.size(); ++i)
+        if (!d_packed[i]) return MM_ERR_NULL;
+    group_drop_sequence(g);
+    for (size_t i = 0; i < g->ws.size(); ++i) g->d_seq[i] = const_cast<void *>(d_packed[i]);
+    g->seq_bytes = packed_bytes;
+    return MM_OK;
 }
 
 int mm_device_group_size(const mm_device_group_t *g) { return g ? (int)g->ws.size() : 0; }
@@ -1860,14 +1940,6 @@ int mm_run_sharded_host(const mm_plan_t *plan, mm_device_group_t *g, const uint8
         r.count = count;
         if (rc && rc != MM_ERR_CAPACITY) return fail(rc);
         if (rc == MM_ERR_CAPACITY) r.rc = rc;
-        if (out_pos && count && rc == MM_OK) {
-            uint32_t fl[2] = {0, 0};
-            if (hipMemcpy(&fl[0], ws->d_out, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess ||
-                hipMemcpy(&fl[1], ws->d_out + (count - 1), sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
-                return fail(MM_ERR_HIP);
-            r.first = fl[0];
-            r.last = fl[1];
-        }
     };
     {
         std::vector<std::thread> th;
@@ -1880,25 +1952,18 @@ int mm_run_sharded_host(const mm_plan_t *plan, mm_device_group_t *g, const uint8
             g_last_error = res[i].err;
             return res[i].rc;
         }
-    // ---- seam rule between consecutive shards (src/collect.rs:265-271): a shard's first position equal to the
-    // last one before it is the same minimizer seen again; syncmers have no such rule (src/syncmers.rs:166-169)
+    // ---- the seam between consecutive shards needs nothing here: the reference drops a lane's first position when
+    // it equals the last one before it (src/collect.rs:265-271), and a window-range run already starts by comparing
+    // with the window BEFORE its range (element 0 of its first lane), so a shard never begins with a repeat.  (Rounds
+    // 1-3 read every shard's first and last position back to apply a rule that could not fire.)
     std::vector<uint64_t> drop(N, 0), off(N + 1, 0);
     bool over = false;
-    {
-        bool have_last = false;
-        uint32_t last = 0;
-        for (uint64_t i = 0; i < N; ++i) {
-            if (res[i].rc == MM_ERR_CAPACITY) over = true;
-            if (res[i].count && !over && out_pos) {
-                if (plan->mode == MM_MINIMIZERS && have_last && res[i].first == last) drop[i] = 1;
-                last = res[i].last;
-                have_last = true;
-            }
-            off[i + 1] = off[i] + res[i].count - drop[i];
-        }
+    for (uint64_t i = 0; i < N; ++i) {
+        if (res[i].rc == MM_ERR_CAPACITY) over = true;
+        off[i + 1] = off[i] + res[i].count;
     }
     if (out_count) *out_count = off[N];
-    if (over || (out_pos && off[N] > capacity)) return MM_ERR_CAPACITY;  // (the count may miss seam drops then)
+    if (over || (out_pos && off[N] > capacity)) return MM_ERR_CAPACITY;
     if (!out_pos) return MM_OK;
     // ---- phase 2: every shard's positions to their place in the caller's buffer
     auto phase2 = [&](uint64_t i) {
@@ -1922,6 +1987,144 @@ int mm_run_sharded_host(const mm_plan_t *plan, mm_device_group_t *g, const uint8
             g_last_error = res[i].err;
             return res[i].rc;
         }
+    return MM_OK;
+}
+
+// ---- device-resident shards: one asynchronous launch per entry from the calling thread, results stay on the devices
+int mm_run_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, uint64_t base_offset, uint64_t n_bases,
+                          int want_superkmers, uint64_t *counts, uint64_t *total) {
+    if (!plan || !g || g->ws.empty()) return MM_ERR_NULL;
+    if (g->seq_bytes == 0) {
+        g_last_error = "mm_run_sharded_device: no resident sequence (mm_device_group_upload / _adopt first)";
+        return MM_ERR_NULL;
+    }
+    if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    if (want_superkmers && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;  // src/lib.rs:339
+    if ((base_offset + n_bases + 3) / 4 > g->seq_bytes) return MM_ERR_CAPACITY;
+    const uint64_t N = g->ws.size();
+    const uint64_t l = (uint64_t)plan->k + plan->w - 1;
+    const uint64_t n_w = n_bases >= l ? n_bases - l + 1 : 0;
+    if (total) *total = 0;
+    g->ran = true;
+    // expected positions per window (+ 15 % and a constant): a shard that needs more is run again with what it needs
+    const double dens = plan->mode == MM_OPEN_SYNCMERS ? 1.0 / plan->w
+                        : plan->mode == MM_CLOSED_SYNCMERS ? 2.0 / plan->w : 2.0 / (plan->w + 1.0);
+    std::vector<char> host_written(N, 0), pending(N, 0);
+    auto grow_shard = [&](uint64_t i, uint64_t need) -> int {
+        mm_device_group::Shard &s = g->shard[i];
+        int r = grow(s.d_pos, s.cap_pos, need ? need : 1, sizeof(uint32_t));
+        if (r == MM_OK && want_superkmers) r = grow(s.d_sk, s.cap_sk, need ? need : 1, sizeof(uint32_t));
+        return r;
+    };
+    auto issue = [&](uint64_t i) -> int {
+        mm_device_group::Shard &s = g->shard[i];
+        mm_workspace *ws = g->ws[i];
+        MM_HIP(hipSetDevice(ws->device));
+        bool hw = false;
+        ws->h_total[0] = 0;
+        ws->h_total[1] = 0;
+        const uint64_t cap = want_superkmers ? (s.cap_pos < s.cap_sk ? s.cap_pos : s.cap_sk) : s.cap_pos;
+        int r = run_device_async_impl(plan, ws, g->d_seq[i], g->seq_bytes + (g->own_seq[i] ? 64 : 0), base_offset, n_bases,
+                                      s.win_begin, s.win_end, s.d_pos, want_superkmers ? s.d_sk : nullptr, cap, nullptr,
+                                      false, nullptr, &hw);
+        if (r) return r;
+        if (!hw)
+            MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                  ws->stream));
+        host_written[i] = hw ? 1 : 0;
+        pending[i] = 1;
+        return MM_OK;
+    };
+    for (uint64_t i = 0; i < N; ++i) {
+        mm_device_group::Shard &s = g->shard[i];
+        s.win_begin = n_w / N * i + (n_w % N) * i / N;  // equal window ranges
+        s.win_end = i + 1 == N ? n_w : n_w / N * (i + 1) + (n_w % N) * (i + 1) / N;
+        s.count = 0;
+        s.has_sk = want_superkmers != 0;
+        if (s.win_begin >= s.win_end) continue;
+        const uint64_t nw = s.win_end - s.win_begin;
+        uint64_t want = (uint64_t)(dens * 1.15 * (double)nw) + 4096;
+        if (want > nw) want = nw;
+        MM_HIP(hipSetDevice(g->ws[i]->device));
+        int r = grow_shard(i, want);
+        if (r) return r;
+        r = issue(i);
+        if (r) return r;
+    }
+    // wait for the shards in turn; a shard that reports a look-back time-out or needs more room runs again
+    uint64_t sum = 0;
+    for (uint64_t i = 0; i < N; ++i) {
+        mm_device_group::Shard &s = g->shard[i];
+        mm_workspace *ws = g->ws[i];
+        for (int attempt = 0; pending[i] && attempt < 4; ++attempt) {
+            MM_HIP(hipSetDevice(ws->device));
+            MM_HIP(hipStreamSynchronize(ws->stream));
+            pending[i] = 0;
+            const int je = judge_run_error(ws);
+            if (je < 0) return je;
+            const uint64_t cnt = ws->h_total[0];
+            const uint64_t cap = want_superkmers ? (s.cap_pos < s.cap_sk ? s.cap_pos : s.cap_sk) : s.cap_pos;
+            if (je == 1 || cnt > cap) {  // ticket mode is now on / the true count is known
+                if (cnt > cap) {
+                    const int r = grow_shard(i, cnt);
+                    if (r) return r;
+                }
+                const int r = issue(i);
+                if (r) return r;
+                continue;
+            }
+            s.count = cnt;
+        }
+        if (pending[i]) {
+            g_last_error = "mm_run_sharded_device: a shard did not complete";
+            return MM_ERR_HIP;
+        }
+        if (counts) counts[i] = s.count;
+        sum += s.count;
+    }
+    if (total) *total = sum;
+    return MM_OK;
+}
+
+int mm_device_group_result(const mm_device_group_t *g, int entry, uint32_t **d_pos, uint32_t **d_sk, uint64_t *count,
+                           uint64_t *win_begin, uint64_t *win_end) {
+    if (!g || entry < 0 || (size_t)entry >= g->shard.size() || !g->ran) return MM_ERR_NULL;
+    const mm_device_group::Shard &s = g->shard[(size_t)entry];
+    if (d_pos) *d_pos = s.d_pos;
+    if (d_sk) *d_sk = s.has_sk ? s.d_sk : nullptr;
+    if (count) *count = s.count;
+    if (win_begin) *win_begin = s.win_begin;
+    if (win_end) *win_end = s.win_end;
+    return MM_OK;
+}
+
+int mm_device_group_gather(mm_device_group_t *g, int root, uint32_t *d_dst_pos, uint32_t *d_dst_sk, uint64_t capacity,
+                           uint64_t *total) {
+    if (!g || root < 0 || (size_t)root >= g->ws.size() || !g->ran) return MM_ERR_NULL;
+    uint64_t sum = 0;
+    for (const mm_device_group::Shard &s : g->shard) sum += s.count;
+    if (total) *total = sum;
+    if (sum > capacity) return MM_ERR_CAPACITY;
+    if (sum && !d_dst_pos) return MM_ERR_NULL;
+    const int root_dev = g->ws[(size_t)root]->device;
+    uint64_t off = 0;
+    for (size_t i = 0; i < g->ws.size(); ++i) {
+        const mm_device_group::Shard &s = g->shard[i];
+        mm_workspace *ws = g->ws[i];
+        if (s.count) {
+            if (d_dst_sk && !s.has_sk) return MM_ERR_BAD_MODE;
+            // every copy on its SOURCE entry's stream: all of them in flight together, one link each
+            MM_HIP(hipSetDevice(ws->device));
+            MM_HIP(hipMemcpyPeerAsync(d_dst_pos + off, root_dev, s.d_pos, ws->device, s.count * sizeof(uint32_t), ws->stream));
+            if (d_dst_sk)
+                MM_HIP(hipMemcpyPeerAsync(d_dst_sk + off, root_dev, s.d_sk, ws->device, s.count * sizeof(uint32_t), ws->stream));
+        }
+        off += s.count;
+    }
+    for (size_t i = 0; i < g->ws.size(); ++i) {
+        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(hipStreamSynchronize(g->ws[i]->stream));
+    }
     return MM_OK;
 }
 

@@ -7,23 +7,21 @@
 namespace mm {
 
 // packed-seq read_kmer: base j of the k-mer at bits 2j; read_revcomp_kmer: reversed, code ^ 2.
-__global__ __launch_bounds__(kBlockThreads) void values_u64_kernel(SeqView seq, uint32_t len,
-                                                                   int canonical,
-                                                                   const uint32_t *__restrict__ pos,
-                                                                   uint64_t n_pos,
-                                                                   unsigned long long *__restrict__ out) {
-    uint64_t i = (uint64_t)blockIdx.x * kBlockThreads + threadIdx.x;
-    if (i >= n_pos) return;
-    long long p = (long long)seq.base0 + (long long)pos[i];
-    long long q = p >> 4;
-    uint32_t sh = 2u * (uint32_t)(p & 15);
-    unsigned long long w0 = load_dword_clamped(seq, q);
-    unsigned long long w1 = load_dword_clamped(seq, q + 1);
-    unsigned long long w2 = load_dword_clamped(seq, q + 2);
-    unsigned long long lo = w0 | (w1 << 32);
-    unsigned long long v = sh ? (lo >> sh) | (w2 << (64u - sh)) : lo;
-    const unsigned long long mask = len >= 32 ? ~0ull : ((1ull << (2u * len)) - 1ull);
-    v &= mask;
+//
+// Round 4: FOUR values per thread.  The round-3 kernel made one value per thread - one 4-byte position load, three
+// dependent clamped dword loads, one 8-byte store: too few bytes in flight per wave to stream (3.2 TB/s of its 12 bytes
+// per value where pack_ascii reaches 5.4 on the same chip).  Now a thread loads four consecutive positions with one
+// 16-byte load, issues the four 16-byte sequence loads together (bounds-checked raw buffer loads: dwords past the end
+// read as 0, and every bit a valid position needs lies inside the sequence, so no clamping arithmetic), funnel-shifts
+// with v_alignbit, and stores the four values as two 16-byte stores - 32 contiguous bytes per lane.  Positions are in
+// window order, so the 256 positions of a wave fall into a few hundred bytes of sequence: the sequence loads hit the
+// same two or three lines.
+constexpr int kValuesPerThread = 4;
+
+__device__ __forceinline__ unsigned long long value_of(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t sh, uint32_t len,
+                                                       int canonical, unsigned long long mask) {
+    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    unsigned long long v = (((unsigned long long)hi << 32) | lo) & mask;
     if (canonical) {
         unsigned long long r = __brevll(v);  // reverses bit order: pairs reversed and bit-swapped
         r = ((r & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((r & 0x5555555555555555ull) << 1);
@@ -31,13 +29,58 @@ __global__ __launch_bounds__(kBlockThreads) void values_u64_kernel(SeqView seq, 
         r ^= 0xAAAAAAAAAAAAAAAAull & mask;  // complement: code ^ 2
         v = r < v ? r : v;
     }
-    out[i] = v;
+    return v;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void values_u64_kernel(SeqView seq, uint32_t len,
+                                                                   int canonical,
+                                                                   const uint32_t *__restrict__ pos,
+                                                                   uint64_t n_pos,
+                                                                   unsigned long long *__restrict__ out) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr uint64_t kPerBlock = (uint64_t)kBlockThreads * kValuesPerThread;
+    const uint64_t i0 = (uint64_t)blockIdx.x * kPerBlock;  // first value of the block
+    const uint64_t left = n_pos - i0;
+    const uint32_t here = left < kPerBlock ? (uint32_t)left : (uint32_t)kPerBlock;
+    // block-local bounds-checked views: positions in, values out (lanes past the end load 0 / store nothing)
+    const __amdgpu_buffer_rsrc_t rpos = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(pos + i0), 0, (int)(here * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out + i0, 0, (int)(here * 8u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rseq = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(seq.d), 0, seq.n_dwords >= 0x3fffffffu ? (int)0xfffffffcu : (int)(seq.n_dwords * 4u), 0x00020000);
+    const uint32_t t = threadIdx.x;
+    // (the position array may start at any 4-byte boundary: a 16-byte load needs no more)
+    const u32x4 pp = __builtin_amdgcn_raw_buffer_load_b128(rpos, t * 16u, 0, 0);
+    const uint32_t ps[4] = {pp.x, pp.y, pp.z, pp.w};
+    const unsigned long long mask = len >= 32 ? ~0ull : ((1ull << (2u * len)) - 1ull);
+    u32x4 w[kValuesPerThread];
+    uint32_t sh[kValuesPerThread];
+#pragma unroll
+    for (int u = 0; u < kValuesPerThread; ++u) {
+        const unsigned long long p = (unsigned long long)seq.base0 + ps[u];
+        sh[u] = 2u * (uint32_t)(p & 15u);
+        // (a sequence of 2^32 bases holds 2^28 dwords = 2^30 bytes: the byte offset fits 32 bits)
+        w[u] = __builtin_amdgcn_raw_buffer_load_b128(rseq, (uint32_t)(p >> 4) * 4u, 0, 0);
+    }
+    unsigned long long v[kValuesPerThread];
+#pragma unroll
+    for (int u = 0; u < kValuesPerThread; ++u) v[u] = value_of(w[u].x, w[u].y, w[u].z, sh[u], len, canonical, mask);
+#pragma unroll
+    for (int u = 0; u < kValuesPerThread; u += 2) {
+        u32x4 o;
+        o.x = (uint32_t)v[u];
+        o.y = (uint32_t)(v[u] >> 32);
+        o.z = (uint32_t)v[u + 1];
+        o.w = (uint32_t)(v[u + 1] >> 32);
+        // (the last pair of the array may be half inside: the bounds check works per dword, so its inner half is stored)
+        __builtin_amdgcn_raw_buffer_store_b128(o, rout, t * 32u + (uint32_t)u * 8u, 0, 0);
+    }
 }
 
 int launch_values_u64(SeqView seq, uint32_t len, int canonical, const uint32_t *d_pos,
                       uint64_t n_pos, unsigned long long *d_values, hipStream_t stream) {
     if (n_pos == 0) return 0;
-    uint32_t grid = (uint32_t)((n_pos + kBlockThreads - 1) / kBlockThreads);
+    const uint64_t per_block = (uint64_t)kBlockThreads * kValuesPerThread;
+    uint32_t grid = (uint32_t)((n_pos + per_block - 1) / per_block);
     hipLaunchKernelGGL(values_u64_kernel, dim3(grid), dim3(kBlockThreads), 0, stream, seq, len,
                        canonical, d_pos, n_pos, d_values);
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -350,3 +350,110 @@ def test_tapered_tail(sm, oracle, gpu, monkeypatch):
         c = sm.canonical_minimizers(21, 11).run_device(db, n2, ob)
         assert c == len(want) and np.array_equal(_dev(ob, c), want), env
     monkeypatch.delenv("MM_NO_TAPER")
+
+
+def test_values_u64_four_per_thread(sm, oracle, gpu):
+    """values_u64 makes four values per thread since round 4: every count around the blocks of 1024 values, every
+    length 1..32, both strands' choice, positions at the very end of the sequence, a position array that is only
+    4-byte aligned and a sequence buffer at an odd byte offset - against the oracle (src/lib.rs:584-612)."""
+    import torch
+    rng = np.random.default_rng(5)
+    n = 300_000
+    host = oracle.gen_packed(6, n + 64)
+    d = torch.from_numpy(host).cuda()
+    checked = 0
+    for ln in (1, 2, 5, 15, 16, 17, 21, 31, 32):
+        for canonical in (True, False):
+            for c in (1, 2, 3, 4, 5, 7, 1023, 1024, 1025, 2047, 4099, 50_001):
+                pos = np.sort(rng.integers(0, n - ln + 1, size=c)).astype(np.uint32)
+                pos[-1] = n - ln  # the last value ends with the sequence
+                dp = torch.zeros(c + 3, dtype=torch.int32, device="cuda")
+                shift = int(rng.integers(0, 3))  # the position array starts at any 4-byte boundary
+                dp[shift: shift + c] = torch.from_numpy(pos.view(np.int32)).cuda()
+                vals = torch.full((c + 2,), -1, dtype=torch.int64, device="cuda")
+                sm._check(sm.lib().mm_values_u64_device_async(gpu.h, C.c_void_p(d.data_ptr()), d.numel(), 0, n, ln,
+                                                              int(canonical), C.c_void_p(dp[shift:].data_ptr()), c,
+                                                              C.c_void_p(vals.data_ptr())))
+                gpu.sync()
+                want = oracle.values_u64(host, ln, pos, canonical)
+                got = vals.cpu().numpy()
+                assert np.array_equal(got[:c].view(np.uint64), want), (ln, canonical, c)
+                assert got[c] == -1 and got[c + 1] == -1, (ln, canonical, c)  # nothing past the count
+                checked += 1
+    # a sequence view that starts at an odd byte and a base offset
+    for byte_off, base_off in ((1, 0), (3, 2), (2, 3)):
+        m = n - 4 * byte_off - base_off
+        pos = np.sort(rng.integers(0, m - 21 + 1, size=3001)).astype(np.uint32)
+        dp = torch.from_numpy(pos.view(np.int32)).cuda()
+        vals = torch.zeros(3001, dtype=torch.int64, device="cuda")
+        sm._check(sm.lib().mm_values_u64_device_async(gpu.h, C.c_void_p(d[byte_off:].data_ptr()), d.numel() - byte_off,
+                                                      base_off, m, 21, 1, C.c_void_p(dp.data_ptr()), 3001,
+                                                      C.c_void_p(vals.data_ptr())))
+        gpu.sync()
+        want = oracle.values_u64(host, 21, pos, True, base_offset=4 * byte_off + base_off)
+        assert np.array_equal(vals.cpu().numpy().view(np.uint64), want), (byte_off, base_off)
+    assert checked == 9 * 2 * 12
+
+
+def test_device_resident_shards(sm, oracle, gpu):
+    """mm_device_group_upload / _adopt, mm_run_sharded_device, mm_device_group_result, mm_device_group_gather: the
+    sequence resident on every entry's device, one asynchronous launch per entry, the positions left on the devices
+    and gathered device-to-device.  Entries share this box's one GPU ({0, 0}, {0, 0, 0}): the shards laid end to end
+    must BE the oracle's result (exact seam), for minimizers, super-k-mer indices and syncmers, odd base offsets and a
+    tie-heavy sequence whose first shard overflows its expected capacity (re-run with the true count)."""
+    import torch
+    n = 5_000_037
+    host = oracle.gen_packed(31, n + 64)
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        g = sm.DeviceGroup(devices)
+        g.upload(host[: (n + 3) // 4 + 1])
+        for (k, w, canonical, mode, sk, off) in ((21, 11, True, 0, False, 0), (21, 11, False, 0, True, 3), (31, 51, True, 0, False, 1),
+                                                 (15, 17, True, 1, False, 2), (15, 17, True, 2, False, 0)):
+            m = n - off
+            b = sm.Builder(k, w, canonical, mode)
+            sk_list = []
+            if sk:
+                b = b.super_kmers(sk_list)
+            counts = g.run_device(b, m, base_offset=off)
+            if sk:
+                want, wsk = oracle.run(host, m, k, w, canonical=canonical, mode=mode, base_offset=off, super_kmers=True)
+            else:
+                want = oracle.run(host, m, k, w, canonical=canonical, mode=mode, base_offset=off)
+            assert sum(counts) == len(want), (devices, k, w, mode)
+            dst = torch.full((len(want) + 8,), -3, dtype=torch.int32, device="cuda")
+            dsk = torch.full((len(want) + 8,), -3, dtype=torch.int32, device="cuda") if sk else None
+            tot = g.gather(0, dst, dsk)
+            assert tot == len(want) and np.array_equal(_dev(dst, tot), want), (devices, k, w, mode)
+            assert int(dst[tot].item()) == -3
+            if sk:
+                assert np.array_equal(_dev(dsk, tot), wsk)
+            # the shards' own description: contiguous window ranges that cover every window, counts that add up
+            nw = m - (k + w - 1) + 1
+            prev_end = 0
+            for i in range(len(devices)):
+                dp, ds, cnt, wb, we = g.result(i)
+                assert wb == prev_end and cnt == counts[i] and (dp != 0 or cnt == 0) and ((ds != 0) == sk or cnt == 0)
+                prev_end = we
+            assert prev_end == nw
+            with pytest.raises(sm.MinimizerError) as e:
+                g.gather(0, dst[: max(1, tot // 2)])
+            assert e.value.code == sm.ERR["CAPACITY"]
+        g.close()
+    # adopted device buffers (the caller's own tensors) and a dense first shard: poly-A makes every window emit,
+    # far above the expected density, so the shard is run again with the count the kernel reported
+    asc = np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(2).integers(0, 4, 400_000)].copy()
+    asc[:150_000] = ord("A")
+    data = np.concatenate([oracle.pack_ascii(asc.tobytes()), np.zeros(64, dtype=np.uint8)])
+    t = torch.from_numpy(data).cuda()
+    g = sm.DeviceGroup([0, 0])
+    g.adopt([t, t])
+    counts = g.run_device(sm.minimizers(5, 3), 400_000)
+    want = oracle.run(data, 400_000, 5, 3, canonical=False)
+    dst = torch.zeros(len(want) + 1, dtype=torch.int32, device="cuda")
+    assert g.gather(1, dst) == len(want) and np.array_equal(_dev(dst, len(want)), want) and counts[0] > 140_000
+    g.close()
+    # no resident sequence: refused
+    g = sm.DeviceGroup([0])
+    with pytest.raises(sm.MinimizerError):
+        g.run_device(sm.minimizers(21, 11), 1000)
+    g.close()
