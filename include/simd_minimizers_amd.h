@@ -332,7 +332,7 @@ int mm_pack_ascii_n_device_async(mm_workspace_t *ws, const uint8_t *d_ascii, uin
  * mm_run_batch_device.  d_rec_text_pos[r] (optional) = byte offset of the record's '>' in the text (the
  * caller slices the header from there).  d_counts[0] = bases, d_counts[1] = records found; records past
  * max_records are counted but not tabulated.  The text must be shorter than 2^32 bytes.  The text is read once
- * (one kernel, 16 KB chunks chained by a decoupled look-back); a text whose lines are shorter than 16 bytes on
+ * (one kernel, 32 KB chunks chained by a decoupled look-back); a text whose lines are shorter than 16 bytes on
  * average, or a device that does not start workgroups in index order, makes that kernel give up: the synchronous
  * call below then repeats the text with the three-pass kernels by itself, an asynchronous caller gets MM_ERR_ORDER
  * from mm_workspace_check() and repeats the call (MM_FASTA_ONEPASS=0 takes the three-pass kernels from the start). */

@@ -1656,10 +1656,11 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
     const int r = grow(sp, ws->scratch_bytes, mm::fasta_scratch_bytes(n_bytes), 1);
     ws->scratch = sp;
     if (r) return r;
-    // The one-pass kernel over lines (mm_fasta.hip: the text read once, one decoupled look-back between 16 KB chunks)
+    // The one-pass kernel over lines (mm_fasta.hip: the text read once, one decoupled look-back between 32 KB chunks)
     // is the default since its third version (round 3: 0.96 ms for 1 GiB of 60-base lines against 1.66 ms for the
     // three passes); MM_FASTA_ONEPASS=0 takes the three-pass kernels, which also serve texts the one-pass kernel
-    // gives up on (lines shorter than 16 bytes on average; a look-back time-out).
+    // gives up on (lines shorter than 16 bytes on average - more than 2 048 line segments in a chunk; a look-back
+    // time-out).
     const char *env_one = mm::mm_env("MM_FASTA_ONEPASS");
     const bool one_pass = !(env_one && env_one[0] == '0') && !ws->fasta_three_pass && !ws->fasta_three_once;
     if (one_pass) MM_HIP(hipMemsetAsync(ws->total + 1, 0, sizeof(unsigned long long), ws->stream));
@@ -1675,8 +1676,13 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
 int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
                          uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
                          uint64_t max_records, uint64_t *d_counts, uint64_t *out_counts) {
-    if (!out_counts) return MM_ERR_NULL;
-    if (ws && d_text && n_bytes) {
+    if (!out_counts || !ws) return MM_ERR_NULL;  // (a null workspace used to reach the error branch below)
+    // whatever way this call ends, the per-call three-pass flag does not outlive it
+    struct ClearOnce {
+        mm_workspace_t *w;
+        ~ClearOnce() { w->fasta_three_once = false; }
+    } clear_once{ws};
+    if (d_text && n_bytes) {
         // FASTQ starts with '@' where FASTA starts with '>' (needletail tells them apart the same way)
         unsigned char head[256];
         const size_t nh = n_bytes < sizeof head ? (size_t)n_bytes : sizeof head;
@@ -1693,22 +1699,22 @@ int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_b
     for (int attempt = 0; attempt < 2; ++attempt) {
         const int r = mm_fasta_pack_device_async(ws, d_text, n_bytes, d_packed, packed_capacity_bytes, d_rec_base,
                                                  d_rec_text_pos, max_records, d_counts);
-        if (r) {
-            ws->fasta_three_once = false;
-            return r;
-        }
+        if (r) return r;
+        // (only an attempt that launched the one-pass kernel cleared the error word and may consult it: the three-pass
+        // kernels neither clear nor raise it, and a word left by an earlier failed run is not theirs - ADVICE r3)
+        const char *env_one = mm::mm_env("MM_FASTA_ONEPASS");
+        const bool was_one_pass = n_bytes != 0 && !(env_one && env_one[0] == '0') && !ws->fasta_three_pass && !ws->fasta_three_once;
         MM_HIP(hipMemcpyAsync(out_counts, d_counts, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ws->stream));
         MM_HIP(hipMemcpyAsync(ws->h_total + 1, ws->total + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                               ws->stream));
         MM_HIP(hipStreamSynchronize(ws->stream));
-        if (n_bytes == 0 || ws->fasta_three_pass || ws->fasta_three_once || (uint32_t)ws->h_total[1] == 0) break;
+        if (!was_one_pass || (uint32_t)ws->h_total[1] == 0) break;
         // the one-pass packer gave up: a look-back timed out (chunks not dispatched in order: three passes from now
         // on) or this text's lines are too short for its tables (error 3: three passes for this call)
         if ((uint32_t)ws->h_total[1] == 3u) ws->fasta_three_once = true;
         else ws->fasta_three_pass = true;
         if (!ws->async_unchecked) MM_HIP(hipMemsetAsync(ws->total + 2, 0, sizeof(unsigned long long), ws->stream));
     }
-    ws->fasta_three_once = false;
     if (out_counts[0] > (packed_capacity_bytes & ~3ull) * 4 || out_counts[1] > max_records) return MM_ERR_CAPACITY;
     return MM_OK;
 }

@@ -6,7 +6,16 @@
 // header are ignored; every sequence byte is packed as (c >> 1) & 3 like PackedSeqVec::from_ascii.
 //
 // All records are packed back to back into ONE 2-bit buffer (record r = bases [rec_base[r], rec_base[r+1]) of it,
-// any base offset - what mm_run_batch_device takes), so the job is a stream compaction of the text:
+// any base offset - what mm_run_batch_device takes), so the job is a stream compaction of the text.
+//
+// THE DEFAULT (round 3) is the ONE-PASS kernel fasta_lines_kernel further down ("the one-pass kernel over lines"):
+// the text is read once, every 32 KB chunk is staged in LDS, cut into line segments with a SWAR separator scan and
+// packed to its final place, and the chunks are chained by ONE decoupled look-back whose status word carries the line
+// / header context, the bases and the records before the chunk (a look-back over functions, not only over sums).
+// 1 GiB of 60-base lines: 0.87 ms (1.24 TB/s of text).  What follows first is the THREE-PASS family it replaced,
+// kept as the fallback for texts the one-pass kernel gives up on (more than 2 048 line segments in a chunk, a
+// look-back time-out: mm_fasta_pack_device repeats the call with it by itself) and as its cross-check
+// (tests/test_gpu_fasta.py, tests/test_gpu_round4.py):
 //   K1  per 32 KB chunk: position of its last '\n' and of its last record start (context-free: a '>' right after
 //       a '\n' starts a record whatever came before)
 //   S1  exclusive max-scan of both over the chunks (one workgroup) -> the line / record context at every chunk start
@@ -14,8 +23,7 @@
 //   S2  exclusive sum-scan of both
 //   K3  per chunk: 2-bit codes of its sequence bytes to their final place (staged in LDS, whole dwords stored,
 //       the two dwords a chunk shares with its neighbours OR-ed in), record table entries
-// Three passes over the text; for 3.1 GB that is ~10 GB of HBM reads against 56 ms of PCIe time to bring the
-// text in, so the passes are kept simple rather than fused behind a look-back.
+// Three passes over the text (1.66 ms for the same 1 GiB).
 #include "mm_common.h"
 #include "mm_launch.h"
 #include "mm_env.h"
