@@ -147,7 +147,7 @@ struct mm_workspace {
     // batch mode tables (sequence descriptors, tile -> sequence, per-sequence offsets)
     mm::BatchSeq *batch_seqs = nullptr;
     uint64_t batch_seqs_n = 0;
-    uint32_t *batch_tiles = nullptr;
+    mm::BatchTile *batch_tiles = nullptr;
     uint64_t batch_tiles_n = 0;
     unsigned long long *batch_offsets = nullptr;
     uint64_t batch_offsets_n = 0;
@@ -853,22 +853,24 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
         const uint64_t per_seq = a.work_windows / nonempty * 1024ull;
         if (per_seq < a.work_windows) a.work_windows = per_seq ? per_seq : 1;
     }
-    {
-        // lanes sized so that the batch fills whole rounds of resident workgroups (mm_fused.hip)
-        std::vector<uint64_t> nws(n_seqs);
-        for (uint64_t s = 0; s < n_seqs; ++s) nws[s] = n_bases[s] >= l ? n_bases[s] - l + 1 : 0;
-        const uint32_t nb = mm::fused_batch_nblk(a, nws.data(), n_seqs);
-        if (nb) a.nblk = nb;
-    }
-    const uint64_t NB = mm::fused_tile_windows(a);
-
     std::vector<mm::BatchSeq> seqs(n_seqs);
-    std::vector<uint32_t> tile_seq;
+    std::vector<mm::BatchTile> tile_seq;
+    std::vector<uint64_t> nws(n_seqs);
     for (uint64_t s = 0; s < n_seqs; ++s) {
         if (n_bases[s] >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
-        const uint64_t nw = n_bases[s] >= l ? n_bases[s] - l + 1 : 0;
+        nws[s] = n_bases[s] >= l ? n_bases[s] - l + 1 : 0;
+    }
+    {
+        // the tile table (mm_fused.hip): whole tiles per sequence, lanes sized for whole rounds of resident
+        // workgroups or - long batches - default lanes and a tapered last round
+        uint32_t nb = 0;
+        if (!mm::fused_batch_tiles(a, nws.data(), n_seqs, tile_seq, &nb)) return MM_BATCH_FALLBACK;
+        a.nblk = nb;
+    }
+    for (uint64_t s = 0; s < n_seqs; ++s) {
+        const uint64_t nw = nws[s];
         mm::BatchSeq &b = seqs[s];
-        b = mm::BatchSeq{nullptr, 0, 0, 0, (uint32_t)tile_seq.size(), {0, 0}};
+        b = mm::BatchSeq{nullptr, 0, 0, 0, 0, {0, 0}};
         if (nw == 0) continue;
         if (!d_packed[s]) return MM_ERR_NULL;
         mm::SeqView v;
@@ -878,9 +880,6 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
         b.n_dwords = v.n_dwords;
         b.base0 = v.base0;
         b.n_windows = (uint32_t)nw;
-        const uint64_t tiles = (nw + NB - 1) / NB;
-        if (tile_seq.size() + tiles >= (1ull << 31)) return MM_BATCH_FALLBACK;
-        tile_seq.insert(tile_seq.end(), (size_t)tiles, (uint32_t)s);
     }
     const uint64_t n_tiles = tile_seq.size();
     if (n_tiles == 0) {
@@ -889,13 +888,13 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
     }
     int r = grow(ws->batch_seqs, ws->batch_seqs_n, n_seqs, sizeof(mm::BatchSeq));
     if (r) return r;
-    r = grow(ws->batch_tiles, ws->batch_tiles_n, n_tiles, sizeof(uint32_t));
+    r = grow(ws->batch_tiles, ws->batch_tiles_n, n_tiles, sizeof(mm::BatchTile));
     if (r) return r;
     r = grow(ws->batch_offsets, ws->batch_offsets_n, n_seqs + 1, sizeof(unsigned long long));
     if (r) return r;
     MM_HIP(hipMemcpyAsync(ws->batch_seqs, seqs.data(), n_seqs * sizeof(mm::BatchSeq), hipMemcpyHostToDevice,
                           ws->stream));
-    MM_HIP(hipMemcpyAsync(ws->batch_tiles, tile_seq.data(), n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice,
+    MM_HIP(hipMemcpyAsync(ws->batch_tiles, tile_seq.data(), n_tiles * sizeof(mm::BatchTile), hipMemcpyHostToDevice,
                           ws->stream));
     a.batch_seqs = ws->batch_seqs;
     a.batch_tile_seq = ws->batch_tiles;

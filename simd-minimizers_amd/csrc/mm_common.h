@@ -62,6 +62,16 @@ struct BatchSeq {
     uint32_t pad[2];
 };
 
+// One tile of a batch launch (device table, 16 bytes): the sequence it belongs to, its first window (sequence-local)
+// and its lane length.  The host lays the tiles out (fused_batch_tiles, mm_fused.hip): whole tiles per sequence, the
+// last round of the LAUNCH tapered like a single sequence's (FusedParams::taper_*).
+struct BatchTile {
+    uint32_t seq;
+    uint32_t win0;
+    uint32_t nblk;
+    uint32_t pad;
+};
+
 struct OutParams {
     uint32_t *pos;
     uint32_t *sk;  // may be null

@@ -433,6 +433,60 @@ static Taper plan_taper(const RunArgs &a, const KernelRef &kr, const Geometry &g
     return t;
 }
 
+// The tile table of a batch launch.  Sequences in input order, whole tiles each (the last one of a sequence partial).
+// Long batches (the tapered round + half a round of whole tiles, as for single sequences) keep the default lanes and
+// taper the LAST ROUND OF THE LAUNCH: from the point where `cap_w` windows remain in the concatenated window stream,
+// tile j of the tapered stretch walks nblk - min(1 + j / per_level, lmax) blocks per lane (cut short where its
+// sequence ends).  k=31 w=51 on the 24 CHM13-like contigs: a slot cycle is 140 us, so uniform tiles idle the chip for
+// about 70 of the launch's 1 660 us at its end.  Shorter batches get uniform tiles of the whole-rounds tuner's length.
+bool fused_batch_tiles(const RunArgs &a0, const uint64_t *n_windows, uint64_t n_seqs, std::vector<BatchTile> &tiles,
+                       uint32_t *nblk_out) {
+    RunArgs a = a0;
+    Geometry g = geometry(a);
+    uint64_t total = 0;
+    for (uint64_t s = 0; s < n_seqs; ++s) total += n_windows[s];
+    const uint64_t blk_w = (uint64_t)kFusedThreads * a.w;
+    uint64_t zone_start = ~0ull, per_level = 1, lmax = 0;
+    const KernelRef kr = (a.nblk == 0 && total) ? resolve_kernel(a.w, a.canonical_windows, (int)a.ht.canonical, a.mode, a.out.sk != nullptr) : KernelRef();
+    int per_cu = 0, cus = 0;
+    if (kr && !mm_env("MM_NO_TAPER") && g.nblk >= kTaperMinBlocks + 4u && resident_slots(kr, g.lds_bytes, &per_cu, &cus)) {
+        uint64_t slots = (uint64_t)per_cu * cus;
+        if (const char *e = mm_env("MM_TAPER_SLOTS")) slots = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : slots;
+        lmax = g.nblk - kTaperMinBlocks;
+        per_level = (slots + lmax - 1) / lmax;
+        const uint64_t cap_w = per_level * blk_w * (lmax * g.nblk - lmax * (lmax + 1) / 2);
+        if (total >= cap_w + slots * (uint64_t)g.NB / 2) zone_start = total - cap_w;
+    }
+    if (zone_start == ~0ull && a.nblk == 0) {
+        const uint32_t nb = fused_batch_nblk(a, n_windows, n_seqs);  // uniform tiles: whole rounds
+        if (nb) {
+            a.nblk = nb;
+            g = geometry(a);
+        }
+    }
+    *nblk_out = g.nblk;
+    uint64_t cursor = 0, j = 0;  // windows of the concatenated stream before the next tile; tapered tiles so far
+    for (uint64_t s = 0; s < n_seqs; ++s) {
+        uint64_t w0 = 0;
+        const uint64_t nw = n_windows[s];
+        while (w0 < nw) {
+            uint32_t nb = g.nblk;
+            if (cursor >= zone_start) {
+                uint64_t l = 1 + j / per_level;
+                l = l < lmax ? l : lmax;
+                nb = g.nblk - (uint32_t)l;
+                ++j;
+            }
+            const uint64_t span = (uint64_t)nb * blk_w, take = nw - w0 < span ? nw - w0 : span;
+            if (tiles.size() + 1 >= (1ull << 31)) return false;
+            tiles.push_back(BatchTile{(uint32_t)s, (uint32_t)w0, nb, 0u});
+            w0 += take;
+            cursor += take;
+        }
+    }
+    return true;
+}
+
 int launch_fused(const RunArgs &a, hipStream_t stream) {
     Geometry g = geometry(a);
     if (g.nblocks == 0) return 0;

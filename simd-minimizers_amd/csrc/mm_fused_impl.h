@@ -144,7 +144,7 @@ struct FusedParams {
     // batch_seqs[]; positions are sequence-local; batch_offsets[s] receives the first output slot
     // of sequence s (written by its first tile), batch_offsets[n] the total.  Null = one sequence.
     const BatchSeq *batch_seqs;
-    const uint32_t *batch_tile_seq;
+    const BatchTile *batch_tile_seq;
     unsigned long long *batch_offsets;
     uint32_t batch_n;
     // timing experiments (MM_TRACE): 4 timestamps per tile (start, phase 1 done, look-back done, end)
@@ -1565,7 +1565,11 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     uint32_t nblk_t = p.nblk;
     unsigned long long tile_off = 0;  // first window of the tile relative to the range's first (single-sequence runs)
     bool tapered = false;
-    if (!READS && bid >= p.taper_first) {
+    const bool batch = !READS && p.batch_tile_seq != nullptr;
+    if (batch) {
+        nblk_t = __builtin_amdgcn_readfirstlane(p.batch_tile_seq[bid].nblk);  // (batches: the tile table says)
+        if (nblk_t > p.nblk) nblk_t = 0u;  // (never longer than the lists were sized for: refused below)
+    } else if (!READS && bid >= p.taper_first) {
         const uint32_t j = bid - p.taper_first, lmax = p.nblk - p.taper_min_nblk;
         uint32_t l = 1u + j / p.taper_per_level;
         l = l < lmax ? l : lmax;
@@ -1583,10 +1587,11 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     // the sequence this tile belongs to (tile-uniform scalars)
     const uint32_t *seq_d = p.seq.d;
     uint32_t seq_dwords = p.seq.n_dwords, seq_base0 = p.seq.base0;
-    uint32_t win_begin = p.win_begin, win_end = p.win_end, local_tile = bid, batch_s = 0;
-    const bool batch = !READS && p.batch_tile_seq != nullptr;
+    uint32_t win_begin = p.win_begin, win_end = p.win_end, local_tile = bid, batch_s = 0, batch_win0 = 0;
     if (batch) {
-        batch_s = __builtin_amdgcn_readfirstlane(p.batch_tile_seq[bid]);
+        const BatchTile bt = p.batch_tile_seq[bid];
+        batch_s = __builtin_amdgcn_readfirstlane(bt.seq);
+        batch_win0 = __builtin_amdgcn_readfirstlane(bt.win0);
         const BatchSeq bs = p.batch_seqs[batch_s];
         {
             const unsigned long long a = (unsigned long long)reinterpret_cast<uintptr_t>(bs.d);
@@ -1600,9 +1605,9 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         seq_base0 = __builtin_amdgcn_readfirstlane(bs.base0);
         win_begin = 0;
         win_end = __builtin_amdgcn_readfirstlane(bs.n_windows);
-        local_tile = bid - __builtin_amdgcn_readfirstlane(bs.first_tile);
+        local_tile = batch_win0;  // (only "is this the sequence's first tile" is asked of it below)
         // a table entry that does not describe this tile must never be dereferenced
-        if (batch_s >= p.batch_n || win_end == 0u || (uint64_t)local_tile * NB >= win_end || seq_d == nullptr) {
+        if (batch_s >= p.batch_n || win_end == 0u || batch_win0 >= win_end || seq_d == nullptr || nblk_t == 0u) {
             if (tid == 0) {
                 flag_error(p.out.error, 0xbad00000u | (bid & 0xfffffu));
                 p.out.error[1] = batch_s;
@@ -1616,7 +1621,9 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         p.trace[10 * (size_t)bid + 8] = ((unsigned long long)win_end << 32) | local_tile;
         p.trace[10 * (size_t)bid + 9] = batch_s;
     }
-    const uint64_t bw0 = READS ? 0ull : (uint64_t)win_begin + (tapered ? tile_off : (uint64_t)local_tile * NB);  // first window of the tile
+    const uint64_t bw0 = READS ? 0ull
+                     : batch ? (uint64_t)batch_win0
+                             : (uint64_t)win_begin + (tapered ? tile_off : (uint64_t)local_tile * NB);  // first window of the tile
     const uint32_t nvalid = READS ? NB
         : (uint32_t)(((uint64_t)win_end - bw0) < NB ? ((uint64_t)win_end - bw0) : NB);
     const bool partial = READS || nvalid < NB;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "mm_common.h"
 
@@ -22,7 +23,7 @@ struct RunArgs {
     uint32_t wamb_dwords;
     // batch mode of the fused family: many sequences, one launch (device tables; null = one sequence)
     const BatchSeq *batch_seqs;
-    const uint32_t *batch_tile_seq;
+    const BatchTile *batch_tile_seq;
     unsigned long long *batch_offsets;  // n + 1 entries
     uint32_t batch_n;
     uint64_t batch_tiles;
@@ -53,6 +54,11 @@ uint32_t fused_tile_windows(const RunArgs &a);
 // blocks per lane that make a batch fill whole rounds of resident workgroups (0 = keep the default);
 // the caller puts it into RunArgs::nblk before building the tile table
 uint32_t fused_batch_nblk(const RunArgs &a, const uint64_t *n_windows, uint64_t n_seqs);
+// The tile table of a batch launch: whole tiles per sequence in input order (a sequence's last tile may be partial),
+// the last round of the launch tapered.  Appends to `tiles`; returns false if the table would pass 2^31 tiles.
+// *nblk_out receives the longest lane of the table (RunArgs::nblk of the launch: it sizes the lists).
+bool fused_batch_tiles(const RunArgs &a, const uint64_t *n_windows, uint64_t n_seqs, std::vector<BatchTile> &tiles,
+                       uint32_t *nblk_out);
 // returns 0, -1 (HIP failure) or -2 (no kernel for this plan: take the generic family;
 // fused_unavailable_reason() says why)
 int launch_fused(const RunArgs &a, hipStream_t stream);

@@ -336,8 +336,23 @@ def test_tapered_tail(sm, oracle, gpu, monkeypatch):
                 c = b.run_device(d, n, out, win_begin=a, win_end=e)
                 assert c == len(wr) and np.array_equal(_dev(out, c), wr), (slots, k, w, canonical, a, e)
                 checked += 2
+    # batches: the last round of the LAUNCH tapers, across the sequences' ends (fused_batch_tiles)
+    for slots in (1, 3):
+        monkeypatch.setenv("MM_TAPER_SLOTS", str(slots))
+        for (k, w, canonical, mode) in ((21, 11, True, 0), (31, 51, True, 0), (21, 11, False, 0), (15, 17, True, 1)):
+            lens = [900_001, 5, 1_200_000, 0, 333_333, 64_000, 500_017]
+            starts = np.concatenate([[0], np.cumsum(np.array(lens) + 3)])[: len(lens)]
+            seqs = [d[int(s0) // 4:] for s0 in starts]
+            offs_b = [int(s0) % 4 for s0 in starts]
+            b = sm.Builder(k, w, canonical, mode)
+            offs = sm.run_batch_device(b, seqs, lens, out, base_offsets=offs_b)
+            flat = out[: offs[-1]].cpu().numpy().view(np.uint32)
+            for i, ln in enumerate(lens):
+                want = oracle.run(data, ln, k, w, canonical=canonical, mode=mode, base_offset=int(starts[i]))
+                assert np.array_equal(flat[offs[i]: offs[i + 1]], want), (slots, k, w, mode, i)
+            checked += 1
     monkeypatch.delenv("MM_TAPER_SLOTS")
-    assert checked >= 3 * (8 * 3 + 5 * 2)
+    assert checked >= 3 * (8 * 3 + 5 * 2) + 8
     # the real chip: 150 Mbp canonical k=21 w=11 tapers (threshold about 80 Mbp), element by element
     n2 = 150_000_001
     big = oracle.gen_packed(42, n2 + 64)
