@@ -1355,10 +1355,28 @@ __device__ __forceinline__ void copy_out_wave(const uint8_t *smem, const OutPara
                     // (round 2 experiment: storing every list as one or two full, aligned 128-byte lines
                     // instead changed the forward kernel by -1.5 % / +3 % - the stores cost by their bytes,
                     // not by their partial lines, so staging them into aligned runs would not pay)
+#ifdef MM_EXP_DENSE_STORES
+                    // Timing experiment (WRONG RESULTS by design): what a workgroup-dense copy-out
+                    // could gain at best.  The same values and the same bytes leave through FULL, 256-byte-aligned
+                    // 64-lane stores - row r of the wave's output region for the first ceil(total / 64) lists, nothing
+                    // for the others - i.e. the store stream of a perfect dense copy-out without the LDS transposition
+                    // it would need.  (The LDS reads and the value arithmetic of all 64 lists stay.)
+                    {
+                        (void)n;
+                        const uint32_t rows = (wave_total + 63u) / 64u;
+                        const unsigned long long base64 = run0_u & ~63ull;
+                        const __amdgpu_buffer_rsrc_t dl = __builtin_amdgcn_make_buffer_rsrc(
+                            const_cast<uint32_t *>(out.pos + base64), 0,
+                            (int)(((uint32_t)(L0 + u) < rows && room32 >= wave_total + 128u ? rows * 256u : 0u) & store_mask), 0x00020000);
+                        __builtin_amdgcn_raw_buffer_store_b32(val, dl, lane4, (uint32_t)(L0 + u) * 256u, MM_STORE_AUX);
+                    }
+                    const uint32_t end_bytes = 0u;  // (the super-k-mer store below: nothing in this experiment)
+#else
                     const uint32_t end_bytes = ((off + n) * 4u) & store_mask;  // (store_mask 0: timing experiment)
                     const __amdgpu_buffer_rsrc_t dl = __builtin_amdgcn_make_buffer_rsrc(
                         const_cast<uint32_t *>(obase32), 0, (int)end_bytes, 0x00020000);
                     __builtin_amdgcn_raw_buffer_store_b32(val, dl, lane4, off * 4u, MM_STORE_AUX);
+#endif
                     if (SK) {
                         const __amdgpu_buffer_rsrc_t dl2 = __builtin_amdgcn_make_buffer_rsrc(
                             const_cast<uint32_t *>(sbase32), 0, (int)end_bytes, 0x00020000);
