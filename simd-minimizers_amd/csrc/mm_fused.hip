@@ -11,7 +11,10 @@
 
 #include <cstdlib>
 #include <cstdio>
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace mm {
@@ -298,11 +301,31 @@ static uint32_t g_lds_pad = 0;
 // left alone (at most 4 % to win), as are batches (their tile table is built from the default).
 // tiles(S) = tiles of the run with S windows per lane; returns the chosen blocks per lane (g.nblk if
 // nothing is to be gained)
-// workgroups of this kernel the chip holds at once (occupancy x CUs); false if the runtime cannot say
+// workgroups of this kernel the chip holds at once (occupancy x CUs); false if the runtime cannot say.
+// (Answers are kept per kernel, LDS size and device: the two runtime queries cost microseconds, and a caller that
+// runs one short sequence per call pays them on every launch otherwise.)
 static bool resident_slots(const KernelRef &kr, uint32_t lds_bytes, int *per_cu_out, int *cus_out) {
     int per_cu = 0, cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    struct Key {
+        const void *fn;
+        uint32_t lds;
+        int dev;
+        bool operator<(const Key &o) const { return fn != o.fn ? fn < o.fn : (lds != o.lds ? lds < o.lds : dev < o.dev); }
+    };
+    static std::mutex mu;
+    static std::map<Key, std::pair<int, int>> cache;
+    const Key key{kr.host ? reinterpret_cast<const void *>(kr.host) : reinterpret_cast<const void *>(kr.mod), lds_bytes, dev};
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) {
+            *per_cu_out = it->second.first;
+            *cus_out = it->second.second;
+            return it->second.first > 0;
+        }
+    }
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return false;
     const hipError_t e =
         kr.host ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kr.host),
@@ -311,6 +334,10 @@ static bool resident_slots(const KernelRef &kr, uint32_t lds_bytes, int *per_cu_
     if (e != hipSuccess || per_cu < 1 || cus < 1) {
         (void)hipGetLastError();
         return false;
+    }
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        cache[key] = std::make_pair(per_cu, cus);
     }
     *per_cu_out = per_cu;
     *cus_out = cus;
@@ -503,7 +530,9 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     // k=31 w=51 on 268 Mbp 0.227 -> 0.180 ms, forward k=21 w=11 on 67 Mbp 0.0398 -> 0.0368; BELOW about half a round
     // the rule loses (k=31 w=51 on 134 Mbp: 0.151 ms with 768 tiles of 14 blocks against 0.111 with 1 028 of 10), so
     // shorter runs keep geometry()'s lanes.
-    if (a.nblk == 0 && !a.batch_tile_seq && !mm_env("MM_NO_ONE_ROUND")) {
+    // (runs of fewer than 128 tiles are below every rule's threshold on any chip: no queries, no planning)
+    const bool small_run = g.nblocks < 128 && !mm_env("MM_TAPER_SLOTS");
+    if (!small_run && a.nblk == 0 && !a.batch_tile_seq && !mm_env("MM_NO_ONE_ROUND")) {
         RunArgs full = a;
         full.work_windows = 0;  // (the default lanes of a long run)
         const Geometry gd = geometry(full);
@@ -523,8 +552,8 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
             }
         }
     }
-    const bool tapers = plan_taper(a, kr, g).first != 0xffffffffu && !mm_env("MM_TUNE_ALWAYS");
-    if (!tapers) {
+    const bool tapers = !small_run && plan_taper(a, kr, g).first != 0xffffffffu && !mm_env("MM_TUNE_ALWAYS");
+    if (!tapers && !small_run) {
         const Geometry untuned = g;
         tune_whole_rounds(a, kr, g);
         // never launch (or clear) more tile status words than the caller allocated: keep the default lanes
@@ -535,12 +564,14 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         }
         if (a.status_avail && (g.nblocks + 8) * status_stride_host() > a.status_avail) return -1;
     }
-    Taper taper = plan_taper(a, kr, g);
+    Taper taper = small_run ? Taper() : plan_taper(a, kr, g);
+    if (small_run) taper.tiles = g.nblocks;
     if (a.status_avail && (taper.tiles + 8) * status_stride_host() > a.status_avail) {
         taper = Taper();  // (a caller that reserved less than fused_status_words asked for: uniform tiles)
         taper.tiles = g.nblocks;
     }
     g.nblocks = taper.tiles;
+    if (a.status_avail && (g.nblocks + 8) * status_stride_host() > a.status_avail) return -1;  // (never past the caller's words)
 
     FusedParams p;
     p.seq = a.seq;
