@@ -416,7 +416,7 @@ def main():
         return statistics.median(ms), ms
 
     extras = []
-    if rank == 0 and world == 1 and not args.no_extra and args.workload == "headline" and args.bases == N_BASES:
+    if rank == 0 and world == 1 and not args.no_extra and args.workload == "headline" and args.bases == N_BASES and not os.environ.get("MM_BENCH_SKIP_SECONDARY"):
         # Secondary configurations of BASELINE.json (untimed region, before the headline so that they
         # also bring the clocks up): kernel time by HIP events, median of 5 after 12 warm-up steps.
         def secondary(name, builder, n, seed, density, contigs=None):
@@ -738,6 +738,26 @@ def main():
                     link["floor_ms_at_these_rates"] = round(max((n / 4) / (link["h2d_GBps"] * 1e9),
                                                                 (4 * n_out) / (link["d2h_GBps"] * 1e9)) * 1e3, 2)
                     del dbuf
+                    # where this process sits relative to the GPU: a page-locked buffer on the OTHER socket's memory makes
+                    # every transfer cross the inter-socket link as well (the same code measured 39.6 and 71.5 ms on boxes
+                    # of this pool whose one-way rates were both 57 GB/s)
+                    try:
+                        pr = torch.cuda.get_device_properties(dev)
+                        bdf = f"{int(pr.pci_domain_id):04x}:{int(pr.pci_bus_id):02x}:{int(pr.pci_device_id):02x}.0"
+                    except Exception:
+                        bdf = None
+                    try:
+                        gpu_node = int(open(f"/sys/bus/pci/devices/{bdf.lower()}/numa_node").read()) if bdf else None
+                    except Exception:
+                        gpu_node = None
+                    try:
+                        cpu = os.sched_getcpu()
+                        import glob as _glob
+                        nodes = _glob.glob(f"/sys/devices/system/cpu/cpu{cpu}/node*")
+                        cpu_node = int(os.path.basename(nodes[0])[4:]) if nodes else None
+                    except Exception:
+                        cpu_node = None
+                    link["numa"] = {"gpu_node": gpu_node, "cpu_node_of_this_thread": cpu_node}
                 except Exception as e:
                     link = {"error": str(e)[:120]}
                 end_to_end = {"ms": round(m, 2), "Gbases_per_s": round(n / m / 1e6, 1), "link": link,
