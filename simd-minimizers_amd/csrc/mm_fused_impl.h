@@ -1162,6 +1162,40 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     return (lp32 - list0) / kStride + dropped;
 }
 
+// Skip-ambiguous runs (round 4): does ANY lane of this wave have a skipped window in its range (or right before it)?
+// A wave-uniform answer from the window-ambiguity bits themselves - every lane ORs the S / 32 + 2 dwords that cover
+// its own windows, ends unmasked (a neighbour's bit only makes a clean wave look dirty).  A clean wave takes the
+// PLAIN walk: the instantiation that knows skipped windows carries the ambiguity words and their look-ahead on top of
+// a register budget that is already full for the larger windows, and ran at half speed whether or not anything was
+// skipped (k=31 w=51 on 1 Gbp: 1.13 ms against 0.59 plain).  A genome's Ns sit in a few gaps, so
+// nearly all waves are clean; the walks agree on clean ranges by construction.
+__device__ __forceinline__ bool wave_has_skipped(const FusedParams &p, const LaneCtx &ctx, uint32_t S, bool lane_active) {
+    // the wave's lanes walk consecutive ranges: one contiguous stretch of bits, read with coalesced 16-byte loads
+    // (a per-lane loop over each lane's own dwords cost 0.12 ms per Gbp at w = 51: 44 dependent strided loads a lane)
+    const uint32_t nw = ctx.rem_valid < (int)S ? (uint32_t)(ctx.rem_valid > 0 ? ctx.rem_valid : 0) : S;
+    uint32_t b0 = lane_active ? (ctx.abase ? ctx.abase - 1u : 0u) : 0xffffffffu;
+    uint32_t b1 = lane_active ? ctx.abase + nw : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        b0 = min(b0, (uint32_t)__shfl_xor((int)b0, d, kWave));
+        b1 = max(b1, (uint32_t)__shfl_xor((int)b1, d, kWave));
+    }
+    b0 = __builtin_amdgcn_readfirstlane(b0);
+    b1 = __builtin_amdgcn_readfirstlane(b1);
+    if (b1 <= b0) return false;  // (no lane of this wave walks)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.wamb), 0,
+                                                                       (int)(p.wamb_dwords * 4u), 0x00020000);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t q0 = (b0 >> 5) & ~3u, q1 = (b1 - 1u) >> 5;  // dwords [q0, q1], 16-byte groups
+    const int lane = threadIdx.x & (kWave - 1);
+    uint32_t any = 0;
+    for (uint32_t q = q0 + 4u * (uint32_t)lane; q <= q1; q += 4u * kWave) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, q * 4u, 0, 0);  // (past the end: zeros)
+        any |= v.x | v.y | v.z | v.w;
+    }
+    return __ballot(any != 0u) != 0ull;
+}
+
 // a no-progress round of lookback_overlapped sleeps up to 64 x 3.5 us: give up after about a second
 constexpr uint32_t kMaxIdleRounds = 1u << 12;
 
@@ -1717,9 +1751,10 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         set_min_rem(lane_active);
         if (redo) {
             my_count = reinterpret_cast<const uint16_t *>(p.dump + (size_t)bid * p.dump_stride)[tid];
-        } else if (lane_active && !(MM_DBG(p) & 4u)) {
+        } else if (const bool dirty = (kAmbi && p.wamb) ? wave_has_skipped(p, ctx, S, lane_active) : false;
+                   lane_active && !(MM_DBG(p) & 4u)) {
             bool over = false;
-            if (kAmbi && p.wamb)
+            if (kAmbi && p.wamb && dirty)
                 my_count = (partial || !kTwoBodies<W>)
                                ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi, kE8>(p, ctx, over)
                                : lane_walk<W, CANON, HASH_RC, MODE, SK, false, kAmbi && !kTwoBodies<W>, kAmbi, kE8>(p, ctx, over);
@@ -1907,9 +1942,10 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS_WALK) void walk_kernel
         {
             // ------------------------------------------------------------ the walk, into the lane lists
             uint32_t my_count = 0;
+            const bool dirty = (kAmbi && p.wamb) ? wave_has_skipped(p, ctx, S, lane_active) : false;
             if (lane_active && !(MM_DBG(p) & 4u)) {
                 bool over = false;
-                if (kAmbi && p.wamb)
+                if (kAmbi && p.wamb && dirty)
                     my_count = (partial || !kTwoBodies<W>)
                                    ? lane_walk<W, CANON, HASH_RC, MODE, SK, false, true, kAmbi, kE8>(p, ctx, over)
                                    : lane_walk<W, CANON, HASH_RC, MODE, SK, false, kAmbi && !kTwoBodies<W>, kAmbi, kE8>(p, ctx, over);

@@ -24,3 +24,10 @@ for (k, w) in ((21, 11), (31, 51), (31, 33)):
     print(f"k={k} w={w}: plain kernel {kt(lambda: b.run_device(d, n, out, sync=False, d_count=cnt)):.3f} ms | skip kernel, Ns as in the bench "
           f"{kt(lambda: b.run_skip_ambiguous_device(d, amb, n, out, sync=False, d_count=cnt)):.3f} | skip kernel, no N at all "
           f"{kt(lambda: b.run_skip_ambiguous_device(d, zero, n, out, sync=False, d_count=cnt)):.3f}", flush=True)
+# a genome-like pattern: 200 gaps of 50 kbp and nothing between them (round 4: clean waves take the plain walk)
+gaps = torch.zeros_like(amb)
+for s in torch.randint(0, n // 8 - 7000, (200,), generator=g, device="cuda").tolist():
+    gaps[s:s + 6250] = 0xFF
+for (k, w) in ((21, 11), (31, 51), (31, 33), (15, 17)):
+    b = sm.canonical_minimizers(k, w)
+    print(f"k={k} w={w}: skip kernel, 200 gaps of 50 kbp only {kt(lambda: b.run_skip_ambiguous_device(d, gaps, n, out, sync=False, d_count=cnt)):.3f} ms", flush=True)
