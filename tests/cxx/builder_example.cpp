@@ -126,6 +126,18 @@ int main() {
             std::vector<uint32_t> want = canonical_minimizers(21, 11).run_once(parts[i]);
             if (std::vector<uint32_t>(pos.begin() + offs[i], pos.begin() + offs[i + 1]) != want) return 24 + (int)i;
         }
+        // device-resident shards (round 4): the sequence uploaded once, one launch per entry, the counts back; the
+        // shards' window ranges are contiguous and their counts add up to the single-device result
+        group.upload(whole);
+        const std::vector<uint64_t> counts = group.run_device(canonical_minimizers(21, 11), whole.len);
+        uint64_t sum = 0, prev_end = 0;
+        for (int i = 0; i < group.size(); ++i) {
+            const DeviceGroup::Shard sh = group.result(i);
+            if (sh.count != counts[(size_t)i] || sh.win_begin != prev_end || (sh.count && !sh.d_pos)) return 30;
+            prev_end = sh.win_end;
+            sum += sh.count;
+        }
+        if (sum != one.size() || prev_end != big.size() - 31 + 1) return 31;
     }
     printf("builder_example ok\n");
     return 0;
