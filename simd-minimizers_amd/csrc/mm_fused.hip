@@ -421,9 +421,22 @@ uint32_t fused_batch_nblk(const RunArgs &a, const uint64_t *n_windows, uint64_t 
 // per-tile overhead more per slot.  Single sequences and window ranges with default lanes only (a caller who pins
 // the lane length gets exactly that; batches keep their tile table).  MM_NO_TAPER=1 switches it off (A/B; results
 // are identical either way).
-constexpr uint32_t kTaperMinBlocks = 4;
+constexpr uint32_t kTaperMinBlocksDefault = 4;
+// (tuning: MM_TAPER_MIN_BLOCKS = lane length of the last level; MM_TAPER_ROUNDS_PCT = tiles of the tapered stretch in % of
+// the chip's slots - 100: one tile per slot)
+static uint32_t taper_min_blocks() {
+    const char *e = mm_env("MM_TAPER_MIN_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 ? (uint32_t)v : kTaperMinBlocksDefault;
+}
+static uint64_t taper_slots_pct() {
+    const char *e = mm_env("MM_TAPER_ROUNDS_PCT");
+    const int v = e ? atoi(e) : 0;
+    return v >= 10 ? (uint64_t)v : 100u;
+}
+#define kTaperMinBlocks taper_min_blocks()
 struct Taper {
-    uint32_t first = 0xffffffffu, per_level = 1, min_nblk = kTaperMinBlocks;
+    uint32_t first = 0xffffffffu, per_level = 1, min_nblk = kTaperMinBlocksDefault;
     unsigned long long start = 0;
     uint64_t tiles = 0;  // tiles of the whole launch
 };
@@ -440,7 +453,7 @@ static Taper plan_taper(const RunArgs &a, const KernelRef &kr, const Geometry &g
     if (const char *e = mm_env("MM_TAPER_SLOTS")) slots = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : slots;
     const uint64_t nwin = a.win_end - a.win_begin;
     const uint64_t lmax = g.nblk - kTaperMinBlocks;          // levels 1 .. lmax: g.nblk - 1 .. kTaperMinBlocks blocks
-    const uint64_t per_level = (slots + lmax - 1) / lmax;
+    const uint64_t per_level = (slots * taper_slots_pct() / 100 + lmax - 1) / lmax;
     const uint64_t blk_w = (uint64_t)kFusedThreads * a.w;    // windows of one block of one tile
     const uint64_t cap_w = per_level * blk_w * (lmax * g.nblk - lmax * (lmax + 1) / 2);  // windows the levels hold
     // (a run has to hold the tapered round and at least half a round of whole tiles before it: shorter ones keep
@@ -454,6 +467,7 @@ static Taper plan_taper(const RunArgs &a, const KernelRef &kr, const Geometry &g
     const uint64_t tiles = f1 + per_level * lmax + extra;
     if (tiles >= (1ull << 31) || per_level >= (1ull << 31)) return t;
     t.first = (uint32_t)f1;
+    t.min_nblk = kTaperMinBlocks;
     t.per_level = (uint32_t)per_level;
     t.start = f1 * (uint64_t)g.NB;
     t.tiles = tiles;
@@ -480,7 +494,7 @@ bool fused_batch_tiles(const RunArgs &a0, const uint64_t *n_windows, uint64_t n_
         uint64_t slots = (uint64_t)per_cu * cus;
         if (const char *e = mm_env("MM_TAPER_SLOTS")) slots = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : slots;
         lmax = g.nblk - kTaperMinBlocks;
-        per_level = (slots + lmax - 1) / lmax;
+        per_level = (slots * taper_slots_pct() / 100 + lmax - 1) / lmax;
         const uint64_t cap_w = per_level * blk_w * (lmax * g.nblk - lmax * (lmax + 1) / 2);
         if (total >= cap_w + slots * (uint64_t)g.NB / 2) zone_start = total - cap_w;
     }
