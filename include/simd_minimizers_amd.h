@@ -344,11 +344,23 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
 /* The same, synchronous: out_counts[0..1] receive the counts; MM_ERR_CAPACITY when the bases did not fit
  * d_packed or the records did not fit the table (the counts say what is needed: out_counts[0] against
  * 4 * packed_capacity_bytes, out_counts[1] against max_records).  A text whose first non-blank byte is '@'
- * is FASTQ, which the reference's loader also reads and this packer does not: MM_ERR_FORMAT, nothing is
- * packed (the asynchronous entry point does not look and would pack no record from it). */
+ * is FASTQ, which the reference's loader reads through the same call (needletail::parse_fastx_file): since
+ * round 4 this entry point looks at that byte and packs FASTQ with mm_fastq_pack_device_async (same outputs).
+ * The asynchronous FASTA entry point above does not look and would pack no record from a FASTQ text. */
 int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
                          uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
                          uint64_t max_records, uint64_t *d_counts, uint64_t *out_counts /* [2] */);
+/* FASTQ text -> packed records (round 4; mm_fastq.hip): four-line records ('@' name, sequence, '+', qualities;
+ * "\r\n" or '\n', a last line without '\n', blank lines after the last record); the sequence of every record is
+ * packed like a FASTA record's, same output layout: record r = bases [d_rec_base[r], d_rec_base[r + 1]),
+ * d_rec_text_pos[r] = byte offset of its '@', d_counts = {bases, records}.  Reads of one length go straight into
+ * mm_run_reads_device (read_stride = read_len), any lengths into mm_run_batch_device.  needletail is not in the
+ * reference tree: parity unpinned like the FASTA packer's; no validation of '+' lines or quality lengths. */
+int mm_fastq_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes,
+                               uint8_t *d_packed, uint64_t packed_capacity_bytes,
+                               uint64_t *d_rec_base /* [max_records + 1] */,
+                               uint64_t *d_rec_text_pos /* [max_records] or NULL */, uint64_t max_records,
+                               uint64_t *d_counts /* [2] */);
 /* ------------------------------------------------------------------ several devices from one call
  * The reference's parallel driver is host code: rayon over the contigs, one Builder::run each
  * (bench/src/bin/paper.rs:442-459).  A device group holds one workspace (stream, scratch) per listed device; a

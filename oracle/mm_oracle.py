@@ -159,6 +159,32 @@ def fasta_records(text: bytes) -> list[tuple[int, bytes, bytes]]:
     return [(p, bytes(h), bytes(q)) for p, h, q in recs]
 
 
+def fastq_records(text: bytes) -> list[tuple[int, bytes, bytes]]:
+    """FASTQ reader restated (needletail::parse_fastx_file reads FASTQ through the same call, bench/src/lib.rs:51-82;
+    the crate is not in the tree - parity unpinned): records of FOUR lines - '@' + name, the sequence, '+', the
+    qualities; lines end with '\n' or '\r\n' ('\r' dropped), the last line may lack its '\n', blank lines after
+    the last record are ignored.  No validation (needletail errors on a malformed record).  Returns (byte offset of
+    '@', name without '@' and line end, sequence) per record."""
+    recs = []
+    lines = []  # (offset, content)
+    i, n = 0, len(text)
+    while i < n:
+        j = text.find(b"\n", i)
+        end = n if j < 0 else j
+        lines.append((i, text[i:end]))
+        i = end + 1
+    for r in range(0, len(lines), 4):
+        off, head = lines[r]
+        # (the first non-'\r' byte of a line 4r starts a record; a blank line 4r starts none)
+        stripped = head.replace(b"\r", b"")
+        if not stripped:
+            continue
+        first = off + next(k for k, c in enumerate(head) if c != 13)
+        seq = lines[r + 1][1].replace(b"\r", b"") if r + 1 < len(lines) else b""
+        recs.append((first, stripped[1:], seq))
+    return recs
+
+
 def gen_packed(seed: int, n: int, first_base: int = 0) -> np.ndarray:
     out = np.zeros((n + 3) // 4 + 16, dtype=np.uint8)
     if n:

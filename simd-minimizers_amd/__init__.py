@@ -158,6 +158,8 @@ def lib():
         fasta_args = [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, C.c_uint64, vp]
         L.mm_fasta_pack_device_async.argtypes = fasta_args
         L.mm_fasta_pack_device.argtypes = fasta_args + [u64p]
+        if hasattr(L, "mm_fastq_pack_device_async"):
+            L.mm_fastq_pack_device_async.argtypes = fasta_args
         _lib = L
     return _lib
 
@@ -176,7 +178,7 @@ EXPORTED_SYMBOLS = [
     "mm_run_skip_ambiguous_host_ascii", "mm_run_reads_skip_ambiguous_device_async",
     "mm_run_reads_skip_ambiguous_device", "mm_pack_ascii_n_device_async", "mm_pack_ascii_device_async",
     "mm_host_alloc", "mm_host_free",
-    "mm_generate_device_async", "mm_fasta_pack_device_async", "mm_fasta_pack_device",
+    "mm_generate_device_async", "mm_fasta_pack_device_async", "mm_fasta_pack_device", "mm_fastq_pack_device_async",
     "mm_clock_probe_begin", "mm_clock_probe_end",
     "mm_device_group_create", "mm_device_group_destroy", "mm_device_group_size", "mm_run_sharded_host",
     "mm_run_batch_sharded_host",
@@ -905,7 +907,8 @@ class FastaRecords:
 
 def fasta_pack_device(text, max_records: int = 1 << 16, device: int = 0) -> FastaRecords:
     """needletail::parse_fastx_file + PackedSeqVec::from_ascii of every record (bench/src/lib.rs:51-82) on the
-    device: ``text`` = the FASTA file's bytes (bytes / numpy uint8 / torch uint8 CUDA tensor)."""
+    device: ``text`` = the file's bytes (bytes / numpy uint8 / torch uint8 CUDA tensor), FASTA or - since round 4,
+    told apart by the first non-blank byte like needletail does - FASTQ (four-line records)."""
     import torch
 
     dev = f"cuda:{device}"
@@ -934,6 +937,9 @@ def fasta_pack_device(text, max_records: int = 1 << 16, device: int = 0) -> Fast
     n_rec = int(out[1])
     return FastaRecords(packed, rec_base[: n_rec + 1].cpu().numpy().astype(np.uint64),
                         rec_pos[:n_rec].cpu().numpy().astype(np.uint64))
+
+
+fastx_pack_device = fasta_pack_device  # (the reference's loader call reads both formats)
 
 
 def run_fasta_device(builder: "Builder", records: FastaRecords, out_pos, out_sk=None):

@@ -1672,6 +1672,32 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
     return MM_OK;
 }
 
+// FASTQ (round 4): four-line records, the sequence of every record packed like a FASTA record's (mm_fastq.hip).
+int mm_fastq_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
+                               uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
+                               uint64_t max_records, uint64_t *d_counts) {
+    if (!ws || !d_counts || !d_rec_base) return MM_ERR_NULL;
+    if (n_bytes >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    if (reinterpret_cast<uintptr_t>(d_packed) % 4 != 0) return MM_ERR_NULL;
+    MM_HIP(hipSetDevice(ws->device));
+    if (n_bytes == 0) {
+        MM_HIP(hipMemsetAsync(d_counts, 0, 2 * sizeof(uint64_t), ws->stream));
+        MM_HIP(hipMemsetAsync(d_rec_base, 0, sizeof(uint64_t), ws->stream));
+        return MM_OK;
+    }
+    if (!d_text || (!d_packed && packed_capacity_bytes)) return MM_ERR_NULL;
+    uint8_t *sp = reinterpret_cast<uint8_t *>(ws->scratch);
+    const int r = grow(sp, ws->scratch_bytes, mm::fastq_scratch_bytes(n_bytes), 1);
+    ws->scratch = sp;
+    if (r) return r;
+    if (mm::launch_fastq_pack(d_text, n_bytes, d_packed, packed_capacity_bytes & ~3ull,
+                              reinterpret_cast<unsigned long long *>(d_rec_base),
+                              reinterpret_cast<unsigned long long *>(d_rec_text_pos), max_records,
+                              reinterpret_cast<unsigned long long *>(d_counts), ws->scratch, ws->stream))
+        return hip_fail(hipGetLastError(), "fastq_pack");
+    return MM_OK;
+}
+
 int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
                          uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
                          uint64_t max_records, uint64_t *d_counts, uint64_t *out_counts) {
@@ -1691,8 +1717,14 @@ int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_b
         size_t i = 0;
         while (i < nh && (head[i] == ' ' || head[i] == '\t' || head[i] == '\r' || head[i] == '\n')) ++i;
         if (i < nh && head[i] == '@') {
-            g_last_error = "mm_fasta_pack_device: the text starts with '@' (FASTQ)";
-            return MM_ERR_FORMAT;
+            // FASTQ (needletail::parse_fastx tells the formats apart by this byte too): the four-line packer
+            const int r = mm_fastq_pack_device_async(ws, d_text, n_bytes, d_packed, packed_capacity_bytes, d_rec_base,
+                                                     d_rec_text_pos, max_records, d_counts);
+            if (r) return r;
+            MM_HIP(hipMemcpyAsync(out_counts, d_counts, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ws->stream));
+            MM_HIP(hipStreamSynchronize(ws->stream));
+            if (out_counts[0] > (packed_capacity_bytes & ~3ull) * 4 || out_counts[1] > max_records) return MM_ERR_CAPACITY;
+            return MM_OK;
         }
     }
     for (int attempt = 0; attempt < 2; ++attempt) {

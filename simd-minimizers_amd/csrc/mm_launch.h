@@ -139,6 +139,11 @@ int launch_fasta_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed
                       unsigned long long *d_rec_base, unsigned long long *d_rec_pos, uint64_t max_records,
                       unsigned long long *d_counts, void *scratch, hipStream_t stream, bool one_pass = false,
                       uint32_t *d_error = nullptr);
+// ---- FASTQ text -> packed records (mm_fastq.hip): four-line records, the sequences of lines 4r + 1
+uint64_t fastq_scratch_bytes(uint64_t n_bytes);
+int launch_fastq_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed, uint64_t packed_capacity_bytes,
+                      unsigned long long *d_rec_base, unsigned long long *d_rec_pos, uint64_t max_records,
+                      unsigned long long *d_counts, void *scratch, hipStream_t stream);
 // diagnostics: shader clock while other kernels run (out: 2 words per workgroup)
 int launch_clock_probe(unsigned long long *d_out, uint32_t workgroups, uint64_t ticks, hipStream_t stream);
 int launch_generate(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d_packed,

@@ -10,7 +10,7 @@ import ctypes as C
 
 from . import (Builder, _check, canonical_minimizers, lib, run_reads_device)
 
-COMPONENTS = ("READS", "READS_SK", "SKIP", "VALUES", "PACK", "FASTA")
+COMPONENTS = ("READS", "READS_SK", "SKIP", "VALUES", "PACK", "FASTA", "FASTQ")
 
 
 def _generate(ws, dev, n, seed):
@@ -121,6 +121,38 @@ def component(name, ws, dev):
                 "what": f"FASTA text -> packed records on the device (needletail + from_ascii, bench/src/lib.rs:51-82): "
                         f"{n} bytes of text, {width}-base lines, {n_rec} records",
                 "kernels": ["fasta"]}
+    if name == "FASTQ":
+        # 150 bp reads: '@' + 19 name bytes, the sequence, '+', the qualities = 324 bytes per record
+        rl, name_len = 150, 19
+        rec_bytes = (1 + name_len + 1) + (rl + 1) + 2 + (rl + 1)
+        n_rec = (1 << 30) // rec_bytes
+        n = n_rec * rec_bytes
+        g = torch.Generator(device=dev)
+        g.manual_seed(2)
+        t = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (n,), device=dev, generator=g)]
+        i = torch.arange(n, device=dev) % rec_bytes
+        t[i == 0] = ord("@")
+        for p in (name_len + 1, name_len + 2 + rl, name_len + 2 + rl + 2, rec_bytes - 1):
+            t[i == p] = 10
+        t[i == name_len + 2 + rl + 1] = ord("+")
+        del i
+        packed = torch.empty(n // 4 + 64, dtype=torch.uint8, device=dev)
+        rb = torch.zeros(n_rec + 1, dtype=torch.int64, device=dev)
+        rp = torch.zeros(n_rec, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+
+        def step():
+            _check(L.mm_fastq_pack_device_async(ws.h, C.c_void_p(t.data_ptr()), n, C.c_void_p(packed.data_ptr()),
+                                                packed.numel() // 4 * 4, C.c_void_p(rb.data_ptr()),
+                                                C.c_void_p(rp.data_ptr()), n_rec, C.c_void_p(cnt.data_ptr())))
+
+        def alg():
+            assert int(cnt[1].item()) == n_rec and int(cnt[0].item()) == n_rec * rl
+            return n + (n_rec * rl + 3) // 4 + 16 * n_rec
+        return {"step": step, "units": n, "unit": "text bytes", "alg_bytes": alg, "keep": (t, packed, rb, rp, cnt),
+                "what": f"FASTQ text -> packed reads on the device (needletail + from_ascii, bench/src/lib.rs:51-82): {n} bytes "
+                        f"of text, {n_rec} records of {rl} bases",
+                "kernels": ["fastq"]}
     raise ValueError("unknown component " + name)
 
 

@@ -167,14 +167,8 @@ def test_status_words_cover_the_tuned_grid(sm, gpu):
 # since round 4 - the MM_DEBUG=32 hook lives in the experiments build, which that test loads in a child process)
 
 
-def test_fasta_packer_refuses_fastq(sm, gpu):
-    text = b"@read1\nACGTACGT\n+\nIIIIIIII\n@read2\nTTTT\n+\nIIII\n"
-    with pytest.raises(sm.MinimizerError) as e:
-        sm.fasta_pack_device(text)
-    assert e.value.code == sm.ERR["FORMAT"]
-    with pytest.raises(sm.MinimizerError) as e:
-        sm.fasta_pack_device(b"\n\n  @r\nACGT\n+\nIIII\n")
-    assert e.value.code == sm.ERR["FORMAT"]
+def test_fasta_packer_record_table_limit(sm, gpu):
+    # (FASTQ was refused here until round 4: tests/test_gpu_round4.py::test_fastq_packer)
     rec = sm.fasta_pack_device(b">a\nACGT\n>b\nTT\n")
     assert len(rec) == 2
     with pytest.raises(sm.MinimizerError) as e:

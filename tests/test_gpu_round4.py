@@ -472,3 +472,86 @@ def test_device_resident_shards(sm, oracle, gpu):
     with pytest.raises(sm.MinimizerError):
         g.run_device(sm.minimizers(21, 11), 1000)
     g.close()
+
+
+def _check_fastq(sm, oracle, text, max_records=1 << 16):
+    import torch
+    rec = sm.fasta_pack_device(text, max_records=max_records)
+    want = oracle.fastq_records(bytes(text))
+    assert len(rec) == len(want), (len(rec), len(want))
+    packed = rec.packed.cpu().numpy()
+    for i, (pos, name, seq) in enumerate(want):
+        b, e = int(rec.base[i]), int(rec.base[i + 1])
+        assert e - b == len(seq), (i, e - b, len(seq))
+        assert int(rec.text_pos[i]) == pos, i
+        if i < 50 or i % 997 == 0 or i >= len(want) - 3:
+            codes = [(packed[(b + j) // 4] >> (2 * ((b + j) % 4))) & 3 for j in range(len(seq))]
+            assert codes == [(c >> 1) & 3 for c in seq], i
+    return rec
+
+
+def test_fastq_packer(sm, oracle, gpu):
+    """FASTQ text -> packed records on the device (mm_fastq.hip; mm_fasta_pack_device tells the formats apart by the
+    first non-blank byte like needletail::parse_fastx_file): four-line records against the oracle's reader - CRLF, no
+    trailing newline, empty reads, blank lines after the last record, reads longer than a chunk, sizes around the 4 KB
+    chunks, an unaligned text pointer, the record-table limit; then reads of one length straight into the reads-mode
+    kernel and of any lengths into a batch launch, every read's minimizers against the oracle."""
+    import torch
+    rng = np.random.default_rng(21)
+    _check_fastq(sm, oracle, b"@r1 x\nACGT\n+\nIIII\n@r2\r\nTTGA\r\n+r2\r\nIIII\r\n@r3\n\n+\n\n@r4\nAC")
+    _check_fastq(sm, oracle, b"@a\nAC\n+\nII\n\n\n")
+    _check_fastq(sm, oracle, b"\n  @a\nACGTTTGA\n+\nIIIIIIII\n"[1:].lstrip())
+    acgt = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)
+
+    def make(n_reads, lens, crlf=False, final_newline=True):
+        parts = []
+        nl = b"\r\n" if crlf else b"\n"
+        for r in range(n_reads):
+            ln = int(lens[r])
+            seq = acgt[rng.integers(0, 9, ln)].tobytes()
+            qual = bytes(rng.integers(33, 74, ln).astype(np.uint8))
+            parts.append(b"@read%d/1 len=%d" % (r, ln) + nl + seq + nl + (b"+" if r % 3 else b"+read%d" % r) + nl + qual + nl)
+        text = b"".join(parts)
+        return text if final_newline else text[: -len(nl)]
+    for n_reads, lo, hi, crlf, fin in ((1, 1, 2, False, True), (7, 0, 30, False, False), (500, 100, 151, False, True),
+                                       (300, 150, 151, True, True), (40, 3000, 9000, False, True), (3000, 0, 40, True, False)):
+        text = make(n_reads, rng.integers(lo, hi, n_reads), crlf, fin)
+        _check_fastq(sm, oracle, text)
+    # lengths of the text around the chunk size, and an unaligned device pointer
+    base = make(400, rng.integers(90, 151, 400))  # about 120 KB of text
+    for cut in (4095, 4096, 4097, 8191, 8192, 12289, 16383, 16384, 16385, 32769, 65535, 65537):
+        piece = base[:cut]
+        _check_fastq(sm, oracle, piece)
+    want_base = oracle.fastq_records(base)
+    for off in (1, 2, 3):
+        tt = torch.from_numpy(np.frombuffer(b"x" * off + base, dtype=np.uint8).copy()).cuda()
+        rec = sm.fasta_pack_device(tt[off:], max_records=1 << 12)
+        assert len(rec) == 400 and [int(x) for x in rec.text_pos[:5]] == [p for p, _, _ in want_base[:5]]
+        assert rec.lengths() == [len(q) for _, _, q in want_base]
+    with pytest.raises(sm.MinimizerError) as e:
+        sm.fasta_pack_device(make(10, [5] * 10), max_records=4)
+    assert e.value.code == sm.ERR["CAPACITY"]
+    # FASTQ -> reads-mode kernel (one length) and -> batch launch (any lengths); every read against the oracle
+    n_reads, ln = 2000, 150
+    text = make(n_reads, [ln] * n_reads)
+    rec = _check_fastq(sm, oracle, text)
+    want = oracle.fastq_records(text)
+    b = sm.canonical_minimizers(21, 11)
+    out = torch.zeros(n_reads * ln, dtype=torch.int32, device="cuda")
+    offs = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
+    total = sm.run_reads_device(b, rec.packed, n_reads, ln, ln, out, offs)
+    ho = offs.cpu().numpy()
+    flat = out[:total].cpu().numpy().view(np.uint32)
+    for r in (0, 1, 777, n_reads - 1):
+        seq_packed = oracle.pack_ascii(want[r][2])
+        w_r = oracle.run(np.concatenate([seq_packed, np.zeros(16, dtype=np.uint8)]), ln, 21, 11, canonical=True)
+        assert np.array_equal(flat[ho[r]:ho[r + 1]], w_r), r
+    text2 = make(300, rng.integers(31, 400, 300))
+    rec2 = _check_fastq(sm, oracle, text2)
+    want2 = oracle.fastq_records(text2)
+    offs2 = sm.run_fasta_device(b, rec2, out)
+    flat2 = out[: offs2[-1]].cpu().numpy().view(np.uint32)
+    for r in (0, 5, 150, 299):
+        seq_packed = oracle.pack_ascii(want2[r][2])
+        w_r = oracle.run(np.concatenate([seq_packed, np.zeros(16, dtype=np.uint8)]), len(want2[r][2]), 21, 11, canonical=True)
+        assert np.array_equal(flat2[offs2[r]: offs2[r + 1]], w_r), r

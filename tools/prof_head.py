@@ -156,7 +156,7 @@ def component(tag, cfg):
     import importlib.util
     spec = importlib.util.spec_from_file_location("wl", os.path.join(ROOT, "simd-minimizers_amd", "workloads.py"))
     likes = {"READS": ["fused_kernel"], "READS_SK": ["fused_kernel"], "SKIP": ["window_ambiguity_kernel", "fused_kernel"],
-             "VALUES": ["values_u64_kernel"], "PACK": ["pack_ascii"], "FASTA": ["fasta"]}[cfg]
+             "VALUES": ["values_u64_kernel"], "PACK": ["pack_ascii"], "FASTA": ["fasta"], "FASTQ": ["fastq"]}[cfg]
     lines = []
     db = rocprof(f"{tag}_{cfg}_stats", None, ["python3", "tools/run_config.py", cfg, "5", "3"])
     lines.append(f"== rocprofv3 --kernel-trace --stats -- python3 tools/run_config.py {cfg} 5 3\n")
@@ -203,7 +203,7 @@ if __name__ == "__main__":
     for what in sys.argv[2:]:
         if what == "headline":
             headline(tag)
-        elif what in ("READS", "READS_SK", "SKIP", "VALUES", "PACK", "FASTA"):
+        elif what in ("READS", "READS_SK", "SKIP", "VALUES", "PACK", "FASTA", "FASTQ"):
             component(tag, what)
         else:
             config(tag, what)
