@@ -306,3 +306,33 @@ def test_fasta_reader_restatement(oracle):
     assert recs == [(5, b"chr1 test", b"ACGTAC"), (27, b"c2", b""), (31, b"c3", b"GG>TA")]
     assert oracle.fasta_records(b"") == [] and oracle.fasta_records(b"ACGT\n") == []
     assert oracle.fasta_records(b">x") == [(0, b"x", b"")]
+
+
+def test_fastq_reader_restatement(oracle):
+    """oracle.fastq_records (four-line records; needletail is not in the tree: parity unpinned) on hand-made texts: CRLF,
+    a last line without its newline, an empty read, blank lines after the last record."""
+    t = b"@r1 x\nACGT\n+\nIIII\n@r2\r\nTTGA\r\n+r2\r\nIIII\r\n@r3\n\n+\n\n@r4\nAC"
+    assert oracle.fastq_records(t) == [(0, b"r1 x", b"ACGT"), (18, b"r2", b"TTGA"), (40, b"r3", b""), (48, b"r4", b"AC")]
+    assert oracle.fastq_records(b"@a\nAC\n+\nII\n\n\n") == [(0, b"a", b"AC")]
+    assert oracle.fastq_records(b"") == []
+    # the sequence packs like a FASTA record's
+    assert list(oracle.pack_ascii(b"ACGT")[:1]) == [0 | (1 << 2) | (3 << 4) | (2 << 6)]
+
+
+def test_embedded_kernel_source_is_stripped():
+    """The kernel source the library embeds for the run-time specialisation carries no comments (strip_comments.py): the
+    shipped .so must not name experiment switches, and the stripped text must keep its line structure."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "simd-minimizers_amd", "csrc", "strip_comments.py")
+    spec = importlib.util.spec_from_file_location("strip_comments", path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    src = 'int a; // note MM_DEBUG\n#define X(a) \\\n  a /* block\n comment */ + 1 // tail \\\n  + 2\nconst char *s = "// not a comment"; /* x */\n'
+    out = m.strip(src)
+    assert "MM_DEBUG" not in out and "block" not in out and '"// not a comment"' in out
+    assert out.count("\n") == src.count("\n")
+    header = open(os.path.join(root, "simd-minimizers_amd", "csrc", "mm_fused_impl.h")).read()
+    stripped = m.strip(header)
+    assert "MM_DEBUG" not in stripped and stripped.count("\n") == header.count("\n")
+    assert "fused_kernel" in stripped and "v_cmpx_ne_u32_sdwa" in stripped
