@@ -414,6 +414,25 @@ int mm_device_group_result(const mm_device_group_t *group, int entry, uint32_t *
 int mm_device_group_gather(mm_device_group_t *group, int root, uint32_t *d_dst_pos, uint32_t *d_dst_sk /* or NULL */,
                            uint64_t capacity, uint64_t *total);
 
+/* ---- device-resident BATCHES (round 4): north_star's "sharded by contig across the GPUs of a node, gather of the
+ * positions".  mm_device_group_upload_batch places n_seqs independent sequences greedily, longest first, on the
+ * entries of the group and copies each to ITS entry's device only (kept until the next batch upload / the group's
+ * end).  mm_run_batch_sharded_device runs every entry's sequences in ONE batch launch on its device (Builder::run per
+ * sequence, sequence-local positions, bench/src/bin/paper.rs:425-431,442-459); the positions stay on the devices.
+ * n_bases[s] (and base_offsets[s], or NULL) describe sequence s of the upload; out_counts[s] (may be NULL) receives
+ * its count, *total their sum.  mm_device_group_batch_result hands out where a sequence's positions lie;
+ * mm_device_group_gather_batch copies all sequences, in input order, into device memory of entry `root`
+ * (device-to-device) and fills the n_seqs + 1 offsets. */
+int mm_device_group_upload_batch(mm_device_group_t *group, uint64_t n_seqs, const uint8_t *const *packed,
+                                 const uint64_t *packed_bytes);
+int mm_run_batch_sharded_device(const mm_plan_t *plan, mm_device_group_t *group, const uint64_t *base_offsets /* or NULL */,
+                                const uint64_t *n_bases, int want_superkmers, uint64_t *out_counts /* [n_seqs] or NULL */,
+                                uint64_t *total);
+int mm_device_group_batch_result(const mm_device_group_t *group, uint64_t seq, int *entry, uint32_t **d_pos,
+                                 uint32_t **d_sk, uint64_t *count);
+int mm_device_group_gather_batch(mm_device_group_t *group, int root, uint32_t *d_dst_pos, uint32_t *d_dst_sk /* or NULL */,
+                                 uint64_t capacity, uint64_t *out_offsets /* [n_seqs + 1] */);
+
 /* Diagnostics: the shader clock while other work runs on the device.  _begin starts a handful of sleeping
  * single-wave workgroups on a stream of the workspace's own that sample the shader cycle counter against the
  * 100 MHz real-time counter for duration_us; _end waits for them and returns the mean clock in GHz (bench.py

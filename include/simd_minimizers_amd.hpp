@@ -351,6 +351,36 @@ class DeviceGroup {
         check(mm_device_group_result(g_, entry, &s.d_pos, &s.d_sk, &s.count, &s.win_begin, &s.win_end));
         return s;
     }
+    // device-resident BATCHES: independent sequences placed greedily on the entries, each on its entry's device only;
+    // one batch launch per entry; sequence-local positions stay on the devices (mm_device_group_batch_result)
+    void upload_batch(const std::vector<PackedSeq> &seqs) {
+        std::vector<const uint8_t *> ptr;
+        std::vector<uint64_t> bytes;
+        for (const PackedSeq &s : seqs) {
+            ptr.push_back(s.data);
+            bytes.push_back((s.offset + s.len + 3) / 4);
+        }
+        check(mm_device_group_upload_batch(g_, seqs.size(), ptr.data(), bytes.data()));
+    }
+    template <bool CANONICAL, int SYNCMER>
+    std::vector<uint64_t> run_batch_device(const Builder<CANONICAL, SYNCMER> &b, const std::vector<PackedSeq> &seqs) const {
+        mm_plan_t *plan = b.make_plan();
+        std::vector<uint64_t> off, len, counts(seqs.size());
+        for (const PackedSeq &s : seqs) {
+            off.push_back(s.offset);
+            len.push_back(s.len);
+        }
+        const int r = mm_run_batch_sharded_device(plan, g_, off.data(), len.data(), 0, counts.data(), nullptr);
+        mm_plan_destroy(plan);
+        check(r);
+        return counts;
+    }
+    // all sequences, input order, into device memory of entry `root`; returns the n + 1 offsets
+    std::vector<uint64_t> gather_batch(int root, size_t n_seqs, uint32_t *d_dst_pos, uint64_t capacity) const {
+        std::vector<uint64_t> offs(n_seqs + 1);
+        check(mm_device_group_gather_batch(g_, root, d_dst_pos, nullptr, capacity, offs.data()));
+        return offs;
+    }
     // the shards, dense and in window order, into device memory of entry `root` (device-to-device copies)
     uint64_t gather(int root, uint32_t *d_dst_pos, uint64_t capacity, uint32_t *d_dst_sk = nullptr) const {
         uint64_t total = 0;

@@ -104,6 +104,10 @@ def lib():
             L.mm_run_sharded_device.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int, u64p, u64p]
             L.mm_device_group_result.argtypes = [vp, C.c_int, C.POINTER(u32p), C.POINTER(u32p), u64p, u64p, u64p]
             L.mm_device_group_gather.argtypes = [vp, C.c_int, vp, vp, C.c_uint64, u64p]
+            L.mm_device_group_upload_batch.argtypes = [vp, C.c_uint64, C.POINTER(u8p), u64p]
+            L.mm_run_batch_sharded_device.argtypes = [vp, vp, u64p, u64p, C.c_int, u64p, u64p]
+            L.mm_device_group_batch_result.argtypes = [vp, C.c_uint64, C.POINTER(C.c_int), C.POINTER(u32p), C.POINTER(u32p), u64p]
+            L.mm_device_group_gather_batch.argtypes = [vp, C.c_int, vp, vp, C.c_uint64, u64p]
         L.mm_clock_probe_begin.argtypes = [vp, C.c_uint64]
         L.mm_clock_probe_end.argtypes = [vp, C.POINTER(C.c_double)]
         L.mm_workspace_force_generic.argtypes = [vp, C.c_int]
@@ -184,6 +188,8 @@ EXPORTED_SYMBOLS = [
     "mm_run_batch_sharded_host",
     "mm_device_group_upload", "mm_device_group_adopt", "mm_run_sharded_device", "mm_device_group_result",
     "mm_device_group_gather",
+    "mm_device_group_upload_batch", "mm_run_batch_sharded_device", "mm_device_group_batch_result",
+    "mm_device_group_gather_batch",
 ]
 
 
@@ -457,6 +463,39 @@ class DeviceGroup:
             raise MinimizerError(code, f"gather capacity {int(d_dst_pos.numel())} < {total.value}")
         _check(code)
         return int(total.value)
+
+    # ---- device-resident batches (mm_device_group_upload_batch, mm_run_batch_sharded_device, _gather_batch)
+    def upload_batch(self, seqs):
+        """Independent host sequences placed greedily on the entries, each copied to its entry's device only."""
+        keep = [np.ascontiguousarray(a, dtype=np.uint8) for a in seqs]
+        n = len(keep)
+        ptrs = (C.POINTER(C.c_uint8) * max(n, 1))(*[a.ctypes.data_as(C.POINTER(C.c_uint8)) for a in keep])
+        nbytes = (C.c_uint64 * max(n, 1))(*[a.size for a in keep])
+        _check(lib().mm_device_group_upload_batch(self.h, n, ptrs, nbytes))
+        self._batch_n = n
+
+    def run_batch_device(self, builder: "Builder", n_bases, base_offsets=None):
+        """One batch launch per entry over its resident sequences; returns the per-sequence counts (input order)."""
+        n = self._batch_n
+        lens = (C.c_uint64 * max(n, 1))(*n_bases)
+        offs = (C.c_uint64 * max(n, 1))(*(base_offsets or [0] * n))
+        counts = (C.c_uint64 * max(n, 1))()
+        total = C.c_uint64()
+        _check(lib().mm_run_batch_sharded_device(builder.plan().h, self.h, offs, lens, 1 if builder._sk is not None else 0,
+                                                 counts, C.byref(total)))
+        return [int(c) for c in counts[:n]]
+
+    def gather_batch(self, root: int, d_dst_pos, d_dst_sk=None):
+        """All sequences' positions, input order, into device tensors on the root entry's device; returns the offsets."""
+        n = self._batch_n
+        offs = (C.c_uint64 * (n + 1))()
+        code = lib().mm_device_group_gather_batch(self.h, root, C.c_void_p(d_dst_pos.data_ptr()),
+                                                  C.c_void_p(d_dst_sk.data_ptr()) if d_dst_sk is not None else None,
+                                                  int(d_dst_pos.numel()), offs)
+        if code == ERR["CAPACITY"]:
+            raise MinimizerError(code, f"gather capacity {int(d_dst_pos.numel())} < {offs[n]}")
+        _check(code)
+        return [int(o) for o in offs]
 
     def run_batch(self, builder: "Builder", seqs, n_bases, base_offsets=None, capacity=None):
         """Independent host sequences placed greedily on the entries (``mm_run_batch_sharded_host``): (positions,

@@ -1812,6 +1812,19 @@ struct mm_device_group {
     };
     std::vector<Shard> shard;
     bool ran = false;
+    // resident batch (mm_device_group_upload_batch, mm_run_batch_sharded_device): independent sequences placed
+    // greedily, longest first, each on its entry's device only
+    struct BatchEntry {
+        uint8_t *d_buf = nullptr;           // the entry's sequences back to back, each at a 16-byte boundary
+        uint64_t buf_bytes = 0;
+        std::vector<uint64_t> seqs;         // sequences of this entry, input order
+        std::vector<uint64_t> at, nbytes;   // where each lies in d_buf, its packed bytes
+        std::vector<uint64_t> offs;         // offsets of its sequences' positions in the entry's result buffer (last run)
+    };
+    std::vector<BatchEntry> batch;
+    std::vector<int> seq_entry;             // entry of every sequence
+    std::vector<uint64_t> seq_slot;         // its index among the entry's sequences
+    bool batch_ran = false;
 };
 
 namespace {
@@ -1886,6 +1899,11 @@ void mm_device_group_destroy(mm_device_group_t *g) {
         if (g->shard[i].d_sk) hipFree(g->shard[i].d_sk);
     }
     if (!g->d_seq.empty()) group_drop_sequence(g);
+    for (size_t i = 0; i < g->batch.size() && i < g->ws.size(); ++i)
+        if (g->batch[i].d_buf) {
+            hipSetDevice(g->ws[i]->device);
+            hipFree(g->batch[i].d_buf);
+        }
     for (mm_workspace_t *ws : g->ws) mm_workspace_destroy(ws);
     delete g;
 }
@@ -2157,6 +2175,187 @@ int mm_device_group_gather(mm_device_group_t *g, int root, uint32_t *d_dst_pos, 
                 MM_HIP(hipMemcpyPeerAsync(d_dst_sk + off, root_dev, s.d_sk, ws->device, s.count * sizeof(uint32_t), ws->stream));
         }
         off += s.count;
+    }
+    for (size_t i = 0; i < g->ws.size(); ++i) {
+        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(hipStreamSynchronize(g->ws[i]->stream));
+    }
+    return MM_OK;
+}
+
+// ---- device-resident batches: independent sequences (contigs), each on ONE device of the group
+int mm_device_group_upload_batch(mm_device_group_t *g, uint64_t n_seqs, const uint8_t *const *packed,
+                                 const uint64_t *packed_bytes) {
+    if (!g || g->ws.empty() || (n_seqs && (!packed || !packed_bytes))) return MM_ERR_NULL;
+    const uint64_t N = g->ws.size();
+    // greedy placement, longest sequence first onto the least loaded entry (sharding.assign_contigs)
+    std::vector<uint64_t> order(n_seqs);
+    for (uint64_t s = 0; s < n_seqs; ++s) order[s] = s;
+    std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return packed_bytes[a] > packed_bytes[b]; });
+    std::vector<uint64_t> load(N, 0);
+    g->batch.resize(N);
+    for (mm_device_group::BatchEntry &b : g->batch) {
+        b.seqs.clear();
+        b.at.clear();
+        b.nbytes.clear();
+        b.offs.clear();
+    }
+    g->seq_entry.assign(n_seqs, 0);
+    g->seq_slot.assign(n_seqs, 0);
+    g->batch_ran = false;
+    for (uint64_t s : order) {
+        uint64_t best = 0;
+        for (uint64_t i = 1; i < N; ++i)
+            if (load[i] < load[best]) best = i;
+        g->batch[best].seqs.push_back(s);
+        load[best] += packed_bytes[s];
+    }
+    for (uint64_t i = 0; i < N; ++i) {
+        mm_device_group::BatchEntry &b = g->batch[i];
+        std::sort(b.seqs.begin(), b.seqs.end());
+        uint64_t total = 0;
+        for (size_t j = 0; j < b.seqs.size(); ++j) {
+            const uint64_t s = b.seqs[j];
+            g->seq_entry[s] = (int)i;
+            g->seq_slot[s] = j;
+            b.at.push_back(total);
+            b.nbytes.push_back(packed_bytes[s]);
+            total += (packed_bytes[s] + 64 + 15) & ~15ull;  // (the walk's loads run a few dwords past the last base)
+        }
+        MM_HIP(hipSetDevice(g->ws[i]->device));
+        int r = grow(b.d_buf, b.buf_bytes, total + 16, 1);
+        if (r) return r;
+        MM_HIP(hipMemsetAsync(b.d_buf, 0, b.buf_bytes, g->ws[i]->stream));
+        for (size_t j = 0; j < b.seqs.size(); ++j)
+            if (b.nbytes[j]) {
+                if (!packed[b.seqs[j]]) return MM_ERR_NULL;
+                MM_HIP(hipMemcpyAsync(b.d_buf + b.at[j], packed[b.seqs[j]], b.nbytes[j], hipMemcpyHostToDevice, g->ws[i]->stream));
+            }
+    }
+    for (uint64_t i = 0; i < N; ++i) {
+        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(hipStreamSynchronize(g->ws[i]->stream));
+    }
+    return MM_OK;
+}
+
+int mm_run_batch_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, const uint64_t *base_offsets,
+                                const uint64_t *n_bases, int want_superkmers, uint64_t *out_counts, uint64_t *total) {
+    if (!plan || !g || g->ws.empty() || g->batch.size() != g->ws.size() || !n_bases) return MM_ERR_NULL;
+    if (want_superkmers && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;
+    const uint64_t N = g->ws.size(), n_seqs = g->seq_entry.size();
+    const uint64_t l = (uint64_t)plan->k + plan->w - 1;
+    const double dens = plan->mode == MM_OPEN_SYNCMERS ? 1.0 / plan->w
+                        : plan->mode == MM_CLOSED_SYNCMERS ? 2.0 / plan->w : 2.0 / (plan->w + 1.0);
+    std::vector<ShardResult> res(N);
+    // one host thread per entry: a batch launch reads its offsets back, so the entries would run one after the other
+    // from one thread
+    auto run_entry = [&](uint64_t i) {
+        ShardResult &r = res[i];
+        mm_device_group::BatchEntry &b = g->batch[i];
+        mm_device_group::Shard &sh = g->shard[i];
+        mm_workspace *ws = g->ws[i];
+        sh.count = 0;
+        sh.has_sk = want_superkmers != 0;
+        b.offs.assign(b.seqs.size() + 1, 0);
+        if (b.seqs.empty()) return;
+        auto fail = [&](int rc) {
+            r.rc = rc;
+            r.err = g_last_error;
+        };
+        if (hipSetDevice(ws->device) != hipSuccess) return fail(MM_ERR_HIP);
+        std::vector<const void *> dptr(b.seqs.size());
+        std::vector<uint64_t> dbytes(b.seqs.size()), offs(b.seqs.size()), lens(b.seqs.size());
+        uint64_t windows = 0;
+        for (size_t j = 0; j < b.seqs.size(); ++j) {
+            const uint64_t s = b.seqs[j];
+            offs[j] = base_offsets ? base_offsets[s] : 0;
+            lens[j] = n_bases[s];
+            if ((offs[j] + lens[j] + 3) / 4 > b.nbytes[j]) return fail(MM_ERR_CAPACITY);  // more bases than were uploaded
+            dptr[j] = b.d_buf + b.at[j];
+            dbytes[j] = b.nbytes[j] + 64;
+            windows += lens[j] >= l ? lens[j] - l + 1 : 0;
+        }
+        uint64_t want = (uint64_t)(dens * 1.15 * (double)windows) + 4096;
+        if (want > windows) want = windows;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            int rc = grow(sh.d_pos, sh.cap_pos, want ? want : 1, sizeof(uint32_t));
+            if (rc == MM_OK && want_superkmers) rc = grow(sh.d_sk, sh.cap_sk, want ? want : 1, sizeof(uint32_t));
+            if (rc) return fail(rc);
+            const uint64_t cap = want_superkmers ? (sh.cap_pos < sh.cap_sk ? sh.cap_pos : sh.cap_sk) : sh.cap_pos;
+            rc = mm_run_batch_device(plan, ws, b.seqs.size(), dptr.data(), dbytes.data(), offs.data(), lens.data(), sh.d_pos,
+                                     want_superkmers ? sh.d_sk : nullptr, cap, b.offs.data());
+            if (rc == MM_ERR_CAPACITY && attempt == 0) {  // denser than expected: again with what it needs
+                want = b.offs[b.seqs.size()];
+                continue;
+            }
+            if (rc) return fail(rc);
+            break;
+        }
+        sh.count = b.offs[b.seqs.size()];
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint64_t i = 1; i < N; ++i) th.emplace_back(run_entry, i);
+        run_entry(0);
+        for (std::thread &t : th) t.join();
+    }
+    for (uint64_t i = 0; i < N; ++i)
+        if (res[i].rc) {
+            g_last_error = res[i].err;
+            return res[i].rc;
+        }
+    uint64_t sum = 0;
+    for (uint64_t s = 0; s < n_seqs; ++s) {
+        const mm_device_group::BatchEntry &b = g->batch[(size_t)g->seq_entry[s]];
+        const uint64_t c = b.offs[g->seq_slot[s] + 1] - b.offs[g->seq_slot[s]];
+        if (out_counts) out_counts[s] = c;
+        sum += c;
+    }
+    if (total) *total = sum;
+    g->batch_ran = true;
+    return MM_OK;
+}
+
+int mm_device_group_batch_result(const mm_device_group_t *g, uint64_t seq, int *entry, uint32_t **d_pos, uint32_t **d_sk,
+                                 uint64_t *count) {
+    if (!g || !g->batch_ran || seq >= g->seq_entry.size()) return MM_ERR_NULL;
+    const int e = g->seq_entry[seq];
+    const mm_device_group::BatchEntry &b = g->batch[(size_t)e];
+    const mm_device_group::Shard &sh = g->shard[(size_t)e];
+    const uint64_t j = g->seq_slot[seq];
+    if (entry) *entry = e;
+    if (d_pos) *d_pos = sh.d_pos ? sh.d_pos + b.offs[j] : nullptr;
+    if (d_sk) *d_sk = (sh.has_sk && sh.d_sk) ? sh.d_sk + b.offs[j] : nullptr;
+    if (count) *count = b.offs[j + 1] - b.offs[j];
+    return MM_OK;
+}
+
+int mm_device_group_gather_batch(mm_device_group_t *g, int root, uint32_t *d_dst_pos, uint32_t *d_dst_sk,
+                                 uint64_t capacity, uint64_t *out_offsets) {
+    if (!g || !g->batch_ran || root < 0 || (size_t)root >= g->ws.size() || !out_offsets) return MM_ERR_NULL;
+    const uint64_t n_seqs = g->seq_entry.size();
+    out_offsets[0] = 0;
+    for (uint64_t s = 0; s < n_seqs; ++s) {
+        const mm_device_group::BatchEntry &b = g->batch[(size_t)g->seq_entry[s]];
+        out_offsets[s + 1] = out_offsets[s] + (b.offs[g->seq_slot[s] + 1] - b.offs[g->seq_slot[s]]);
+    }
+    if (out_offsets[n_seqs] > capacity) return MM_ERR_CAPACITY;
+    if (out_offsets[n_seqs] && !d_dst_pos) return MM_ERR_NULL;
+    const int root_dev = g->ws[(size_t)root]->device;
+    for (uint64_t s = 0; s < n_seqs; ++s) {
+        const int e = g->seq_entry[s];
+        const mm_device_group::BatchEntry &b = g->batch[(size_t)e];
+        const mm_device_group::Shard &sh = g->shard[(size_t)e];
+        mm_workspace *ws = g->ws[(size_t)e];
+        const uint64_t j = g->seq_slot[s], c = b.offs[j + 1] - b.offs[j];
+        if (!c) continue;
+        if (d_dst_sk && !sh.has_sk) return MM_ERR_BAD_MODE;
+        // every copy on its SOURCE entry's stream: the entries' copies run side by side
+        MM_HIP(hipSetDevice(ws->device));
+        MM_HIP(hipMemcpyPeerAsync(d_dst_pos + out_offsets[s], root_dev, sh.d_pos + b.offs[j], ws->device, c * sizeof(uint32_t), ws->stream));
+        if (d_dst_sk)
+            MM_HIP(hipMemcpyPeerAsync(d_dst_sk + out_offsets[s], root_dev, sh.d_sk + b.offs[j], ws->device, c * sizeof(uint32_t), ws->stream));
     }
     for (size_t i = 0; i < g->ws.size(); ++i) {
         MM_HIP(hipSetDevice(g->ws[i]->device));

@@ -138,6 +138,11 @@ int main() {
             sum += sh.count;
         }
         if (sum != one.size() || prev_end != big.size() - 31 + 1) return 31;
+        // device-resident batches: the contigs above, each on one entry's device; counts per contig
+        group.upload_batch(parts);
+        const std::vector<uint64_t> cc = group.run_batch_device(canonical_minimizers(21, 11), parts);
+        for (size_t i = 0; i < parts.size(); ++i)
+            if (cc[i] != offs[i + 1] - offs[i]) return 32;
     }
     printf("builder_example ok\n");
     return 0;

@@ -555,3 +555,41 @@ def test_fastq_packer(sm, oracle, gpu):
         seq_packed = oracle.pack_ascii(want2[r][2])
         w_r = oracle.run(np.concatenate([seq_packed, np.zeros(16, dtype=np.uint8)]), len(want2[r][2]), 21, 11, canonical=True)
         assert np.array_equal(flat2[offs2[r]: offs2[r + 1]], w_r), r
+
+
+def test_device_resident_batches(sm, oracle, gpu):
+    """mm_device_group_upload_batch / mm_run_batch_sharded_device / mm_device_group_gather_batch: independent sequences
+    placed greedily on the entries, each resident on its entry's device only, one batch launch per entry, the positions
+    left on the devices and gathered device-to-device in input order (north_star's "sharded by contig, gather of the
+    positions"; entries share this box's one GPU).  Every sequence against the oracle."""
+    import torch
+    rng = np.random.default_rng(8)
+    lens = [700_001, 40, 1_200_017, 0, 333_333, 90_000, 30, 450_123]
+    offs = [0, 1, 3, 0, 2, 0, 0, 1]
+    seqs = [oracle.gen_packed(300 + i, o + n + 64) for i, (n, o) in enumerate(zip(lens, offs))]
+    # a dense one: poly-A emits at every window, far above the expected density of its entry
+    seqs[5] = np.zeros_like(seqs[5])
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        g = sm.DeviceGroup(devices)
+        g.upload_batch([s[: (o + n + 3) // 4 + 1] for s, n, o in zip(seqs, lens, offs)])
+        for (k, w, canonical, mode, sk) in ((21, 11, True, 0, False), (31, 51, True, 0, False), (5, 3, False, 0, True), (15, 17, True, 1, False)):
+            b = sm.Builder(k, w, canonical, mode)
+            if sk:
+                b = b.super_kmers([])
+            counts = g.run_batch_device(b, lens, base_offsets=offs)
+            wants = [oracle.run(s, n, k, w, canonical=canonical, mode=mode, base_offset=o, super_kmers=sk) for s, n, o in zip(seqs, lens, offs)]
+            wpos = [x[0] if sk else x for x in wants]
+            assert counts == [len(x) for x in wpos], (devices, k, w, mode)
+            dst = torch.full((sum(counts) + 4,), -3, dtype=torch.int32, device="cuda")
+            dsk = torch.full((sum(counts) + 4,), -3, dtype=torch.int32, device="cuda") if sk else None
+            o = g.gather_batch(0, dst, dsk)
+            assert o[-1] == sum(counts) and int(dst[o[-1]].item()) == -3
+            flat = _dev(dst, o[-1])
+            for i in range(len(lens)):
+                assert np.array_equal(flat[o[i]: o[i + 1]], wpos[i]), (devices, k, w, mode, i)
+                if sk:
+                    assert np.array_equal(_dev(dsk, o[-1])[o[i]: o[i + 1]], wants[i][1]), i
+            with pytest.raises(sm.MinimizerError) as e:
+                g.gather_batch(0, dst[: max(1, o[-1] // 3)])
+            assert e.value.code == sm.ERR["CAPACITY"]
+        g.close()
