@@ -461,16 +461,25 @@ int mm_workspace_create(mm_workspace_t **out, int device, void *hip_stream) {
     }
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&ws->ticket), 64);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ws->total), 64);
-    if (e == hipSuccess)
+    if (e == hipSuccess) {
+        // page-locked, mapped and coherent: the kernel's last tile stores the run's total there itself.  A runtime
+        // that refuses the flags still gives a plain page-locked block: the entry points then copy the words as
+        // rounds 1-3 did (h_total_dev stays null).
         e = hipHostMalloc(reinterpret_cast<void **>(&ws->h_total), 64, hipHostMallocMapped | hipHostMallocCoherent);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            ws->h_total = nullptr;
+            e = hipHostMalloc(reinterpret_cast<void **>(&ws->h_total), 64, hipHostMallocDefault);
+        }
+    }
     if (e == hipSuccess) {
         memset(ws->h_total, 0, 64);
         void *dp = nullptr;
-        e = hipHostGetDevicePointer(&dp, ws->h_total, 0);
-        ws->h_total_dev = reinterpret_cast<unsigned long long *>(dp);
+        if (hipHostGetDevicePointer(&dp, ws->h_total, 0) == hipSuccess) ws->h_total_dev = reinterpret_cast<unsigned long long *>(dp);
+        else (void)hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemset(ws->total, 0, 64);  // [0] total, [1] per-run error, [2] sticky error
-    if (e == hipSuccess) {
+    if (e == hipSuccess && ws->h_total_dev) {
         // [3]: where the host keeps its copy of the error word (flag_error stores the code there as well)
         const unsigned long long host_err = (unsigned long long)reinterpret_cast<uintptr_t>(ws->h_total_dev + 1);
         e = hipMemcpy(ws->total + 3, &host_err, sizeof(host_err), hipMemcpyHostToDevice);
@@ -749,7 +758,7 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
             lr = mm::launch_fused(a, ws->stream);
             if (lr == 0) {
                 count_stored = d_count != nullptr;
-                if (host_total_written) *host_total_written = true;
+                if (host_total_written && ws->h_total_dev) *host_total_written = true;
             }
             a.out.count_out = a.out.total_host = nullptr;
             if (lr == -2) {
@@ -1229,6 +1238,8 @@ static int run_device_sync(const mm_plan_t *plan, mm_workspace_t *ws, const void
         bool host_written = false;
         ws->h_total[0] = 0;
         ws->h_total[1] = 0;
+        // (no mapped host words on this runtime: the device's error word is read back below, so clear it first)
+        if (!ws->h_total_dev) MM_HIP(hipMemsetAsync(ws->total + 1, 0, sizeof(unsigned long long), ws->stream));
         int r = run_device_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin,
                                       win_end, d_out_pos, d_out_sk, capacity, nullptr, false, amb, &host_written);
         if (r) return r;
@@ -2078,6 +2089,7 @@ int mm_run_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, uint64_t 
         bool hw = false;
         ws->h_total[0] = 0;
         ws->h_total[1] = 0;
+        if (!ws->h_total_dev) MM_HIP(hipMemsetAsync(ws->total + 1, 0, sizeof(unsigned long long), ws->stream));
         const uint64_t cap = want_superkmers ? (s.cap_pos < s.cap_sk ? s.cap_pos : s.cap_sk) : s.cap_pos;
         int r = run_device_async_impl(plan, ws, g->d_seq[i], g->seq_bytes + (g->own_seq[i] ? 64 : 0), base_offset, n_bases,
                                       s.win_begin, s.win_end, s.d_pos, want_superkmers ? s.d_sk : nullptr, cap, nullptr,
