@@ -433,6 +433,16 @@ int mm_device_group_batch_result(const mm_device_group_t *group, uint64_t seq, i
 int mm_device_group_gather_batch(mm_device_group_t *group, int root, uint32_t *d_dst_pos, uint32_t *d_dst_sk /* or NULL */,
                                  uint64_t capacity, uint64_t *out_offsets /* [n_seqs + 1] */);
 
+/* Diagnostics: the launch plan of the fused kernel as the host lays it out - lane length, tiles, the tapered tail
+ * (DESIGN.md 4.1 "Launch geometry").  With MM_TAPER_SLOTS=<workgroup slots> in the environment no device is needed:
+ * the CPU test-suite checks with it that the tiles tile every window range exactly.  n_seqs == 0: ONE sequence of
+ * n_windows[0] windows, out7 = {blocks per lane, tiles, first tapered tile, tiles per taper level, last level's blocks
+ * per lane, first tapered window, windows per block of a tile}.  n_seqs > 0: a batch, the tile table itself (tile t =
+ * sequence, first window, blocks per lane; out7[0] = the longest lane); MM_ERR_CAPACITY when it holds more than
+ * tile_capacity tiles (*n_tiles says how many). */
+int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n_seqs, const uint64_t *n_windows,
+                         uint64_t *out7, uint32_t *tile_seq, uint32_t *tile_win0, uint32_t *tile_nblk,
+                         uint64_t tile_capacity, uint64_t *n_tiles);
 /* Diagnostics: the shader clock while other work runs on the device.  _begin starts a handful of sleeping
  * single-wave workgroups on a stream of the workspace's own that sample the shader cycle counter against the
  * 100 MHz real-time counter for duration_us; _end waits for them and returns the mean clock in GHz (bench.py

@@ -108,6 +108,8 @@ def lib():
             L.mm_run_batch_sharded_device.argtypes = [vp, vp, u64p, u64p, C.c_int, u64p, u64p]
             L.mm_device_group_batch_result.argtypes = [vp, C.c_uint64, C.POINTER(C.c_int), C.POINTER(u32p), C.POINTER(u32p), u64p]
             L.mm_device_group_gather_batch.argtypes = [vp, C.c_int, vp, vp, C.c_uint64, u64p]
+            L.mm_debug_launch_plan.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_uint64, u64p, u64p, u32p, u32p, u32p,
+                                               C.c_uint64, u64p]
         L.mm_clock_probe_begin.argtypes = [vp, C.c_uint64]
         L.mm_clock_probe_end.argtypes = [vp, C.POINTER(C.c_double)]
         L.mm_workspace_force_generic.argtypes = [vp, C.c_int]
@@ -189,7 +191,7 @@ EXPORTED_SYMBOLS = [
     "mm_device_group_upload", "mm_device_group_adopt", "mm_run_sharded_device", "mm_device_group_result",
     "mm_device_group_gather",
     "mm_device_group_upload_batch", "mm_run_batch_sharded_device", "mm_device_group_batch_result",
-    "mm_device_group_gather_batch",
+    "mm_device_group_gather_batch", "mm_debug_launch_plan",
 ]
 
 

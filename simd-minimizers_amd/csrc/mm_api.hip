@@ -612,6 +612,60 @@ int mm_workspace_kernel_time(mm_workspace_t *ws, double *total_ms, uint64_t *lau
 
 int mm_workspace_last_path(const mm_workspace_t *ws) { return ws ? ws->last_path : 0; }
 
+// Diagnostics (no device needed when MM_TAPER_SLOTS names the workgroup slots): the launch plan of a run over
+// n_windows windows - single sequence: out7 = {blocks per lane, tiles, taper_first, taper_per_level, taper_min_nblk,
+// taper_start, windows per block of a tile}; batch (n_seqs > 0): the tile table itself, tile t = {seq, first window,
+// blocks per lane}.  The CPU test-suite checks that the tiles tile every sequence exactly.
+int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n_seqs, const uint64_t *n_windows,
+                         uint64_t *out7, uint32_t *tile_seq, uint32_t *tile_win0, uint32_t *tile_nblk, uint64_t tile_capacity,
+                         uint64_t *n_tiles) {
+    if (!n_windows || w == 0) return MM_ERR_NULL;
+    mm::RunArgs a;
+    memset(&a.seq, 0, sizeof a.seq);
+    memset(&a.ht, 0, sizeof a.ht);
+    a.ht.canonical = canonical_windows ? 1u : 0u;
+    a.k = 21;
+    a.w = w;
+    a.canonical_windows = canonical_windows;
+    a.mode = (uint32_t)mode;
+    a.win_begin = 0;
+    a.win_end = n_windows[0];
+    memset(&a.out, 0, sizeof a.out);
+    a.wamb = nullptr;
+    a.wamb_dwords = 0;
+    a.batch_seqs = nullptr;
+    a.batch_tile_seq = nullptr;
+    a.batch_offsets = nullptr;
+    a.batch_n = (uint32_t)n_seqs;
+    a.batch_tiles = 0;
+    a.nblk = 0;
+    a.work_windows = n_windows[0];
+    a.use_ticket = 0;
+    a.scratch = nullptr;
+    a.generic_round_windows = 0;
+    a.timing_start = a.timing_stop = nullptr;
+    if (n_seqs == 0) {
+        if (!out7) return MM_ERR_NULL;
+        unsigned long long o[7];
+        mm::fused_debug_plan(a, o);
+        for (int i = 0; i < 7; ++i) out7[i] = o[i];
+        return MM_OK;
+    }
+    a.work_windows = 0;
+    for (uint64_t s = 0; s < n_seqs; ++s) a.work_windows += n_windows[s];
+    std::vector<mm::BatchTile> tiles;
+    uint32_t nb = 0;
+    if (!mm::fused_batch_tiles(a, n_windows, n_seqs, tiles, &nb)) return MM_ERR_LEN_TOO_LARGE;
+    if (n_tiles) *n_tiles = tiles.size();
+    if (out7) out7[0] = nb;
+    for (uint64_t t = 0; t < tiles.size() && t < tile_capacity; ++t) {
+        if (tile_seq) tile_seq[t] = tiles[t].seq;
+        if (tile_win0) tile_win0[t] = tiles[t].win0;
+        if (tile_nblk) tile_nblk[t] = tiles[t].nblk;
+    }
+    return tiles.size() > tile_capacity ? MM_ERR_CAPACITY : MM_OK;
+}
+
 int mm_prebuilt_window_sizes(int canonical_windows, int reads_mode, uint32_t *out, int capacity) {
     return mm::fused_prebuilt_windows(canonical_windows != 0, reads_mode != 0, out, capacity < 0 ? 0 : capacity);
 }

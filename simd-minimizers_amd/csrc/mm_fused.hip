@@ -446,11 +446,15 @@ static Taper plan_taper(const RunArgs &a, const KernelRef &kr, const Geometry &g
     t.tiles = g.nblocks;
     const bool off = mm_env("MM_NO_TAPER") != nullptr;
     if (off || a.batch_tile_seq || a.nblk != 0 || g.nblk < kTaperMinBlocks + 4u) return t;
-    int per_cu = 0, cus = 0;
-    if (!resident_slots(kr, g.lds_bytes, &per_cu, &cus)) return t;
-    uint64_t slots = (uint64_t)per_cu * cus;
-    // (tests: pretend the chip holds this many workgroups, so that runs of a few tiles already taper)
-    if (const char *e = mm_env("MM_TAPER_SLOTS")) slots = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : slots;
+    // (tests: MM_TAPER_SLOTS pretends the chip holds this many workgroups, so that runs of a few tiles already taper -
+    // and the planner then needs no device at all: tests/test_abi.py checks its tiling on the CPU)
+    uint64_t slots = 0;
+    if (const char *e = mm_env("MM_TAPER_SLOTS")) slots = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : 0;
+    if (!slots) {
+        int per_cu = 0, cus = 0;
+        if (!resident_slots(kr, g.lds_bytes, &per_cu, &cus)) return t;
+        slots = (uint64_t)per_cu * cus;
+    }
     const uint64_t nwin = a.win_end - a.win_begin;
     const uint64_t lmax = g.nblk - kTaperMinBlocks;          // levels 1 .. lmax: g.nblk - 1 .. kTaperMinBlocks blocks
     const uint64_t per_level = (slots * taper_slots_pct() / 100 + lmax - 1) / lmax;
@@ -488,11 +492,13 @@ bool fused_batch_tiles(const RunArgs &a0, const uint64_t *n_windows, uint64_t n_
     for (uint64_t s = 0; s < n_seqs; ++s) total += n_windows[s];
     const uint64_t blk_w = (uint64_t)kFusedThreads * a.w;
     uint64_t zone_start = ~0ull, per_level = 1, lmax = 0;
-    const KernelRef kr = (a.nblk == 0 && total) ? resolve_kernel(a.w, a.canonical_windows, (int)a.ht.canonical, a.mode, a.out.sk != nullptr) : KernelRef();
+    uint64_t fake_slots = 0;
+    if (const char *e = mm_env("MM_TAPER_SLOTS")) fake_slots = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : 0;
+    const KernelRef kr = (a.nblk == 0 && total && !fake_slots) ? resolve_kernel(a.w, a.canonical_windows, (int)a.ht.canonical, a.mode, a.out.sk != nullptr) : KernelRef();
     int per_cu = 0, cus = 0;
-    if (kr && !mm_env("MM_NO_TAPER") && g.nblk >= kTaperMinBlocks + 4u && resident_slots(kr, g.lds_bytes, &per_cu, &cus)) {
-        uint64_t slots = (uint64_t)per_cu * cus;
-        if (const char *e = mm_env("MM_TAPER_SLOTS")) slots = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : slots;
+    if (a.nblk == 0 && total && !mm_env("MM_NO_TAPER") && g.nblk >= kTaperMinBlocks + 4u &&
+        (fake_slots || (kr && resident_slots(kr, g.lds_bytes, &per_cu, &cus)))) {
+        const uint64_t slots = fake_slots ? fake_slots : (uint64_t)per_cu * cus;
         lmax = g.nblk - kTaperMinBlocks;
         per_level = (slots * taper_slots_pct() / 100 + lmax - 1) / lmax;
         const uint64_t cap_w = per_level * blk_w * (lmax * g.nblk - lmax * (lmax + 1) / 2);
@@ -526,6 +532,22 @@ bool fused_batch_tiles(const RunArgs &a0, const uint64_t *n_windows, uint64_t n_
         }
     }
     return true;
+}
+
+// The launch plan of a single-sequence run without a device (MM_TAPER_SLOTS set): what launch_fused would pass the
+// kernel.  out[0..6] = blocks per lane, tiles, taper_first, taper_per_level, taper_min_nblk, taper_start, windows per block
+// of a tile (256 x w).  Host logic only: the CPU test-suite checks that the tiles tile the window range.
+int fused_debug_plan(const RunArgs &a, unsigned long long *out) {
+    Geometry g = geometry(a);
+    const Taper t = plan_taper(a, KernelRef(), g);
+    out[0] = g.nblk;
+    out[1] = t.tiles;
+    out[2] = t.first;
+    out[3] = t.per_level;
+    out[4] = t.min_nblk;
+    out[5] = t.start;
+    out[6] = (unsigned long long)kFusedThreads * a.w;
+    return 0;
 }
 
 int launch_fused(const RunArgs &a, hipStream_t stream) {

@@ -56,6 +56,8 @@ uint32_t fused_tile_windows(const RunArgs &a);
 uint32_t fused_batch_nblk(const RunArgs &a, const uint64_t *n_windows, uint64_t n_seqs);
 // The tile table of a batch launch: whole tiles per sequence in input order (a sequence's last tile may be partial),
 // the last round of the launch tapered.  Appends to `tiles`; returns false if the table would pass 2^31 tiles.
+// launch plan of a single-sequence run as the kernel would get it (MM_TAPER_SLOTS set: no device needed); see mm_fused.hip
+int fused_debug_plan(const RunArgs &a, unsigned long long *out /* [7] */);
 // *nblk_out receives the longest lane of the table (RunArgs::nblk of the launch: it sizes the lists).
 bool fused_batch_tiles(const RunArgs &a, const uint64_t *n_windows, uint64_t n_seqs, std::vector<BatchTile> &tiles,
                        uint32_t *nblk_out);

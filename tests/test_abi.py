@@ -90,3 +90,87 @@ def test_packed_seq_helpers(sm, oracle):
     assert np.array_equal(rc.data[: (len(seq) + 3) // 4], want_rc[: (len(seq) + 3) // 4])
     sl = ps.slice(3, 17)
     assert list(sl.codes()) == list(ps.codes()[3:17])
+
+
+def _plan(sm, w, canonical, mode, n_windows_list, batch):
+    L = sm.lib()
+    arr = (C.c_uint64 * len(n_windows_list))(*n_windows_list)
+    out7 = (C.c_uint64 * 7)()
+    if not batch:
+        assert L.mm_debug_launch_plan(w, int(canonical), mode, 0, arr, out7, None, None, None, 0, None) == 0
+        return [int(x) for x in out7], None
+    cap = 1 << 22
+    seq, win0, nblk = (C.c_uint32 * cap)(), (C.c_uint32 * cap)(), (C.c_uint32 * cap)()
+    nt = C.c_uint64()
+    assert L.mm_debug_launch_plan(w, int(canonical), mode, len(n_windows_list), arr, out7, seq, win0, nblk, cap, C.byref(nt)) == 0
+    n = int(nt.value)
+    return [int(x) for x in out7], (list(seq[:n]), list(win0[:n]), list(nblk[:n]))
+
+
+def test_launch_plan_tiles_every_window(sm, monkeypatch):
+    """Host logic of the fused kernel's launch (DESIGN.md 4.1 "Launch geometry"), no GPU: with MM_TAPER_SLOTS naming the
+    chip's workgroup slots the planner needs no device.  Single sequences: the kernel's closed form for a tapered
+    tile's lane length and first window (mm_fused_impl.h, restated here) must tile the window range exactly - no gap, no
+    overlap, the last tile reaching the end.  Batches: the tile table must do the same for every sequence."""
+    import random
+    rng = random.Random(5)
+    checked_tapered = 0
+    for it in range(400):
+        w = rng.choice([1, 3, 5, 11, 17, 25, 33, 51])
+        canonical = rng.random() < 0.5
+        mode = rng.choice([0, 0, 1])
+        slots = rng.choice([1, 2, 3, 7, 64, 768, 1024, 1792])
+        monkeypatch.setenv("MM_TAPER_SLOTS", str(slots))
+        n = rng.choice([rng.randrange(1, 10**5), rng.randrange(10**5, 10**8), rng.randrange(10**8, 4 * 10**9)])
+        o, _ = _plan(sm, w, canonical, mode, [n], False)
+        nblk, tiles, first, per_level, min_nblk, start, blk_w = o
+        assert blk_w == 256 * w and nblk >= 1
+        NB = nblk * blk_w
+        if first == 0xFFFFFFFF:
+            assert tiles == -(-n // NB)
+            continue
+        checked_tapered += 1
+        lmax = nblk - min_nblk
+        assert first * NB == start and tiles > first and lmax >= 1 and per_level >= 1
+
+        def tile(bid):  # the kernel's arithmetic (fused_kernel, "Lane length of THIS tile")
+            if bid < first:
+                return bid * NB, nblk
+            j = bid - first
+            lv = min(1 + j // per_level, lmax)
+            nb = nblk - lv
+            before = per_level * ((lv - 1) * nblk - (lv - 1) * lv // 2) + (j - (lv - 1) * per_level) * nb
+            return start + before * blk_w, nb
+        end = start
+        for bid in range(first, tiles):
+            off, nb = tile(bid)
+            assert off == end and min_nblk <= nb < nblk, (it, bid)
+            end = off + nb * blk_w
+        assert end >= n and end - tile(tiles - 1)[1] * blk_w < n, (it, end, n)
+    assert checked_tapered > 100
+    # batches: every sequence tiled exactly, lanes never longer than the table says, the tail of the launch tapered
+    tapered_batches = 0
+    for it in range(150):
+        w = rng.choice([3, 11, 17, 51])
+        slots = rng.choice([1, 2, 5, 64, 768])
+        monkeypatch.setenv("MM_TAPER_SLOTS", str(slots))
+        n_seqs = rng.randrange(1, 30)
+        scale = rng.choice([10**4, 10**6, 10**8])
+        nws = [rng.choice([0, rng.randrange(1, scale)]) if rng.random() < 0.9 else 0 for _ in range(n_seqs)]
+        if sum(nws) == 0:
+            continue
+        o, (seq, win0, nb) = _plan(sm, w, True, 0, nws, True)
+        longest, blk_w = o[0], 256 * w
+        pos = {}
+        for s, w0, b in zip(seq, win0, nb):
+            assert 1 <= b <= longest and w0 == pos.get(s, 0) and w0 < nws[s], (it, s)
+            pos[s] = min(nws[s], w0 + b * blk_w)
+        for s, nw in enumerate(nws):
+            assert pos.get(s, 0) == nw, (it, s)
+        assert seq == sorted(seq)  # input order
+        if any(b < longest for b in nb):
+            tapered_batches += 1
+            k = next(i for i, b in enumerate(nb) if b < longest)
+            assert all(x >= y for x, y in zip(nb[k:], nb[k + 1:])), it  # lanes only shrink from there on
+    assert tapered_batches > 20
+    monkeypatch.delenv("MM_TAPER_SLOTS")
