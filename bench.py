@@ -298,6 +298,37 @@ def single_process(args):
     del out1, dst, d
     torch.cuda.empty_cache()
     extra = []
+    try:  # BASELINE config 4's shape through the same group: the 24 contigs resident on the entries, one batch launch each
+        from simd_minimizers_amd import sharding
+        lens_c = list(sharding.CHM13_CONTIG_LENGTHS)
+        hosts = []
+        for i, m in enumerate(lens_c):
+            t = sm.generate_device(m, sharding.CHM13_CONTIG_SEED0 + i)
+            hosts.append(t.cpu().numpy()[: (m + 3) // 4 + 1].copy())
+            del t
+        g.upload_batch(hosts)
+        del hosts
+        bc = sm.canonical_minimizers(31, 51)
+        for _ in range(3):
+            cc = g.run_batch_device(bc, lens_c)
+        tb = time.perf_counter()
+        reps = max(3, args.steps // 2)
+        for _ in range(reps):
+            cc = g.run_batch_device(bc, lens_c)
+        dtb = (time.perf_counter() - tb) / reps
+        dstc = torch.empty(sum(cc) + 1024, dtype=torch.int32, device="cuda:%d" % devices[0])
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        offs_c = g.gather_batch(0, dstc)
+        gb_ms = (time.perf_counter() - tg) * 1e3
+        extra.append({"config": f"C4 through mm_run_batch_sharded_device: 24 CHM13-like contigs resident on {args.gpus} entries "
+                                "(greedy placement), canonical k=31 w=51, one batch launch per entry, positions left on the devices",
+                      "ms_per_step": round(dtb * 1e3, 4), "Gbases_per_s": round(sum(lens_c) / dtb / 1e9, 1),
+                      "positions": int(offs_c[-1]), "gather_ms": round(gb_ms, 3)})
+        del dstc
+        torch.cuda.empty_cache()
+    except Exception as e:
+        extra.append({"config": "mm_run_batch_sharded_device", "error": str(e)[:200]})
     try:  # the host-buffer call, PCIe-inclusive (at most 1 Gbp: host memory)
         nh = min(n, 1 << 30)
         cap = int(nh * 2.3 / (W + 1)) + 4096

@@ -213,3 +213,48 @@ def test_bench_default_is_the_strong_split():
         assert sum(e - a for a, e in p["ranges"]) == p["windows"] == 3_100_000_000 - 31 + 1
         assert max(e - a for a, e in p["ranges"]) - min(e - a for a, e in p["ranges"]) <= n_gpus
     assert bench.resolve_workload("contigs", 8) == "contigs" and bench.resolve_workload("headline", 8) == "headline"
+
+
+def _gather_edge_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from simd_minimizers_amd import sharding
+    ok = True
+    # (counts per rank, root): ranks without a single position, a root that holds nothing, everything on one rank,
+    # buffers larger than their counts
+    for counts, root in (([5, 0, 3], 0), ([0, 0, 7], 1), ([0, 4, 0], 2), ([0, 0, 0], 0), ([1, 1, 1], 1), ([40000, 3, 0], 2)):
+        mine = np.arange(counts[rank] + 4, dtype=np.uint32) + 1000 * rank  # four entries more than the count
+        got = sharding.gather_positions_cat(torch.from_numpy(mine.view(np.int32)), counts, root)
+        if rank == root:
+            cat, parts = got
+            want = np.concatenate([np.arange(c, dtype=np.uint32) + 1000 * r for r, c in enumerate(counts)]) if sum(counts) else np.zeros(0, np.uint32)
+            ok = ok and np.array_equal(cat.numpy().view(np.uint32), want) and [int(p.numel()) for p in parts] == counts
+        else:
+            ok = ok and got is None
+    if rank == 0:
+        q.put(ok)
+    else:
+        assert ok
+    dist.destroy_process_group()
+
+
+def test_exact_size_gather_edge_cases():
+    """sharding.gather_positions_cat (round 4: every rank sends exactly its count point-to-point, the root receives into
+    slices of ONE buffer): ranks with nothing to send, a root with nothing of its own, nothing at all, buffers longer than
+    their counts - world size 3 over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500) + 577
+    procs = [ctx.Process(target=_gather_edge_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ok
