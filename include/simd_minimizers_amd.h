@@ -350,6 +350,23 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
 int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
                          uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
                          uint64_t max_records, uint64_t *d_counts, uint64_t *out_counts /* [2] */);
+/* Reads packed BACK TO BACK (round 4): read r = bases [d_read_starts[r], d_read_starts[r + 1]) of one packed buffer -
+ * the layout mm_fastq_pack_device_async / mm_fasta_pack_device write (d_rec_base), so millions of reads of ANY
+ * lengths run in ONE launch of the reads-mode kernel (mm_run_batch_device gives every sequence tiles of its own,
+ * which is right for contigs and wasteful for reads).  d_read_starts: n_reads + 1 device entries; total_bases =
+ * d_read_starts[n_reads] (the packer's count of bases); max_read_len: no read is longer (a longer one is cut to it,
+ * like a d_read_lens entry above read_len).  Positions are read-local, d_out_offsets[r] .. [r + 1] delimit read r's;
+ * d_out_sk (or NULL): super-k-mer indices.  Builder::run per read, src/lib.rs:378. */
+int mm_run_packed_reads_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                                     uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
+                                     const uint64_t *d_read_starts /* [n_reads + 1] */, uint64_t total_bases,
+                                     uint32_t max_read_len, uint32_t *d_out_pos, uint32_t *d_out_sk /* or NULL */,
+                                     uint64_t capacity, uint64_t *d_out_offsets /* [n_reads + 1] */, uint64_t *d_count);
+int mm_run_packed_reads_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                               uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
+                               const uint64_t *d_read_starts, uint64_t total_bases, uint32_t max_read_len,
+                               uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_out_offsets,
+                               uint64_t *out_count);
 /* FASTQ text -> packed records (round 4; mm_fastq.hip): four-line records ('@' name, sequence, '+', qualities;
  * "\r\n" or '\n', a last line without '\n', blank lines after the last record); the sequence of every record is
  * packed like a FASTA record's, same output layout: record r = bases [d_rec_base[r], d_rec_base[r + 1]),

@@ -108,6 +108,10 @@ def lib():
             L.mm_run_batch_sharded_device.argtypes = [vp, vp, u64p, u64p, C.c_int, u64p, u64p]
             L.mm_device_group_batch_result.argtypes = [vp, C.c_uint64, C.POINTER(C.c_int), C.POINTER(u32p), C.POINTER(u32p), u64p]
             L.mm_device_group_gather_batch.argtypes = [vp, C.c_int, vp, vp, C.c_uint64, u64p]
+            L.mm_run_packed_reads_device_async.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, vp, C.c_uint64,
+                                                           C.c_uint32, vp, vp, C.c_uint64, vp, vp]
+            L.mm_run_packed_reads_device.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, vp, C.c_uint64,
+                                                     C.c_uint32, vp, vp, C.c_uint64, vp, u64p]
             L.mm_debug_launch_plan.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_uint64, u64p, u64p, u32p, u32p, u32p,
                                                C.c_uint64, u64p]
         L.mm_clock_probe_begin.argtypes = [vp, C.c_uint64]
@@ -192,6 +196,7 @@ EXPORTED_SYMBOLS = [
     "mm_device_group_gather",
     "mm_device_group_upload_batch", "mm_run_batch_sharded_device", "mm_device_group_batch_result",
     "mm_device_group_gather_batch", "mm_debug_launch_plan",
+    "mm_run_packed_reads_device_async", "mm_run_packed_reads_device",
 ]
 
 
@@ -981,6 +986,28 @@ def fasta_pack_device(text, max_records: int = 1 << 16, device: int = 0) -> Fast
 
 
 fastx_pack_device = fasta_pack_device  # (the reference's loader call reads both formats)
+
+
+def run_packed_reads_device(builder: "Builder", records: FastaRecords, out_pos, out_offsets, out_sk=None, max_read_len=None):
+    """All records of a packed FASTQ / FASTA (``fasta_pack_device``) as READS: one launch of the reads-mode kernel over
+    reads of any lengths packed back to back (``mm_run_packed_reads_device``); read-local positions, ``out_offsets``
+    (int64 device tensor, n + 1) delimits the reads.  Returns the number of positions."""
+    import torch
+    n = len(records)
+    starts = torch.from_numpy(np.ascontiguousarray(records.base, dtype=np.uint64).view(np.int64)).to(out_pos.device)
+    lens = records.lengths()
+    mx = max(lens) if lens else 0
+    if max_read_len is None:
+        max_read_len = mx
+    cnt = C.c_uint64()
+    ws = builder._ws()
+    _check(lib().mm_run_packed_reads_device(builder.plan().h, ws.h, C.c_void_p(records.packed.data_ptr()),
+                                            int(records.packed.numel()), 0, n, C.c_void_p(starts.data_ptr()),
+                                            int(records.base[-1]) if n else 0, int(max_read_len),
+                                            C.c_void_p(out_pos.data_ptr()),
+                                            C.c_void_p(out_sk.data_ptr()) if out_sk is not None else None,
+                                            int(out_pos.numel()), C.c_void_p(out_offsets.data_ptr()), C.byref(cnt)))
+    return int(cnt.value)
 
 
 def run_fasta_device(builder: "Builder", records: FastaRecords, out_pos, out_sk=None):

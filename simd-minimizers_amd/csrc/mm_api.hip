@@ -1067,9 +1067,14 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
                                 uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
                                 uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
                                 uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
-                                uint64_t *d_count, const AmbArgs *amb = nullptr, uint32_t *d_out_sk = nullptr) {
+                                uint64_t *d_count, const AmbArgs *amb = nullptr, uint32_t *d_out_sk = nullptr,
+                                const uint64_t *d_read_starts = nullptr, uint64_t total_bases = 0) {
+    // d_read_starts (round 4): reads packed back to back, read r = bases [starts[r], starts[r + 1]) of the buffer
+    // (n_reads + 1 device entries; total_bases = starts[n_reads], which the caller knows from the packer's counts);
+    // read_len is then the longest read to expect (longer ones are cut to it), read_stride is not used.
     if (!plan || !ws || !d_out_offsets) return MM_ERR_NULL;
     if (n_reads >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    if (d_read_starts && (amb || d_read_lens)) return MM_ERR_BAD_MODE;
     if (amb && !plan->canonical_windows) return MM_ERR_HASHER_NOT_CANONICAL;
     if (d_out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;  // src/lib.rs:339
     if (d_out_sk && amb) return MM_ERR_BAD_MODE;  // the reference has no skip-ambiguous super-k-mer run
@@ -1085,7 +1090,7 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
         return MM_OK;
     }
     if (!d_packed) return MM_ERR_NULL;
-    const uint64_t span = (n_reads - 1) * (uint64_t)read_stride + read_len;
+    const uint64_t span = d_read_starts ? total_bases : (n_reads - 1) * (uint64_t)read_stride + read_len;
     if (span >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     mm::SeqView view;
     int r = make_view(d_packed, packed_bytes, base_offset, span, &view);
@@ -1108,6 +1113,7 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
         a.read_stride = read_stride;
         a.read_len = read_len;
         a.read_lens = d_read_lens;
+        a.read_starts = reinterpret_cast<const unsigned long long *>(d_read_starts);
         a.read_offsets = reinterpret_cast<unsigned long long *>(d_out_offsets);
         a.out.pos = d_out_pos;
         a.out.sk = d_out_sk;
@@ -1153,6 +1159,13 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
     }
     if (!fast) {
         std::vector<uint32_t> lens;
+        std::vector<uint64_t> starts;
+        if (d_read_starts) {
+            starts.resize(n_reads + 1);
+            MM_HIP(hipMemcpyAsync(starts.data(), d_read_starts, (n_reads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                  ws->stream));
+            MM_HIP(hipStreamSynchronize(ws->stream));
+        }
         if (d_read_lens) {
             lens.resize(n_reads);
             MM_HIP(hipMemcpyAsync(lens.data(), d_read_lens, n_reads * sizeof(uint32_t),
@@ -1162,8 +1175,9 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
         MM_HIP(hipMemsetAsync(d_out_offsets, 0, sizeof(uint64_t), ws->stream));
         const uint8_t *bytes = static_cast<const uint8_t *>(d_packed);
         for (uint64_t i = 0; i < n_reads; ++i) {
-            const uint64_t first = base_offset + i * (uint64_t)read_stride;
-            const uint64_t len = d_read_lens ? (lens[i] < read_len ? lens[i] : read_len) : read_len;
+            const uint64_t first = base_offset + (d_read_starts ? starts[i] : i * (uint64_t)read_stride);
+            uint64_t len = d_read_lens ? (lens[i] < read_len ? lens[i] : read_len) : read_len;
+            if (d_read_starts) len = starts[i + 1] - starts[i] < read_len ? starts[i + 1] - starts[i] : read_len;
             AmbArgs ra;
             if (amb) ra = AmbArgs{amb->d_amb, amb->bytes, amb->bit_offset + i * (uint64_t)read_stride};
             r = run_device_async_impl(plan, ws, bytes + first / 4, packed_bytes - first / 4, first % 4, len,
@@ -1177,6 +1191,38 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
     if (d_count)
         MM_HIP(hipMemcpyAsync(d_count, ws->total, sizeof(unsigned long long), hipMemcpyDeviceToDevice,
                               ws->stream));
+    return MM_OK;
+}
+
+// Reads packed back to back (the FASTQ / FASTA packers' layout): read r = bases [d_read_starts[r], d_read_starts[r + 1]).
+int mm_run_packed_reads_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed,
+                                     uint64_t packed_bytes, uint64_t base_offset, uint64_t n_reads,
+                                     const uint64_t *d_read_starts, uint64_t total_bases, uint32_t max_read_len,
+                                     uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_out_offsets,
+                                     uint64_t *d_count) {
+    if (!d_read_starts && n_reads) return MM_ERR_NULL;
+    if (ws) ws->async_unchecked = true;
+    return run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, 0, max_read_len, nullptr, d_out_pos,
+                                capacity, d_out_offsets, d_count, nullptr, d_out_sk, d_read_starts, total_bases);
+}
+
+int mm_run_packed_reads_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packed, uint64_t packed_bytes,
+                               uint64_t base_offset, uint64_t n_reads, const uint64_t *d_read_starts, uint64_t total_bases,
+                               uint32_t max_read_len, uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
+                               uint64_t *d_out_offsets, uint64_t *out_count) {
+    if (!ws || (!d_read_starts && n_reads)) return MM_ERR_NULL;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int r = run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, 0, max_read_len, nullptr,
+                                     d_out_pos, capacity, d_out_offsets, nullptr, nullptr, d_out_sk, d_read_starts, total_bases);
+        if (r) return r;
+        MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ws->stream));
+        MM_HIP(hipStreamSynchronize(ws->stream));
+        const int je = judge_run_error(ws);
+        if (je < 0) return je;
+        if (je == 0) break;  // (1: redo the batch in ticket mode)
+    }
+    if (out_count) *out_count = ws->h_total[0];
+    if (d_out_pos && ws->h_total[0] > capacity) return MM_ERR_CAPACITY;
     return MM_OK;
 }
 

@@ -621,6 +621,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.reads_per_lane = 1;
     p.read_stride = p.read_len = 0;
     p.read_lens = nullptr;
+    p.read_starts = nullptr;
     p.read_offsets = nullptr;
     p.wamb = a.wamb;
     p.wamb_dwords = a.wamb_dwords;
@@ -749,6 +750,7 @@ int launch_split(const RunArgs &a, const SplitBuffers &b, hipStream_t stream) {
     p.reads_per_lane = 1;
     p.read_stride = p.read_len = 0;
     p.read_lens = nullptr;
+    p.read_starts = nullptr;
     p.read_offsets = nullptr;
     p.wamb = a.wamb;
     p.wamb_dwords = a.wamb_dwords;
@@ -886,7 +888,8 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     uint32_t R = 1;
     // ... and as keep the spans of the resident lanes in the L2 (about 100 bytes of sequence per lane, see
     // default_cap_limit)
-    const uint32_t r_cache = a.read_stride >= 400u ? 1u : 400u / (a.read_stride ? a.read_stride : 1u);
+    const uint32_t stride_like = a.read_starts ? a.read_len : a.read_stride;  // (back-to-back reads: about their length apart)
+    const uint32_t r_cache = stride_like >= 400u ? 1u : 400u / (stride_like ? stride_like : 1u);
     while (R < 4u && R < r_cache && cap_for(R + 1) * kListStride <= 40u * 1024u) ++R;
     if (const char *e = mm_env("MM_READS_PER_LANE")) R = (uint32_t)atoi(e);
     if (R < 1u) R = 1u;
@@ -933,6 +936,7 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.read_stride = a.read_stride;
     p.read_len = a.read_len;
     p.read_lens = a.read_lens;
+    p.read_starts = a.read_starts;
     p.read_offsets = a.read_offsets;
     p.wamb = a.wamb;
     p.wamb_dwords = a.wamb_dwords;

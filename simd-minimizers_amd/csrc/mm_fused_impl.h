@@ -134,6 +134,9 @@ struct FusedParams {
     uint32_t read_stride;               // bases between the starts of consecutive reads
     uint32_t read_len;                  // length of every read, or the maximum when read_lens != null
     const uint32_t *read_lens;          // optional per-read lengths (device)
+    // (round 4) reads packed BACK TO BACK, read r = bases [read_starts[r], read_starts[r + 1]) of the buffer - what the
+    // FASTQ / FASTA packers write; null = reads at the fixed stride above.  n_reads + 1 entries (device).
+    const unsigned long long *read_starts;
     unsigned long long *read_offsets;   // [n_reads + 1] first output slot of every read (device)
     // skip-ambiguous windows (PackedNSeq, src/minimizers.rs:169-214): bit g set = the window that
     // starts at base g (relative to the first base of the sequence / buffer span) is skipped
@@ -1699,15 +1702,31 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     auto setup_read = [&](uint32_t j) -> bool {
         const uint32_t r = lane_read0 + j;
         const bool in = r < p.n_reads;
-        const uint32_t len = in ? (p.read_lens ? p.read_lens[r] : p.read_len) : 0u;
+        uint32_t len, lane_bases, abase;
+        unsigned long long tile_start;
+        if (p.read_starts) {
+            // reads back to back: the tile's origin is its first read's start (tile-uniform), a lane's read lies where
+            // the table says; a read longer than read_len is cut to it (like read_lens above read_len)
+            tile_start = p.read_starts[tile_read0 < p.n_reads ? tile_read0 : p.n_reads];
+            const unsigned long long s0 = in ? p.read_starts[r] : tile_start, s1 = in ? p.read_starts[r + 1] : tile_start;
+            const unsigned long long ln = s1 > s0 ? s1 - s0 : 0ull;
+            len = ln < (unsigned long long)p.read_len ? (uint32_t)ln : p.read_len;
+            lane_bases = (uint32_t)(s0 - tile_start);
+            abase = (uint32_t)s0;
+        } else {
+            tile_start = (unsigned long long)tile_read0 * p.read_stride;
+            len = in ? (p.read_lens ? p.read_lens[r] : p.read_len) : 0u;
+            lane_bases = ((uint32_t)tid * R + j) * p.read_stride;
+            abase = r * p.read_stride;
+        }
         const uint32_t l = p.k + (uint32_t)W - 1u;
         const uint32_t nw = len >= l ? len - l + 1u : 0u;
-        ctx.p0 = (long long)seq_base0 + (long long)tile_read0 * p.read_stride - 1;
-        ctx.lane_bases = ((uint32_t)tid * R + j) * p.read_stride;
+        ctx.p0 = (long long)seq_base0 + (long long)tile_start - 1;
+        ctx.lane_bases = lane_bases;
         ctx.wbase = 0;
         ctx.no_prev = true;
         ctx.rem_valid = (int)(nw < S ? nw : S);
-        ctx.abase = r * p.read_stride;
+        ctx.abase = abase;
         return nw != 0u;
     };
     // wave-uniform minimum of rem_valid over the lanes that walk (all lanes take part)

@@ -99,6 +99,7 @@ struct ReadsArgs {
     uint64_t n_reads;
     uint32_t read_stride, read_len;
     const uint32_t *read_lens;           // device, optional
+    const unsigned long long *read_starts = nullptr;  // device, optional: reads back to back (n_reads + 1 entries)
     unsigned long long *read_offsets;    // device, n_reads + 1
     const uint32_t *wamb;                // window ambiguity bits over the whole buffer span (or null)
     uint32_t wamb_dwords;

@@ -593,3 +593,54 @@ def test_device_resident_batches(sm, oracle, gpu):
                 g.gather_batch(0, dst[: max(1, o[-1] // 3)])
             assert e.value.code == sm.ERR["CAPACITY"]
         g.close()
+
+
+def test_packed_reads_of_any_lengths(sm, oracle, gpu):
+    """mm_run_packed_reads_device: reads packed back to back (the FASTQ packer's layout) in ONE launch of the reads-mode
+    kernel - lengths 0..400 over several tiles, super-k-mer indices, syncmers, a batch with one read too long for a lane
+    (the per-read fallback), max_read_len below the longest read (cut like read_lens); every read against the oracle."""
+    import torch
+    rng = np.random.default_rng(33)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def fastq(lens):
+        parts = []
+        for r, ln in enumerate(lens):
+            seq = acgt[rng.integers(0, 4, int(ln))].tobytes()
+            parts.append(b"@r%d\n" % r + seq + b"\n+\n" + b"I" * int(ln) + b"\n")
+        return b"".join(parts)
+
+    def check(lens, k, w, canonical, mode, sk=False, max_read_len=None, sample=None):
+        text = fastq(lens)
+        rec = sm.fasta_pack_device(text, max_records=len(lens) + 1)
+        want = oracle.fastq_records(text)
+        assert rec.lengths() == [int(x) for x in lens]
+        b = sm.Builder(k, w, canonical, mode)
+        out = torch.zeros(max(1, int(sum(lens))), dtype=torch.int32, device="cuda")
+        osk = torch.zeros_like(out) if sk else None
+        offs = torch.full((len(lens) + 1,), -1, dtype=torch.int64, device="cuda")
+        total = sm.run_packed_reads_device(b, rec, out, offs, out_sk=osk, max_read_len=max_read_len)
+        ho = offs.cpu().numpy()
+        assert ho[0] == 0 and ho[-1] == total
+        flat = out[:total].cpu().numpy().view(np.uint32)
+        fsk = osk[:total].cpu().numpy().view(np.uint32) if sk else None
+        for r in (sample if sample is not None else range(len(lens))):
+            ln = int(lens[r]) if max_read_len is None else min(int(lens[r]), max_read_len)
+            packed = np.concatenate([oracle.pack_ascii(want[r][2]), np.zeros(16, dtype=np.uint8)])
+            res = oracle.run(packed, ln, k, w, canonical=canonical, mode=mode, super_kmers=sk)
+            wp = res[0] if sk else res
+            assert np.array_equal(flat[ho[r]: ho[r + 1]], wp), (r, ln, k, w, mode)
+            if sk:
+                assert np.array_equal(fsk[ho[r]: ho[r + 1]], res[1]), r
+    lens = rng.integers(0, 401, 1500)
+    lens[:4] = [0, 30, 31, 400]
+    check(lens, 21, 11, True, 0, sample=list(range(0, 1500, 7)) + [1499])
+    assert gpu.last_path() == sm.PATH_FUSED
+    check(lens[:600], 21, 11, False, 0, sk=True, sample=range(0, 600, 5))
+    check(lens[:300], 15, 17, True, 1, sample=range(0, 300, 3))
+    check(rng.integers(100, 151, 700), 31, 19, True, 0, sample=range(0, 700, 9))
+    check(lens[:200], 21, 11, True, 0, max_read_len=150, sample=range(0, 200, 3))  # longer reads are cut to 150
+    long_lens = rng.integers(50, 200, 40)
+    long_lens[17] = 70_001  # too long for one lane: one launch per read, same results
+    check(long_lens, 21, 11, True, 0)
+    check([], 21, 11, True, 0)
