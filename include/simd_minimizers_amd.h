@@ -367,6 +367,15 @@ int mm_run_packed_reads_device(const mm_plan_t *plan, mm_workspace_t *ws, const 
                                const uint64_t *d_read_starts, uint64_t total_bases, uint32_t max_read_len,
                                uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_out_offsets,
                                uint64_t *out_count);
+/* The same from HOST memory in one call: n_reads reads packed back to back in `packed` (read r = bases
+ * [read_starts[r], read_starts[r + 1]), starts on the host, non-decreasing), one upload, ONE launch, one download.
+ * What a caller that looped Builder::run over its reads does instead: a synchronous call costs about 28 us whatever
+ * the length, so a per-read loop runs 10-100 x slower than the reference's CPU on 150-base reads, and this call does
+ * millions of them at PCIe speed.  out_offsets[r] .. [r + 1] delimit read r's (read-local) positions. */
+int mm_run_packed_reads_host(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed, uint64_t n_reads,
+                             const uint64_t *read_starts /* [n_reads + 1] */, uint32_t max_read_len, uint32_t *out_pos,
+                             uint32_t *out_sk /* or NULL */, uint64_t capacity, uint64_t *out_offsets /* [n_reads + 1] */,
+                             uint64_t *out_count);
 /* FASTQ text -> packed records (round 4; mm_fastq.hip): four-line records ('@' name, sequence, '+', qualities;
  * "\r\n" or '\n', a last line without '\n', blank lines after the last record); the sequence of every record is
  * packed like a FASTA record's, same output layout: record r = bases [d_rec_base[r], d_rec_base[r + 1]),

@@ -112,6 +112,7 @@ def lib():
                                                            C.c_uint32, vp, vp, C.c_uint64, vp, vp]
             L.mm_run_packed_reads_device.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, vp, C.c_uint64,
                                                      C.c_uint32, vp, vp, C.c_uint64, vp, u64p]
+            L.mm_run_packed_reads_host.argtypes = [vp, vp, u8p, C.c_uint64, u64p, C.c_uint32, u32p, u32p, C.c_uint64, u64p, u64p]
             L.mm_debug_launch_plan.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_uint64, u64p, u64p, u32p, u32p, u32p,
                                                C.c_uint64, u64p]
         L.mm_clock_probe_begin.argtypes = [vp, C.c_uint64]
@@ -196,7 +197,7 @@ EXPORTED_SYMBOLS = [
     "mm_device_group_gather",
     "mm_device_group_upload_batch", "mm_run_batch_sharded_device", "mm_device_group_batch_result",
     "mm_device_group_gather_batch", "mm_debug_launch_plan",
-    "mm_run_packed_reads_device_async", "mm_run_packed_reads_device",
+    "mm_run_packed_reads_device_async", "mm_run_packed_reads_device", "mm_run_packed_reads_host",
 ]
 
 
@@ -986,6 +987,42 @@ def fasta_pack_device(text, max_records: int = 1 << 16, device: int = 0) -> Fast
 
 
 fastx_pack_device = fasta_pack_device  # (the reference's loader call reads both formats)
+
+
+def run_reads_host(builder: "Builder", reads, super_kmers: bool = False):
+    """Many short host sequences in ONE call (``mm_run_packed_reads_host``): ``reads`` = list of ``PackedSeq`` / ASCII
+    ``bytes``; returns (positions, offsets, indices or None) - read r's read-local positions are
+    ``positions[offsets[r]:offsets[r + 1]]``.  The replacement of a per-read loop over ``Builder.run``."""
+    codes = []
+    for s in reads:
+        if isinstance(s, (bytes, bytearray)):
+            a = np.frombuffer(bytes(s), dtype=np.uint8)
+            codes.append((a >> 1) & 3)
+        else:  # PackedSeq view
+            a = np.asarray(s.data, dtype=np.uint8)
+            idx = np.arange(s.offset, s.offset + s.len)
+            codes.append((a[idx // 4] >> (2 * (idx % 4))) & 3)
+    lens = [len(c) for c in codes]
+    starts = np.zeros(len(lens) + 1, dtype=np.uint64)
+    starts[1:] = np.cumsum(lens, dtype=np.uint64)
+    total = int(starts[-1])
+    flat = np.concatenate(codes).astype(np.uint8) if total else np.zeros(0, dtype=np.uint8)
+    pad = np.zeros((-total) % 4, dtype=np.uint8)
+    q = np.concatenate([flat, pad]).reshape(-1, 4)
+    packed = (q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8) if total else np.zeros(1, dtype=np.uint8)
+    cap = max(1, total)
+    pos = np.empty(cap, dtype=np.uint32)
+    sk = np.empty(cap, dtype=np.uint32) if super_kmers else None
+    offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+    cnt = C.c_uint64()
+    ws = builder._ws()
+    _check(lib().mm_run_packed_reads_host(builder.plan().h, ws.h, packed.ctypes.data_as(C.POINTER(C.c_uint8)), len(lens),
+                                          starts.ctypes.data_as(C.POINTER(C.c_uint64)), max(lens) if lens else 0,
+                                          pos.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                          sk.ctypes.data_as(C.POINTER(C.c_uint32)) if sk is not None else None, cap,
+                                          offs.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(cnt)))
+    n = int(cnt.value)
+    return pos[:n], [int(o) for o in offs], (sk[:n] if sk is not None else None)
 
 
 def run_packed_reads_device(builder: "Builder", records: FastaRecords, out_pos, out_offsets, out_sk=None, max_read_len=None):

@@ -1552,6 +1552,51 @@ int mm_run_host(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed
                            capacity, out_count);
 }
 
+// Many short sequences from HOST memory in one call (round 4): what a caller that looped Builder::run over its reads
+// (src/lib.rs:378; 2-20 ns per base on the reference's CPU, about 28 us per CALL here) does instead - the reads packed
+// back to back, their starts, one upload, ONE launch of the reads-mode kernel, one download.
+int mm_run_packed_reads_host(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed, uint64_t n_reads,
+                             const uint64_t *read_starts, uint32_t max_read_len, uint32_t *out_pos, uint32_t *out_sk,
+                             uint64_t capacity, uint64_t *out_offsets, uint64_t *out_count) {
+    if (!plan || !ws || !out_offsets) return MM_ERR_NULL;
+    if (n_reads && (!read_starts || !packed)) return MM_ERR_NULL;
+    if (out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;
+    if (out_count) *out_count = 0;
+    MM_HIP(hipSetDevice(ws->device));
+    const uint64_t total_bases = n_reads ? read_starts[n_reads] : 0;
+    for (uint64_t r = 0; r < n_reads; ++r)
+        if (read_starts[r] > read_starts[r + 1]) return MM_ERR_CAPACITY;  // (starts must not decrease)
+    if (total_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
+    const uint64_t bytes = (total_bases + 3) / 4;
+    // staging: [packed bytes + slack | starts] in d_in, positions (and indices) in d_out / d_sk, offsets in d_vals
+    const uint64_t starts_at = (bytes + 64 + 15) & ~15ull;
+    uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
+    int r = grow(din, ws->d_in_bytes, starts_at + (n_reads + 1) * sizeof(uint64_t), 1);
+    ws->d_in = din;
+    if (r) return r;
+    uint64_t cap = out_pos ? (capacity < total_bases ? capacity : total_bases) : 0;
+    r = grow(ws->d_out, ws->d_out_elems, cap ? cap : 1, sizeof(uint32_t));
+    if (r == MM_OK && out_sk) r = grow(ws->d_sk, ws->d_sk_elems, cap ? cap : 1, sizeof(uint32_t));
+    if (r == MM_OK) r = grow(ws->d_vals, ws->d_vals_elems, n_reads + 1, sizeof(unsigned long long));
+    if (r) return r;
+    if (bytes) MM_HIP(hipMemcpyAsync(din, packed, bytes, hipMemcpyHostToDevice, ws->stream));
+    MM_HIP(hipMemsetAsync(din + bytes, 0, starts_at - bytes, ws->stream));
+    if (n_reads) MM_HIP(hipMemcpyAsync(din + starts_at, read_starts, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ws->stream));
+    uint64_t count = 0;
+    r = mm_run_packed_reads_device(plan, ws, din, starts_at, 0, n_reads, reinterpret_cast<const uint64_t *>(din + starts_at),
+                                   total_bases, max_read_len, cap ? ws->d_out : nullptr, (out_sk && cap) ? ws->d_sk : nullptr, cap,
+                                   reinterpret_cast<uint64_t *>(ws->d_vals), &count);
+    if (out_count) *out_count = count;
+    if (r) return r;
+    MM_HIP(hipMemcpyAsync(out_offsets, ws->d_vals, (n_reads + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ws->stream));
+    if (out_pos && count) {
+        MM_HIP(hipMemcpyAsync(out_pos, ws->d_out, count * sizeof(uint32_t), hipMemcpyDeviceToHost, ws->stream));
+        if (out_sk) MM_HIP(hipMemcpyAsync(out_sk, ws->d_sk, count * sizeof(uint32_t), hipMemcpyDeviceToHost, ws->stream));
+    }
+    MM_HIP(hipStreamSynchronize(ws->stream));
+    return MM_OK;
+}
+
 int mm_run_host_ascii(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *ascii,
                       uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk, uint64_t capacity,
                       uint64_t *out_count) {

@@ -644,3 +644,24 @@ def test_packed_reads_of_any_lengths(sm, oracle, gpu):
     long_lens[17] = 70_001  # too long for one lane: one launch per read, same results
     check(long_lens, 21, 11, True, 0)
     check([], 21, 11, True, 0)
+
+
+def test_packed_reads_from_host(sm, oracle, gpu):
+    """mm_run_packed_reads_host: the one-call replacement of a per-read loop over Builder::run (src/lib.rs:378) - many short
+    host sequences, one upload, one launch, one download; every read against the oracle, super-k-mer indices too."""
+    rng = np.random.default_rng(44)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = [acgt[rng.integers(0, 4, int(ln))].tobytes() for ln in list(rng.integers(0, 300, 900)) + [0, 30, 31, 1000]]
+    for (k, w, canonical, mode, sk) in ((21, 11, True, 0, False), (21, 11, False, 0, True), (15, 17, True, 1, False)):
+        b = sm.Builder(k, w, canonical, mode)
+        pos, offs, skv = sm.run_reads_host(b, reads, super_kmers=sk)
+        assert len(offs) == len(reads) + 1 and offs[0] == 0 and offs[-1] == len(pos)
+        for r in list(range(0, len(reads), 11)) + [len(reads) - 4, len(reads) - 3, len(reads) - 2, len(reads) - 1]:
+            packed = np.concatenate([oracle.pack_ascii(reads[r]), np.zeros(16, dtype=np.uint8)])
+            res = oracle.run(packed, len(reads[r]), k, w, canonical=canonical, mode=mode, super_kmers=sk)
+            wp = res[0] if sk else res
+            assert np.array_equal(pos[offs[r]: offs[r + 1]], wp), (r, k, w, mode)
+            if sk:
+                assert np.array_equal(skv[offs[r]: offs[r + 1]], res[1]), r
+    pos, offs, _ = sm.run_reads_host(sm.canonical_minimizers(21, 11), [])
+    assert len(pos) == 0 and offs == [0]
