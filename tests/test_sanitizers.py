@@ -88,6 +88,36 @@ g.close()
 text = b">a\nACGTACGTTTGACCA\nACGT\n>b\n\n>c\nTTTTGGGG\n" * 50
 rec = sm.fasta_pack_device(text)
 assert len(rec) == 150
+# round 4: device-resident shards and batches of a group, FASTQ, packed reads (device and host), the launch planner
+g = sm.DeviceGroup([0, 0])
+data = oracle.gen_packed(6, 4_000_003)
+g.upload(data[: (4_000_003 + 3) // 4 + 1])
+for _ in range(3):
+    counts = g.run_device(b, 4_000_003)
+want = oracle.run(data, 4_000_003, k, w, canonical=True)
+dst = torch.zeros(len(want) + 8, dtype=torch.int32, device="cuda")
+assert g.gather(1, dst) == len(want) and np.array_equal(dst[: len(want)].cpu().numpy().view(np.uint32), want)
+lens = [300_000, 7, 0, 1_000_001, 250_000]
+seqs = [oracle.gen_packed(60 + i, m + 3) for i, m in enumerate(lens)]
+g.upload_batch([s_[: (m + 3) // 4 + 1] for s_, m in zip(seqs, lens)])
+cc = g.run_batch_device(b, lens)
+o = g.gather_batch(0, dst)
+assert np.array_equal(dst[o[3]:o[4]].cpu().numpy().view(np.uint32), oracle.run(seqs[3], lens[3], k, w, canonical=True))
+g.close()
+fq = b"".join(b"@r%d\n" % i + b"ACGTTGCATGCA" * (3 + i % 20) + b"\n+\n" + b"I" * (12 * (3 + i % 20)) + b"\n" for i in range(700))
+rec = sm.fasta_pack_device(fq, max_records=1024)
+assert len(rec) == 700
+out = torch.zeros(int(rec.base[-1]) + 8, dtype=torch.int32, device="cuda")
+offs = torch.zeros(701, dtype=torch.int64, device="cuda")
+sm.run_packed_reads_device(b, rec, out, offs)
+pos, ho, _ = sm.run_reads_host(b, [b"ACGTTGCATGCA" * (3 + i % 20) for i in range(300)])
+assert ho[-1] == len(pos)
+import ctypes as C
+os.environ["MM_TAPER_SLOTS"] = "3"
+arr = (C.c_uint64 * 3)(900_000, 0, 5_000_000)
+seq_, w0_, nb_ = (C.c_uint32 * 4096)(), (C.c_uint32 * 4096)(), (C.c_uint32 * 4096)()
+o7, nt = (C.c_uint64 * 7)(), C.c_uint64()
+assert sm.lib().mm_debug_launch_plan(11, 1, 0, 3, arr, o7, seq_, w0_, nb_, 4096, C.byref(nt)) == 0 and nt.value > 3
 print("host paths ok")
 """
 
