@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs ONE secondary configuration a few times (the command rocprofv3 wraps for the per-configuration
-profiles under profiles/): tools/run_config.py <C2|FWD|C4|C5|READS|C3|READS_SK|SKIP|VALUES|PACK|FASTA> [steps] [warmup].
+profiles under profiles/): tools/run_config.py <C2|FWD|C4|C5|READS|C3|SHARD|READS_SK|SKIP|VALUES|PACK|FASTA|FASTQ> [steps] [warmup].
 Prints kernel time by HIP events (median) as one JSON line.  Measurement aid, not part of the product."""
 import json
 import os
@@ -46,6 +46,24 @@ if cfg in ("C2", "FWD", "C3", "C5"):
 
     def step():
         b.run_device(d, n, out, sync=False, d_count=cnt)
+
+    def n_out():
+        return int(cnt.item())
+elif cfg == "SHARD":
+    # the strong split at N = 8 (bench.py's `extra` row) on ONE GPU: the eight window ranges of the 3.1 Gbp sequence,
+    # one launch each, back to back (an isolated 0.2 ms launch after an idle gap runs 15 % slower: clock ramp)
+    b = sm.canonical_minimizers(21, 11).workspace(ws)
+    d = gen(N, 3)
+    nw = N - 31 + 1
+    per = -(-nw // 8)
+    ranges = [(r * per, min((r + 1) * per, nw)) for r in range(8)]
+    n = nw // 8  # per launch
+    out = torch.empty(int(per * 2 / 12 * 1.15) + 4096, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        for wb, we in ranges:
+            b.run_device(d, N, out, win_begin=wb, win_end=we, sync=False, d_count=cnt)
 
     def n_out():
         return int(cnt.item())
