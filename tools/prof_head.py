@@ -149,6 +149,30 @@ def config(tag, cfg):
     open(os.path.join(OUT, f"{tag}_{cfg}.txt"), "w").writelines(lines)
 
 
+def stalls(tag, cfg):
+    """What the waves of a configuration's fused kernel wait for: SQ wait / active counters, separate passes."""
+    cmd = ["python3", "tools/run_config.py", cfg, "3", "2"]
+    passes = {"w1": ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS",
+                     "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"],
+              "w2": ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM",
+                     "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM"],
+              "w3": ["SQ_INST_CYCLES_VMEM_RD", "SQ_INST_CYCLES_VMEM_WR", "SQ_ACTIVE_INST_SCA", "SQ_IFETCH", "SQ_WAIT_IFETCH",
+                     "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INST_LEVEL_VMEM"],
+              "w4": ["TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA_RDREQ_sum",
+                     "TCP_PENDING_STALL_CYCLES_sum"]}
+    lines = [f"== SQ / cache counters of the fused kernel, python3 tools/run_config.py {cfg} 3 2, one group per pass\n"]
+    for name, pmc in passes.items():
+        db = rocprof(f"{tag}_{cfg}_{name}", pmc, cmd)
+        if not db:
+            lines.append(f"({name}: no database; see {tag}_{cfg}_{name}.log)\n")
+            continue
+        cs, meta = counters(db)
+        lines.append(f"-- pass {name} ({meta})\n")
+        for c, (v, dur, cnt) in sorted(cs.items()):
+            lines.append(f"{c:30s} n={cnt} mean={v:.6g} kernel_us={dur:.1f}\n")
+    open(os.path.join(OUT, f"{tag}_{cfg}_stalls.txt"), "w").writelines(lines)
+
+
 def component(tag, cfg):
     """One of the rows either side of the path (simd_minimizers_amd.workloads): kernel trace of `run_config.py cfg 5 3`
     and FETCH_SIZE / WRITE_SIZE summed over the kernels of one step."""
@@ -203,6 +227,8 @@ if __name__ == "__main__":
     for what in sys.argv[2:]:
         if what == "headline":
             headline(tag)
+        elif what.startswith("stalls:"):
+            stalls(tag, what[7:])
         elif what in ("READS", "READS_SK", "SKIP", "VALUES", "PACK", "FASTA", "FASTQ"):
             component(tag, what)
         else:
