@@ -15,13 +15,21 @@
 // All records go back to back into ONE 2-bit buffer, record r = bases [rec_base[r], rec_base[r + 1]) - the layout of
 // the FASTA packer, i.e. what mm_run_batch_device takes, and with a fixed read length what mm_run_reads_device takes.
 //
-// Three plain passes over the text (16 KB per workgroup in four rounds of 4 KB, 16 bytes per thread and round):
-//   K1  '\n' bytes per chunk                      -> S1 exclusive sum = index of the line every chunk starts in
-//   K2  with that index: sequence bytes (bytes of lines 4r + 1 that are not '\n' / '\r') and record starts (first bytes
-//       of lines 4r) per chunk                    -> S2 exclusive sums
-//   K3  every thread packs its (at most 16, consecutive in the output) sequence bytes and ORs one or two dwords into
-//       the cleared output; the first byte of a line 4r writes the record's table entries.
-// Not tuned like the FASTA packer's one-pass kernel: ~2.5 passes over the text and atomics for the output.
+// TWO passes over the text (16 KB per workgroup = four 4 KB pieces, 16 bytes per thread and piece, all four pieces of a
+// thread in registers) with one small resolve step between them:
+//   K1  per chunk: its '\n' bytes, and - for EACH of the four line phases the chunk may start in (line index mod 4) -
+//       its sequence bytes (bytes of lines 4r + 1 that are not '\n' / '\r') and record starts (first bytes of lines
+//       4r), four 16-bit fields per 64-bit word.  What a byte is depends on the number of newlines in front of it mod 4
+//       only, so the four answers are one analysis and a rotation of its four counts.
+//   R   (two tiny kernels, see fastq_groups_kernel) exclusive sum of the newline counts = the phase every chunk starts
+//       in, which selects the field; exclusive sums of the selected counts = every chunk's first output base and first
+//       record.
+//   K2  every thread packs its (at most 16) sequence bytes per piece - one run, consecutive in the output - and ORs one
+//       or two dwords into the cleared output; the first byte of a line 4r writes the record's table entries.
+// Per 16-byte piece of a thread everything is bit arithmetic on 16-bit masks (round 4, second version; the first one
+// walked the bytes one by one in three passes and ran at 0.44 TB/s of text): byte-equality masks by SWAR, the number of
+// newlines before every byte mod 4 from two prefix-XORs (low bit: parity of the newlines; high bit: parity of the
+// newlines that arrive on an odd count), the 2-bit codes of 16 bytes by one multiply per dword.
 #include "mm_common.h"
 #include "mm_launch.h"
 
@@ -31,14 +39,17 @@ namespace {
 
 constexpr uint32_t kFqThreads = 256;
 constexpr uint32_t kFqBytesPerThread = 16;
-constexpr uint32_t kFqPiece = kFqThreads * kFqBytesPerThread;   // 4 KB of text per round of a workgroup
-constexpr uint32_t kFqPieces = 4;                               // rounds per workgroup
+constexpr uint32_t kFqPiece = kFqThreads * kFqBytesPerThread;   // 4 KB of text per piece of a workgroup
+constexpr uint32_t kFqPieces = 4;                               // pieces per workgroup
 constexpr uint32_t kFqChunk = kFqPiece * kFqPieces;             // 16 KB of text per workgroup (one entry of the scans)
+constexpr int kFqWaves = (int)(kFqThreads / kWave);
+static_assert(kFqPieces == 4, "the '\\r' test and the piece-major sums below are written for four pieces");
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// the thread's 16 text bytes (zeros past the end of the text), from a bounds-checked view of the chunk
+// the thread's 16 text bytes (zeros past the end of the text), from a bounds-checked view of the piece
 __device__ __forceinline__ u32x4 load16(const uint8_t *text, uint64_t n, uint64_t c0, uint32_t t) {
+    if (c0 >= n) return u32x4{0u, 0u, 0u, 0u};
     const uint64_t left = n - c0;
     const uint32_t here = left < kFqPiece ? (uint32_t)left : kFqPiece;
     // (the text pointer may have any alignment: the view starts at the dword that holds byte c0)
@@ -62,240 +73,375 @@ __device__ __forceinline__ uint32_t byte_of(const u32x4 &v, int i) {
     return (w >> (8 * (i & 3))) & 0xffu;
 }
 
-// inclusive sum over the workgroup (256 threads); returns this thread's inclusive value, *total = the workgroup's sum
-__device__ __forceinline__ uint32_t block_inclusive(uint32_t v, uint32_t *s_wave, uint32_t *total) {
+// 4-bit mask of the bytes of x that equal the byte replicated in pat (exact zero-byte test, then the four flag bits
+// at 7 / 15 / 23 / 31 gathered by one multiply: the partial products do not overlap)
+__device__ __forceinline__ uint32_t eq4(uint32_t x, uint32_t pat) {
+    const uint32_t z = x ^ pat;
+    const uint32_t t = (z & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+    const uint32_t m = ~(t | z | 0x7f7f7f7fu);
+    return ((m >> 7) * 0x10204080u) >> 28;
+}
+__device__ __forceinline__ uint32_t eq16(const u32x4 &v, uint32_t pat) {
+    return eq4(v.x, pat) | (eq4(v.y, pat) << 4) | (eq4(v.z, pat) << 8) | (eq4(v.w, pat) << 12);
+}
+// does any byte of x equal the byte replicated in pat?  (three operations; exact as a yes / no)
+__device__ __forceinline__ uint32_t any_eq4(uint32_t x, uint32_t pat) {
+    const uint32_t z = x ^ pat;
+    return (z - 0x01010101u) & ~z & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t any_eq16(const u32x4 &v, uint32_t pat) {
+    return any_eq4(v.x, pat) | any_eq4(v.y, pat) | any_eq4(v.z, pat) | any_eq4(v.w, pat);
+}
+// inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (also of packed 16-bit fields whose
+// sums stay below 2^16)
+__device__ __forceinline__ uint32_t fq_wave_scan(uint32_t v) {
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+// inclusive prefix XOR of a 16-bit mask
+__device__ __forceinline__ uint32_t pxor16(uint32_t x) {
+    x ^= x << 1;
+    x ^= x << 2;
+    x ^= x << 4;
+    x ^= x << 8;
+    return x & 0xffffu;
+}
+
+// What the 16 bytes of a thread are, as 16-bit masks (bit i = byte i), whatever line the first byte lies in:
+//   nl     '\n' bytes (inside the text)
+//   valid  bytes inside the text that are neither '\n' nor '\r'
+//   lo, hi the number of newlines among the bytes in front of byte i, mod 4 (bit 0 / bit 1)
+//   first  bytes that start a line ('\n' right in front; byte 0: the thread's `starts_line`)
+struct FqPiece {
+    uint32_t nl, valid, lo, hi, first;
+};
+// (has_cr: wave-uniform, does any thread of the wave hold a '\r' in any of its pieces - most texts have none)
+__device__ __forceinline__ FqPiece analyse(const u32x4 &v, uint64_t b0, uint64_t n, bool starts_line, bool has_cr) {
+    FqPiece f;
+    const uint32_t inside = b0 >= n ? 0u : (n - b0 >= 16u ? 0xffffu : ((1u << (uint32_t)(n - b0)) - 1u));
+    f.nl = eq16(v, 0x0a0a0a0au) & inside;
+    const uint32_t cr = has_cr ? eq16(v, 0x0d0d0d0du) : 0u;
+    f.valid = inside & ~f.nl & ~cr;
+    f.lo = (pxor16(f.nl) << 1) & 0xffffu;
+    f.hi = (pxor16(f.nl & f.lo) << 1) & 0xffffu;  // (the count's bit 1 flips where a newline arrives on an odd count)
+    f.first = ((f.nl << 1) | (starts_line ? 1u : 0u)) & 0xffffu;
+    return f;
+}
+// the bytes in front of which the newline count of the piece is t mod 4
+__device__ __forceinline__ uint32_t count_is(const FqPiece &f, uint32_t t) {
+    return (f.lo ^ ((t & 1u) ? 0u : 0xffffu)) & (f.hi ^ ((t & 2u) ? 0u : 0xffffu));
+}
+
+// does the thread's first byte of this piece start a line?  The byte in front of it is the last byte of the lane before
+// (one DPP-style shuffle); lane 0 of a wave reads it from memory.
+__device__ __forceinline__ bool starts_line_of(const uint8_t *text, uint64_t n, uint64_t b0, const u32x4 &v) {
+    const int lane = threadIdx.x & (kWave - 1);
+    uint32_t prev = __shfl_up(v.w >> 24, 1, kWave);
+    if (lane == 0) prev = (b0 > 0 && b0 <= n) ? text[b0 - 1] : (uint32_t)'\n';
+    return b0 == 0 || (b0 < n && prev == (uint32_t)'\n');
+}
+
+// Sums over the chunk in TEXT order (piece-major: piece p of thread t lies behind piece p of every thread < t and
+// behind every earlier piece).  In: the thread's value per piece.  Out: the exclusive prefix per piece; returns the total.
+__device__ __forceinline__ uint32_t chunk_exclusive(const uint32_t (&v)[kFqPieces], uint32_t (&excl)[kFqPieces],
+                                                    uint32_t (*s_part)[kFqWaves]) {
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const uint32_t incl = wave_inclusive_sum(v);
-    if (lane == kWave - 1) s_wave[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0, tot = 0;
+    uint32_t incl[kFqPieces];
 #pragma unroll
-    for (int w = 0; w < (int)(kFqThreads / kWave); ++w) {
-        const uint32_t x = s_wave[w];
-        if (w < wave) before += x;
-        tot += x;
+    for (int p = 0; p < (int)kFqPieces; ++p) {
+        incl[p] = fq_wave_scan(v[p]);
+        if (lane == kWave - 1) s_part[p][wave] = incl[p];
+    }
+    __syncthreads();
+    uint32_t run = 0;
+#pragma unroll
+    for (int p = 0; p < (int)kFqPieces; ++p) {
+        uint32_t before = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < kFqWaves; ++w) {
+            const uint32_t x = s_part[p][w];
+            if (w < wave) before += x;
+            tot += x;
+        }
+        excl[p] = run + before + incl[p] - v[p];
+        run += tot;
+    }
+    __syncthreads();
+    return run;
+}
+
+// rotate the four 8-bit fields of x up by a fields: field s of the result = field (s - a) & 3 of x
+__device__ __forceinline__ uint32_t rot_fields(uint32_t x, uint32_t a) {
+    return __builtin_amdgcn_alignbit(x, x, (32u - 8u * a) & 31u);
+}
+// four 8-bit fields -> four 16-bit fields
+__device__ __forceinline__ unsigned long long widen_fields(uint32_t x) {
+    return (unsigned long long)(x & 0xffu) | ((unsigned long long)(x & 0xff00u) << 8) | ((unsigned long long)(x & 0xff0000u) << 16) |
+           ((unsigned long long)(x & 0xff000000u) << 24);
+}
+
+// K1: per chunk the newlines, and sequence bytes / record starts for each of the four phases it may start in
+__global__ __launch_bounds__(kFqThreads) void fastq_count_kernel(const uint8_t *__restrict__ text, uint64_t n,
+                                                                 unsigned long long *__restrict__ nl_count,
+                                                                 unsigned long long *__restrict__ seq_by_phase,
+                                                                 unsigned long long *__restrict__ rec_by_phase) {
+    __shared__ uint32_t s_part[kFqPieces][kFqWaves];
+    __shared__ unsigned long long s_red[2][kFqWaves];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint64_t c0 = (uint64_t)blockIdx.x * kFqChunk;
+    u32x4 v[kFqPieces];
+#pragma unroll
+    for (int p = 0; p < (int)kFqPieces; ++p) v[p] = load16(text, n, c0 + (uint64_t)p * kFqPiece, threadIdx.x);
+    FqPiece f[kFqPieces];
+    uint32_t nls[kFqPieces], before[kFqPieces];
+    const bool has_cr = __ballot((any_eq16(v[0], 0x0d0d0d0du) | any_eq16(v[1], 0x0d0d0d0du) | any_eq16(v[2], 0x0d0d0d0du) |
+                                  any_eq16(v[3], 0x0d0d0d0du)) != 0u) != 0ull;
+#pragma unroll
+    for (int p = 0; p < (int)kFqPieces; ++p) {
+        const uint64_t b0 = c0 + (uint64_t)p * kFqPiece + (uint64_t)threadIdx.x * kFqBytesPerThread;
+        f[p] = analyse(v[p], b0, n, starts_line_of(text, n, b0, v[p]), has_cr);
+        nls[p] = __popc(f[p].nl);
+    }
+    const uint32_t total_nl = chunk_exclusive(nls, before, s_part);
+    // Field s (chunk starts in phase s): this thread's byte i is a sequence byte iff s + before + count(i) == 1 mod 4.
+    // P[j] = bytes whose own count is j; the answer for s is P[(1 - before - s) & 3]: the counts in the order
+    // P[0], P[3], P[2], P[1], rotated up by (1 - before) & 3 fields.  Record starts: the same with 0 for 1.
+    uint32_t seq8 = 0, rec8 = 0;
+#pragma unroll
+    for (int p = 0; p < (int)kFqPieces; ++p) {
+        uint32_t ps = 0, pr = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t m = count_is(f[p], j) & f[p].valid;
+            const uint32_t field = 8u * ((4u - j) & 3u);
+            ps |= (uint32_t)__popc(m) << field;
+            pr |= (uint32_t)__popc(m & f[p].first) << field;
+        }
+        seq8 += rot_fields(ps, (1u - before[p]) & 3u);  // (a field stays below 4 x 16 = 64)
+        rec8 += rot_fields(pr, (0u - before[p]) & 3u);
+    }
+    unsigned long long a = widen_fields(seq8), b = widen_fields(rec8);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d, kWave);
+        b += __shfl_xor(b, d, kWave);
+    }
+    if (lane == 0) {
+        s_red[0][wave] = a;
+        s_red[1][wave] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long ta = 0, tb = 0;
+#pragma unroll
+        for (int w = 0; w < kFqWaves; ++w) {
+            ta += s_red[0][w];
+            tb += s_red[1][w];
+        }
+        nl_count[blockIdx.x] = total_nl;
+        seq_by_phase[blockIdx.x] = ta;  // (a field is at most 16 384: no carry between fields)
+        rec_by_phase[blockIdx.x] = tb;
+    }
+}
+
+// R: the chunk functions resolved in two small steps (a first version - ONE workgroup walking all 65 536 chunks of a
+// 1 GiB text, sixteen per thread - took 0.28 ms of 1.06: uncoalesced, and two dependent rounds of loads per round).
+//   R1  one workgroup per GROUP of 256 chunks, one chunk per thread: the newlines in front of every chunk within its
+//       group, and - for each of the four phases the GROUP may start in - the sequence bytes / record starts in front
+//       of every chunk within the group (four 32-bit fields in two words) and of the whole group: the chunk's fields
+//       rotated down by its newline count, then plain workgroup sums.
+//   R2  one workgroup, one group per thread: the line every group starts in -> its phase -> its field -> exclusive sums.
+// K2 adds its group's resolved start and its own within-group prefix of the group's phase.
+constexpr uint32_t kFqGroup = 256;  // chunks per group = threads of R1
+struct FqScratch {
+    unsigned long long *nl;        // [chunks]      K1: '\n' bytes of the chunk; R1: newlines in front of it within its group
+    unsigned long long *seq, *rec; // [chunks]      K1: four 16-bit fields (the chunk starts in phase s)
+    unsigned long long *pre_seq, *pre_rec;  // [2 * chunks]  R1: four 32-bit fields: in front of the chunk within its group
+    unsigned long long *g_nl;      // [groups + 1]  R1: '\n' bytes of the group; R2: the line it starts in
+    unsigned long long *g_seq, *g_rec;      // [2 * groups]  R1: four 32-bit fields: the whole group
+    unsigned long long *g_seq0, *g_rec0;    // [groups + 1]  R2: first output base / first record of the group ([groups]: totals)
+};
+__device__ __forceinline__ unsigned long long block_exclusive64(unsigned long long v, unsigned long long *s_wave,
+                                                                unsigned long long *total) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    unsigned long long x = v;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const unsigned long long y = __shfl_up(x, d, kWave);
+        if (lane >= d) x += y;
+    }
+    if (lane == kWave - 1) s_wave[wave] = x;
+    __syncthreads();
+    unsigned long long before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kFqWaves; ++w) {
+        const unsigned long long t = s_wave[w];
+        if (w < wave) before += t;
+        tot += t;
     }
     __syncthreads();
     *total = tot;
-    return incl + before;
+    return before + x - v;
 }
-
-__global__ __launch_bounds__(kFqThreads) void fastq_newlines_kernel(const uint8_t *__restrict__ text, uint64_t n,
-                                                                    unsigned long long *__restrict__ nl_count) {
-    __shared__ uint32_t s_wave[kFqThreads / kWave];
-    uint32_t cnt = 0;
-    for (uint32_t p = 0; p < kFqPieces; ++p) {
-        const uint64_t c0 = (uint64_t)blockIdx.x * kFqChunk + (uint64_t)p * kFqPiece;
-        if (c0 >= n) break;
-        const u32x4 v = load16(text, n, c0, threadIdx.x);
-        const uint64_t b0 = c0 + (uint64_t)threadIdx.x * kFqBytesPerThread;
-#pragma unroll
-        for (int i = 0; i < (int)kFqBytesPerThread; ++i)
-            if (b0 + i < n && byte_of(v, i) == '\n') ++cnt;
-    }
-    uint32_t total;
-    (void)block_inclusive(cnt, s_wave, &total);
-    if (threadIdx.x == 0) nl_count[blockIdx.x] = total;
+// four 16-bit fields, field s of the result = field (s + by) & 3 of x, widened to four 32-bit fields (lo: 0, 1; hi: 2, 3)
+__device__ __forceinline__ void rotate_widen(unsigned long long x, uint32_t by, unsigned long long *lo, unsigned long long *hi) {
+    const uint32_t sh = 16u * (by & 3u);
+    const unsigned long long y = sh ? (x >> sh) | (x << (64u - sh)) : x;
+    *lo = (y & 0xffffull) | ((y & 0xffff0000ull) << 16);
+    *hi = ((y >> 32) & 0xffffull) | (((y >> 32) & 0xffff0000ull) << 16);
 }
-
-// exclusive sums of one or two arrays of `m` 64-bit counts, in place, by ONE workgroup (m = text bytes / 4096:
-// 262 144 for 1 GiB); element m receives the grand total.  Sixteen consecutive elements per thread and round (a first
-// version with one element per thread took 1.5 ms per scan: a thousand rounds of three barriers).
-constexpr int kFqScanPerThread = 16;
-__global__ __launch_bounds__(kFqThreads) void fastq_scan_kernel(unsigned long long *a, unsigned long long *b, uint64_t m) {
-    __shared__ unsigned long long s_wave[2][kFqThreads / kWave];
-    __shared__ unsigned long long s_carry[2];
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (threadIdx.x < 2) s_carry[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint64_t i0 = 0; i0 < m; i0 += (uint64_t)kFqThreads * kFqScanPerThread) {
-        const uint64_t t0 = i0 + (uint64_t)threadIdx.x * kFqScanPerThread;
-        unsigned long long v[2][kFqScanPerThread], sum[2] = {0ull, 0ull}, incl[2];
-#pragma unroll
-        for (int u = 0; u < kFqScanPerThread; ++u) {
-            v[0][u] = t0 + u < m ? a[t0 + u] : 0ull;
-            v[1][u] = (b && t0 + u < m) ? b[t0 + u] : 0ull;
-            sum[0] += v[0][u];
-            sum[1] += v[1][u];
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            unsigned long long x = sum[q];
-#pragma unroll
-            for (int d = 1; d < kWave; d <<= 1) {
-                const unsigned long long y = __shfl_up(x, d, kWave);
-                if (lane >= d) x += y;
-            }
-            incl[q] = x;
-            if (lane == kWave - 1) s_wave[q][wave] = x;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (q == 1 && !b) continue;
-            unsigned long long run = s_carry[q] + incl[q] - sum[q];
-            for (int w = 0; w < wave; ++w) run += s_wave[q][w];
-#pragma unroll
-            for (int u = 0; u < kFqScanPerThread; ++u) {
-                if (t0 + u < m) (q == 0 ? a : b)[t0 + u] = run;
-                run += v[q][u];
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                unsigned long long tot = 0;
-                for (int w = 0; w < (int)(kFqThreads / kWave); ++w) tot += s_wave[q][w];
-                s_carry[q] += tot;
-            }
-        }
-        __syncthreads();
+__device__ __forceinline__ unsigned long long field32(unsigned long long lo, unsigned long long hi, uint32_t s) {
+    const unsigned long long w = (s & 2u) ? hi : lo;
+    return (s & 1u) ? (w >> 32) : (w & 0xffffffffull);
+}
+__global__ __launch_bounds__(kFqGroup) void fastq_groups_kernel(FqScratch sc, uint64_t chunks) {
+    __shared__ unsigned long long s_wave[kFqWaves];
+    const uint64_t c = (uint64_t)blockIdx.x * kFqGroup + threadIdx.x;
+    const bool in = c < chunks;
+    const unsigned long long nl = in ? sc.nl[c] : 0ull;
+    unsigned long long tot_nl;
+    const unsigned long long before = block_exclusive64(nl, s_wave, &tot_nl);
+    unsigned long long sl, sh, rl, rh;
+    rotate_widen(in ? sc.seq[c] : 0ull, (uint32_t)before, &sl, &sh);
+    rotate_widen(in ? sc.rec[c] : 0ull, (uint32_t)before, &rl, &rh);
+    unsigned long long t0, t1, t2, t3;
+    const unsigned long long psl = block_exclusive64(sl, s_wave, &t0), psh = block_exclusive64(sh, s_wave, &t1);
+    const unsigned long long prl = block_exclusive64(rl, s_wave, &t2), prh = block_exclusive64(rh, s_wave, &t3);
+    if (in) {
+        sc.nl[c] = before;
+        sc.pre_seq[2 * c] = psl;
+        sc.pre_seq[2 * c + 1] = psh;
+        sc.pre_rec[2 * c] = prl;
+        sc.pre_rec[2 * c + 1] = prh;
     }
     if (threadIdx.x == 0) {
-        a[m] = s_carry[0];
-        if (b) b[m] = s_carry[1];
+        sc.g_nl[blockIdx.x] = tot_nl;
+        sc.g_seq[2 * blockIdx.x] = t0;
+        sc.g_seq[2 * blockIdx.x + 1] = t1;
+        sc.g_rec[2 * blockIdx.x] = t2;
+        sc.g_rec[2 * blockIdx.x + 1] = t3;
     }
 }
-
-// What a thread knows about its 16 bytes once the line index of its first byte is known.
-struct FqThread {
-    uint32_t seq_mask;    // bit i: byte i is a sequence byte (line 4r + 1, not '\n' / '\r')
-    uint32_t start_mask;  // bit i: byte i is the first byte of a line 4r (a record's '@')
-};
-__device__ __forceinline__ FqThread classify(const u32x4 &v, uint64_t b0, uint64_t n, unsigned long long line0,
-                                             bool first_is_line_start) {
-    FqThread r{0u, 0u};
-    unsigned long long line = line0;
-    bool at_start = first_is_line_start;
-    // (bytes past the end of the text read as 0: neither '\n' nor counted, see `inside`)
-    uint32_t ph = (uint32_t)(line & 3ull);
-#pragma unroll
-    for (int i = 0; i < (int)kFqBytesPerThread; ++i) {
-        const bool inside = b0 + i < n;
-        const uint32_t c = byte_of(v, i);
-        const bool nl = inside && c == '\n';
-        const bool other = inside && !nl;
-        if (other && at_start && ph == 0u && c != '\r') r.start_mask |= 1u << i;  // (a blank line 4r starts no record)
-        if (other && ph == 1u && c != '\r') r.seq_mask |= 1u << i;
-        ph = nl ? ((ph + 1u) & 3u) : ph;
-        at_start = nl ? true : (other ? false : at_start);
+__global__ __launch_bounds__(kFqGroup) void fastq_resolve_kernel(FqScratch sc, uint64_t groups) {
+    __shared__ unsigned long long s_wave[kFqWaves];
+    unsigned long long carry_nl = 0, carry_seq = 0, carry_rec = 0;
+    for (uint64_t g0 = 0; g0 < groups; g0 += kFqGroup) {  // (one round up to 1 GiB of text)
+        const uint64_t g = g0 + threadIdx.x;
+        const bool in = g < groups;
+        const unsigned long long nl = in ? sc.g_nl[g] : 0ull;
+        unsigned long long tot;
+        const unsigned long long line = carry_nl + block_exclusive64(nl, s_wave, &tot);
+        carry_nl += tot;
+        const uint32_t ph = (uint32_t)(line & 3ull);
+        const unsigned long long s = in ? field32(sc.g_seq[2 * g], sc.g_seq[2 * g + 1], ph) : 0ull;
+        const unsigned long long r = in ? field32(sc.g_rec[2 * g], sc.g_rec[2 * g + 1], ph) : 0ull;
+        const unsigned long long s0 = carry_seq + block_exclusive64(s, s_wave, &tot);
+        carry_seq += tot;
+        const unsigned long long r0 = carry_rec + block_exclusive64(r, s_wave, &tot);
+        carry_rec += tot;
+        if (in) {
+            sc.g_nl[g] = line;
+            sc.g_seq0[g] = s0;
+            sc.g_rec0[g] = r0;
+        }
     }
-    (void)line;
-    return r;
-}
-
-// line index of the thread's first byte and whether that byte starts a line: from the chunk's line index, the
-// newlines of the threads before it in the chunk, and the byte in front of it
-__device__ __forceinline__ void thread_context(const uint8_t *text, uint64_t n, uint64_t c0, const u32x4 &v,
-                                               unsigned long long chunk_line0, uint32_t *s_wave,
-                                               unsigned long long *line0, bool *starts_line, uint32_t *piece_newlines) {
-    const uint64_t b0 = c0 + (uint64_t)threadIdx.x * kFqBytesPerThread;
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int i = 0; i < (int)kFqBytesPerThread; ++i)
-        if (b0 + i < n && byte_of(v, i) == '\n') ++cnt;
-    uint32_t total;
-    const uint32_t incl = block_inclusive(cnt, s_wave, &total);
-    *piece_newlines = total;
-    *line0 = chunk_line0 + (incl - cnt);
-    *starts_line = b0 == 0 || (b0 < n && text[b0 - 1] == '\n');
-}
-
-__global__ __launch_bounds__(kFqThreads) void fastq_count_kernel(const uint8_t *__restrict__ text, uint64_t n,
-                                                                 const unsigned long long *__restrict__ line_base,
-                                                                 unsigned long long *__restrict__ seq_count,
-                                                                 unsigned long long *__restrict__ rec_count) {
-    __shared__ uint32_t s_wave[kFqThreads / kWave];
-    unsigned long long lines = line_base[blockIdx.x];
-    uint32_t nseq = 0, nrec = 0;
-    for (uint32_t p = 0; p < kFqPieces; ++p) {
-        const uint64_t c0 = (uint64_t)blockIdx.x * kFqChunk + (uint64_t)p * kFqPiece;
-        if (c0 >= n) break;
-        const u32x4 v = load16(text, n, c0, threadIdx.x);
-        unsigned long long line0;
-        bool sl;
-        uint32_t nl;
-        thread_context(text, n, c0, v, lines, s_wave, &line0, &sl, &nl);
-        lines += nl;
-        const FqThread f = classify(v, c0 + (uint64_t)threadIdx.x * kFqBytesPerThread, n, line0, sl);
-        nseq += __popc(f.seq_mask);
-        nrec += __popc(f.start_mask);
-    }
-    uint32_t tot_seq, tot_rec;
-    (void)block_inclusive(nseq, s_wave, &tot_seq);
-    (void)block_inclusive(nrec, s_wave, &tot_rec);
     if (threadIdx.x == 0) {
-        seq_count[blockIdx.x] = tot_seq;
-        rec_count[blockIdx.x] = tot_rec;
+        sc.g_nl[groups] = carry_nl;
+        sc.g_seq0[groups] = carry_seq;
+        sc.g_rec0[groups] = carry_rec;
     }
 }
 
-__global__ __launch_bounds__(kFqThreads) void fastq_pack_kernel(const uint8_t *__restrict__ text, uint64_t n,
-                                                                const unsigned long long *__restrict__ line_base,
-                                                                const unsigned long long *__restrict__ seq_base,
-                                                                const unsigned long long *__restrict__ rec_base_chunk,
+// K2: pack
+__global__ __launch_bounds__(kFqThreads) void fastq_pack_kernel(const uint8_t *__restrict__ text, uint64_t n, const FqScratch sc,
                                                                 uint32_t *__restrict__ out32, uint64_t out_dwords,
                                                                 unsigned long long *__restrict__ rec_base,
                                                                 unsigned long long *__restrict__ rec_pos,
                                                                 uint64_t max_records) {
-    __shared__ uint32_t s_wave[kFqThreads / kWave];
-    unsigned long long lines = line_base[blockIdx.x], seq_run = seq_base[blockIdx.x], rec_run = rec_base_chunk[blockIdx.x];
-    for (uint32_t p = 0; p < kFqPieces; ++p) {
-    const uint64_t c0 = (uint64_t)blockIdx.x * kFqChunk + (uint64_t)p * kFqPiece;
-    if (c0 >= n) break;
-    const uint64_t b0 = c0 + (uint64_t)threadIdx.x * kFqBytesPerThread;
-    const u32x4 v = load16(text, n, c0, threadIdx.x);
-    unsigned long long line0;
-    bool sl;
-    uint32_t nl;
-    thread_context(text, n, c0, v, lines, s_wave, &line0, &sl, &nl);
-    lines += nl;
-    const FqThread f = classify(v, b0, n, line0, sl);
-    uint32_t tot_s, tot_r;
-    const uint32_t nseq = __popc(f.seq_mask), nrec = __popc(f.start_mask);
-    const unsigned long long o0 = seq_run + (block_inclusive(nseq, s_wave, &tot_s) - nseq);   // first output base
-    const unsigned long long r0 = rec_run + (block_inclusive(nrec, s_wave, &tot_r) - nrec);
-    seq_run += tot_s;
-    rec_run += tot_r;
-    // the thread's sequence bytes are consecutive in the output: at most 32 bits over one or two dwords
-    if (nseq) {
-        unsigned long long bits = 0;
-        uint32_t k = 0;
+    __shared__ uint32_t s_part[kFqPieces][kFqWaves];
+    const uint64_t c0 = (uint64_t)blockIdx.x * kFqChunk;
+    const uint64_t grp = blockIdx.x / kFqGroup;
+    const uint32_t gphase = (uint32_t)(sc.g_nl[grp] & 3ull);  // phase the chunk's group starts in
+    const uint32_t phase0 = (gphase + (uint32_t)sc.nl[blockIdx.x]) & 3u;
+    const unsigned long long seq0 = sc.g_seq0[grp] + field32(sc.pre_seq[2ull * blockIdx.x], sc.pre_seq[2ull * blockIdx.x + 1], gphase);
+    const unsigned long long rec0 = sc.g_rec0[grp] + field32(sc.pre_rec[2ull * blockIdx.x], sc.pre_rec[2ull * blockIdx.x + 1], gphase);
+    u32x4 v[kFqPieces];
 #pragma unroll
-        for (int i = 0; i < (int)kFqBytesPerThread; ++i)
-            if ((f.seq_mask >> i) & 1u) {
-                bits |= (unsigned long long)((byte_of(v, i) >> 1) & 3u) << (2u * k);
-                ++k;
-            }
-        const uint64_t q = o0 >> 4;
-        const uint32_t sh = 2u * (uint32_t)(o0 & 15ull);
-        const unsigned long long wide = bits << sh;  // (32 bits shifted by at most 30: fits 64)
-        if (q < out_dwords && (uint32_t)wide) atomicOr(&out32[q], (uint32_t)wide);
-        if (q + 1 < out_dwords && (uint32_t)(wide >> 32)) atomicOr(&out32[q + 1], (uint32_t)(wide >> 32));
+    for (int p = 0; p < (int)kFqPieces; ++p) v[p] = load16(text, n, c0 + (uint64_t)p * kFqPiece, threadIdx.x);
+    FqPiece f[kFqPieces];
+    uint32_t nls[kFqPieces], before[kFqPieces];
+    const bool has_cr = __ballot((any_eq16(v[0], 0x0d0d0d0du) | any_eq16(v[1], 0x0d0d0d0du) | any_eq16(v[2], 0x0d0d0d0du) |
+                                  any_eq16(v[3], 0x0d0d0d0du)) != 0u) != 0ull;
+#pragma unroll
+    for (int p = 0; p < (int)kFqPieces; ++p) {
+        const uint64_t b0 = c0 + (uint64_t)p * kFqPiece + (uint64_t)threadIdx.x * kFqBytesPerThread;
+        f[p] = analyse(v[p], b0, n, starts_line_of(text, n, b0, v[p]), has_cr);
+        nls[p] = __popc(f[p].nl);
     }
-    // record table: a record's first base is the number of sequence bytes in front of its '@'
-    if (nrec) {
-        uint32_t seq_before = 0, k = 0;
+    (void)chunk_exclusive(nls, before, s_part);
+    uint32_t seq_mask[kFqPieces], start_mask[kFqPieces], both[kFqPieces], both_before[kFqPieces];
 #pragma unroll
-        for (int i = 0; i < (int)kFqBytesPerThread; ++i) {
-            if ((f.start_mask >> i) & 1u) {
-                const unsigned long long r = r0 + k;
-                if (r < max_records) {
-                    rec_base[r] = o0 + seq_before;
-                    if (rec_pos) rec_pos[r] = b0 + i;
-                }
-                ++k;
+    for (int p = 0; p < (int)kFqPieces; ++p) {
+        const uint32_t ph = (phase0 + before[p]) & 3u;  // phase of the thread's first byte
+        seq_mask[p] = count_is(f[p], (1u - ph) & 3u) & f[p].valid;
+        start_mask[p] = count_is(f[p], (0u - ph) & 3u) & f[p].valid & f[p].first;
+        both[p] = (uint32_t)__popc(seq_mask[p]) | ((uint32_t)__popc(start_mask[p]) << 16);  // (sums stay below 2^16)
+    }
+    (void)chunk_exclusive(both, both_before, s_part);
+#pragma unroll
+    for (int p = 0; p < (int)kFqPieces; ++p) {
+        const uint64_t b0 = c0 + (uint64_t)p * kFqPiece + (uint64_t)threadIdx.x * kFqBytesPerThread;
+        const unsigned long long o0 = seq0 + (both_before[p] & 0xffffu);  // first output base of the thread's piece
+        const unsigned long long r0 = rec0 + (both_before[p] >> 16);
+        const uint32_t sm = seq_mask[p];
+        // the thread's sequence bytes are consecutive in the output: at most 32 bits over one or two dwords
+        if (sm) {
+            // 2-bit codes of the 16 bytes, byte i at bits 2i (one multiply per dword gathers four codes)
+            auto codes8 = [](uint32_t x) { return (((x >> 1) & 0x03030303u) * 0x01041040u) >> 24; };
+            const uint32_t codes = codes8(v[p].x) | (codes8(v[p].y) << 8) | (codes8(v[p].z) << 16) | (codes8(v[p].w) << 24);
+            const uint32_t first = (uint32_t)__builtin_ctz(sm), run = sm >> first;
+            unsigned long long bits;
+            if ((run & (run + 1u)) == 0u) {  // ONE run of bytes (the rule: a piece of one sequence line)
+                const uint32_t len = (uint32_t)__popc(sm);
+                bits = (codes >> (2u * first)) & (len >= 16u ? 0xffffffffu : ((1u << (2u * len)) - 1u));
+            } else {  // ('\r' inside a line, or reads shorter than a piece)
+                bits = 0;
+                uint32_t k = 0;
+#pragma unroll
+                for (int i = 0; i < (int)kFqBytesPerThread; ++i)
+                    if ((sm >> i) & 1u) {
+                        bits |= (unsigned long long)((codes >> (2 * i)) & 3u) << (2u * k);
+                        ++k;
+                    }
             }
-            if ((f.seq_mask >> i) & 1u) ++seq_before;
+            const uint64_t q = o0 >> 4;
+            const uint32_t sh = 2u * (uint32_t)(o0 & 15ull);
+            const unsigned long long wide = bits << sh;  // (32 bits shifted by at most 30: fits 64)
+            if (q < out_dwords && (uint32_t)wide) atomicOr(&out32[q], (uint32_t)wide);
+            if (q + 1 < out_dwords && (uint32_t)(wide >> 32)) atomicOr(&out32[q + 1], (uint32_t)(wide >> 32));
+        }
+        // record table: a record's first base is the number of sequence bytes in front of its '@'
+        uint32_t st = start_mask[p], k = 0;
+        while (st) {
+            const uint32_t i = (uint32_t)__builtin_ctz(st);
+            st &= st - 1u;
+            const unsigned long long r = r0 + k++;
+            if (r < max_records) {
+                rec_base[r] = o0 + (uint32_t)__popc(sm & ((1u << i) - 1u));
+                if (rec_pos) rec_pos[r] = b0 + i;
+            }
         }
     }
-    }  // pieces
 }
 
-__global__ void fastq_finish_kernel(const unsigned long long *seq_base, const unsigned long long *rec_base_chunk, uint64_t chunks,
-                                    unsigned long long *rec_base, uint64_t max_records, unsigned long long *counts) {
-    const unsigned long long bases = seq_base[chunks], recs = rec_base_chunk[chunks];
+__global__ void fastq_finish_kernel(const FqScratch sc, uint64_t groups, unsigned long long *rec_base, uint64_t max_records,
+                                    unsigned long long *counts) {
+    const unsigned long long bases = sc.g_seq0[groups], recs = sc.g_rec0[groups];
     counts[0] = bases;
     counts[1] = recs;
     if (recs <= max_records) rec_base[recs] = bases;
@@ -303,30 +449,40 @@ __global__ void fastq_finish_kernel(const unsigned long long *seq_base, const un
 
 }  // namespace
 
+static uint64_t fastq_chunks(uint64_t n_bytes) { return (n_bytes + kFqChunk - 1) / kFqChunk; }
+static uint64_t fastq_groups(uint64_t chunks) { return (chunks + kFqGroup - 1) / kFqGroup; }
+
 uint64_t fastq_scratch_bytes(uint64_t n_bytes) {
-    const uint64_t chunks = (n_bytes + kFqChunk - 1) / kFqChunk;
-    return 3 * (chunks + 1) * sizeof(unsigned long long);
+    const uint64_t chunks = fastq_chunks(n_bytes), groups = fastq_groups(chunks);
+    return (7 * chunks + 7 * (groups + 1)) * sizeof(unsigned long long);
 }
 
 int launch_fastq_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed, uint64_t packed_capacity_bytes,
                       unsigned long long *d_rec_base, unsigned long long *d_rec_pos, uint64_t max_records,
                       unsigned long long *d_counts, void *scratch, hipStream_t stream) {
-    const uint64_t chunks = (n_bytes + kFqChunk - 1) / kFqChunk;
+    const uint64_t chunks = fastq_chunks(n_bytes), groups = fastq_groups(chunks);
     if (chunks == 0 || chunks >= (1ull << 31)) return -1;
-    unsigned long long *line_base = static_cast<unsigned long long *>(scratch);
-    unsigned long long *seq_base = line_base + (chunks + 1), *rec_chunk = seq_base + (chunks + 1);
+    unsigned long long *q = static_cast<unsigned long long *>(scratch);
+    FqScratch sc;
+    sc.nl = q, q += chunks;
+    sc.seq = q, q += chunks;
+    sc.rec = q, q += chunks;
+    sc.pre_seq = q, q += 2 * chunks;
+    sc.pre_rec = q, q += 2 * chunks;
+    sc.g_nl = q, q += groups + 1;
+    sc.g_seq = q, q += 2 * (groups + 1);
+    sc.g_rec = q, q += 2 * (groups + 1);
+    sc.g_seq0 = q, q += groups + 1;
+    sc.g_rec0 = q, q += groups + 1;
     const uint64_t out_dwords = packed_capacity_bytes / 4;
     if (out_dwords && hipMemsetAsync(d_packed, 0, out_dwords * 4, stream) != hipSuccess) return -1;
-    hipLaunchKernelGGL(fastq_newlines_kernel, dim3((uint32_t)chunks), dim3(kFqThreads), 0, stream, d_text, n_bytes, line_base);
-    hipLaunchKernelGGL(fastq_scan_kernel, dim3(1), dim3(kFqThreads), 0, stream, line_base, (unsigned long long *)nullptr, chunks);
-    hipLaunchKernelGGL(fastq_count_kernel, dim3((uint32_t)chunks), dim3(kFqThreads), 0, stream, d_text, n_bytes, line_base,
-                       seq_base, rec_chunk);
-    hipLaunchKernelGGL(fastq_scan_kernel, dim3(1), dim3(kFqThreads), 0, stream, seq_base, rec_chunk, chunks);
-    hipLaunchKernelGGL(fastq_pack_kernel, dim3((uint32_t)chunks), dim3(kFqThreads), 0, stream, d_text, n_bytes, line_base,
-                       seq_base, rec_chunk, reinterpret_cast<uint32_t *>(d_packed), out_dwords, d_rec_base, d_rec_pos,
-                       max_records);
-    hipLaunchKernelGGL(fastq_finish_kernel, dim3(1), dim3(1), 0, stream, seq_base, rec_chunk, chunks, d_rec_base, max_records,
-                       d_counts);
+    hipLaunchKernelGGL(fastq_count_kernel, dim3((uint32_t)chunks), dim3(kFqThreads), 0, stream, d_text, n_bytes, sc.nl, sc.seq,
+                       sc.rec);
+    hipLaunchKernelGGL(fastq_groups_kernel, dim3((uint32_t)groups), dim3(kFqGroup), 0, stream, sc, chunks);
+    hipLaunchKernelGGL(fastq_resolve_kernel, dim3(1), dim3(kFqGroup), 0, stream, sc, groups);
+    hipLaunchKernelGGL(fastq_pack_kernel, dim3((uint32_t)chunks), dim3(kFqThreads), 0, stream, d_text, n_bytes, sc,
+                       reinterpret_cast<uint32_t *>(d_packed), out_dwords, d_rec_base, d_rec_pos, max_records);
+    hipLaunchKernelGGL(fastq_finish_kernel, dim3(1), dim3(1), 0, stream, sc, groups, d_rec_base, max_records, d_counts);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -184,7 +184,9 @@ def component(tag, cfg):
     lines = []
     db = rocprof(f"{tag}_{cfg}_stats", None, ["python3", "tools/run_config.py", cfg, "5", "3"])
     lines.append(f"== rocprofv3 --kernel-trace --stats -- python3 tools/run_config.py {cfg} 5 3\n")
-    for r in top_kernels(db)[:8]:
+    rows = top_kernels(db)
+    mine = [r for r in rows if any(l in r[0] for l in likes) or "fillBuffer" in r[0]]  # (the row's own kernels first;
+    for r in mine + [r for r in rows if r not in mine][:4]:                            # the rest is input generation)
         lines.append(f"{r[0][:90]:90s} calls={r[1]:4d} total_us={r[2]:12.1f} avg_us={r[3]:10.2f} pct={r[4]:5.1f}\n")
     try:
         log = open(os.path.join(OUT, f"{tag}_{cfg}_stats.log")).read().strip().split("\n")
