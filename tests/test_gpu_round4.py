@@ -501,6 +501,8 @@ def test_fastq_packer(sm, oracle, gpu):
     _check_fastq(sm, oracle, b"@r1 x\nACGT\n+\nIIII\n@r2\r\nTTGA\r\n+r2\r\nIIII\r\n@r3\n\n+\n\n@r4\nAC")
     _check_fastq(sm, oracle, b"@a\nAC\n+\nII\n\n\n")
     _check_fastq(sm, oracle, b"\n  @a\nACGTTTGA\n+\nIIIIIIII\n"[1:].lstrip())
+    # several runs of sequence bytes inside one thread's 16 bytes: a stray '\r' inside a line, records of eight bytes
+    _check_fastq(sm, oracle, b"@a\nAC\rGT\r\r\n+\nIIII\n" + b"@\nA\n+\n!\n@\nC\n+\n!\n" * 40 + b"@z\nGATTACA\n+\n!!!!!!!\n")
     acgt = np.frombuffer(b"ACGTNacgt", dtype=np.uint8)
 
     def make(n_reads, lens, crlf=False, final_newline=True):
@@ -517,6 +519,8 @@ def test_fastq_packer(sm, oracle, gpu):
                                        (300, 150, 151, True, True), (40, 3000, 9000, False, True), (3000, 0, 40, True, False)):
         text = make(n_reads, rng.integers(lo, hi, n_reads), crlf, fin)
         _check_fastq(sm, oracle, text)
+    # more than one GROUP of 256 chunks (4 MB of text: the resolve step's two levels)
+    _check_fastq(sm, oracle, make(27_000, rng.integers(140, 151, 27_000)), max_records=1 << 15)
     # lengths of the text around the chunk size, and an unaligned device pointer
     base = make(400, rng.integers(90, 151, 400))  # about 120 KB of text
     for cut in (4095, 4096, 4097, 8191, 8192, 12289, 16383, 16384, 16385, 32769, 65535, 65537):
@@ -555,6 +559,48 @@ def test_fastq_packer(sm, oracle, gpu):
         seq_packed = oracle.pack_ascii(want2[r][2])
         w_r = oracle.run(np.concatenate([seq_packed, np.zeros(16, dtype=np.uint8)]), len(want2[r][2]), 21, 11, canonical=True)
         assert np.array_equal(flat2[offs2[r]: offs2[r + 1]], w_r), r
+
+
+def test_fastq_packer_large(sm, gpu):
+    """More than 1 GiB of FASTQ text (more than 256 groups of 256 chunks: the second round of the resolve step's single
+    workgroup), records of one shape, checked on the device: counts, every record's first base and byte offset, and the
+    packed bases against mm_pack_ascii of the text's sequence bytes."""
+    import ctypes as C
+
+    import torch
+    dev = torch.device("cuda:0")
+    rl, name_len = 150, 19
+    rec_bytes = (1 + name_len + 1) + (rl + 1) + 2 + (rl + 1)
+    n_rec = int(1.1 * (1 << 30)) // rec_bytes
+    n = n_rec * rec_bytes
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    t = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (n,), device=dev, generator=g)]
+    t = t.view(n_rec, rec_bytes)
+    t[:, 0] = ord("@")
+    for p in (name_len + 1, name_len + 2 + rl, name_len + 2 + rl + 2, rec_bytes - 1):
+        t[:, p] = 10
+    t[:, name_len + 2 + rl + 1] = ord("+")
+    seq_bytes = t[:, name_len + 2: name_len + 2 + rl].contiguous().view(-1)
+    t = t.view(-1)
+    ws = sm.default_workspace(0)
+    L = sm.lib()
+    packed = torch.empty(n_rec * rl // 4 + 64, dtype=torch.uint8, device=dev)
+    rb = torch.zeros(n_rec + 1, dtype=torch.int64, device=dev)
+    rp = torch.zeros(n_rec, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    sm._check(L.mm_fastq_pack_device_async(ws.h, C.c_void_p(t.data_ptr()), n, C.c_void_p(packed.data_ptr()),
+                                           packed.numel() // 4 * 4, C.c_void_p(rb.data_ptr()), C.c_void_p(rp.data_ptr()),
+                                           n_rec, C.c_void_p(cnt.data_ptr())))
+    ws.sync()
+    ws.check()
+    assert [int(x) for x in cnt.cpu()] == [n_rec * rl, n_rec]
+    idx = torch.arange(n_rec + 1, device=dev, dtype=torch.int64)
+    assert bool((rb == idx * rl).all()) and bool((rp == idx[:-1] * rec_bytes).all())
+    want = torch.empty((n_rec * rl + 3) // 4, dtype=torch.uint8, device=dev)
+    sm._check(L.mm_pack_ascii_device_async(ws.h, C.c_void_p(seq_bytes.data_ptr()), n_rec * rl, C.c_void_p(want.data_ptr())))
+    ws.sync()
+    assert bool((packed[: want.numel()] == want).all())
 
 
 def test_device_resident_batches(sm, oracle, gpu):

@@ -149,8 +149,9 @@ def config(tag, cfg):
     open(os.path.join(OUT, f"{tag}_{cfg}.txt"), "w").writelines(lines)
 
 
-def stalls(tag, cfg):
-    """What the waves of a configuration's fused kernel wait for: SQ wait / active counters, separate passes."""
+def stalls(tag, cfg, like="fused_kernel"):
+    """What the waves of a configuration's kernel (default: the fused kernel) wait for: SQ wait / active counters,
+    separate passes.  stalls:<CFG>[:<kernel name part>]"""
     cmd = ["python3", "tools/run_config.py", cfg, "3", "2"]
     passes = {"w1": ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS",
                      "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"],
@@ -160,17 +161,17 @@ def stalls(tag, cfg):
                      "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INST_LEVEL_VMEM"],
               "w4": ["TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA_RDREQ_sum",
                      "TCP_PENDING_STALL_CYCLES_sum"]}
-    lines = [f"== SQ / cache counters of the fused kernel, python3 tools/run_config.py {cfg} 3 2, one group per pass\n"]
+    lines = [f"== SQ / cache counters of {like}, python3 tools/run_config.py {cfg} 3 2, one group per pass\n"]
     for name, pmc in passes.items():
         db = rocprof(f"{tag}_{cfg}_{name}", pmc, cmd)
         if not db:
             lines.append(f"({name}: no database; see {tag}_{cfg}_{name}.log)\n")
             continue
-        cs, meta = counters(db)
+        cs, meta = counters(db, like)
         lines.append(f"-- pass {name} ({meta})\n")
         for c, (v, dur, cnt) in sorted(cs.items()):
             lines.append(f"{c:30s} n={cnt} mean={v:.6g} kernel_us={dur:.1f}\n")
-    open(os.path.join(OUT, f"{tag}_{cfg}_stalls.txt"), "w").writelines(lines)
+    open(os.path.join(OUT, f"{tag}_{cfg}_stalls" + ("" if like == "fused_kernel" else "_" + like) + ".txt"), "w").writelines(lines)
 
 
 def component(tag, cfg):
@@ -230,7 +231,7 @@ if __name__ == "__main__":
         if what == "headline":
             headline(tag)
         elif what.startswith("stalls:"):
-            stalls(tag, what[7:])
+            stalls(tag, *what[7:].split(":"))
         elif what in ("READS", "READS_SK", "SKIP", "VALUES", "PACK", "FASTA", "FASTQ"):
             component(tag, what)
         else:
