@@ -15,7 +15,7 @@
 // All records go back to back into ONE 2-bit buffer, record r = bases [rec_base[r], rec_base[r + 1]) - the layout of
 // the FASTA packer, i.e. what mm_run_batch_device takes, and with a fixed read length what mm_run_reads_device takes.
 //
-// TWO passes over the text (16 KB per workgroup = four 4 KB pieces, 16 bytes per thread and piece, all four pieces of a
+// TWO passes over the text (16 KB per workgroup = two 8 KB pieces, 32 bytes per thread and piece, both pieces of a
 // thread in registers) with one small resolve step between them:
 //   K1  per chunk: its '\n' bytes, and - for EACH of the four line phases the chunk may start in (line index mod 4) -
 //       its sequence bytes (bytes of lines 4r + 1 that are not '\n' / '\r') and record starts (first bytes of lines
@@ -24,12 +24,14 @@
 //   R   (two tiny kernels, see fastq_groups_kernel) exclusive sum of the newline counts = the phase every chunk starts
 //       in, which selects the field; exclusive sums of the selected counts = every chunk's first output base and first
 //       record.
-//   K2  every thread packs its (at most 16) sequence bytes per piece - one run, consecutive in the output - and ORs one
-//       or two dwords into the cleared output; the first byte of a line 4r writes the record's table entries.
-// Per 16-byte piece of a thread everything is bit arithmetic on 16-bit masks (round 4, second version; the first one
+//   K2  every thread packs its (at most 32) sequence bytes per piece - one run, consecutive in the output - and ORs up
+//       to three dwords into the cleared output; the first byte of a line 4r writes the record's table entries.
+// Per 32-byte piece of a thread everything is bit arithmetic on 32-bit masks (round 4, second version; the first one
 // walked the bytes one by one in three passes and ran at 0.44 TB/s of text): byte-equality masks by SWAR, the number of
 // newlines before every byte mod 4 from two prefix-XORs (low bit: parity of the newlines; high bit: parity of the
-// newlines that arrive on an odd count), the 2-bit codes of 16 bytes by one multiply per dword.
+// newlines that arrive on an odd count), the 2-bit codes of four bytes by one multiply per dword.  Both kernels are
+// VALU-bound (SQ_INSTS_VALU x issue rate = kernel time, profiles/r04_e_FASTQ_stalls_*.txt): 32 bytes per thread instead
+// of 16 halved the per-thread part (sums over the workgroup, the phase variants, address arithmetic).
 #include "mm_common.h"
 #include "mm_launch.h"
 
@@ -38,40 +40,47 @@ namespace mm {
 namespace {
 
 constexpr uint32_t kFqThreads = 256;
-constexpr uint32_t kFqBytesPerThread = 16;
-constexpr uint32_t kFqPiece = kFqThreads * kFqBytesPerThread;   // 4 KB of text per piece of a workgroup
-constexpr uint32_t kFqPieces = 4;                               // pieces per workgroup
-constexpr uint32_t kFqChunk = kFqPiece * kFqPieces;             // 16 KB of text per workgroup (one entry of the scans)
+constexpr uint32_t kFqBytesPerThread = 32;
+constexpr uint32_t kFqPiece = kFqThreads * kFqBytesPerThread;   // 8 KB of text per piece of a workgroup
+constexpr uint32_t kFqPieces = 2;                               // pieces per workgroup
+constexpr uint32_t kFqChunk = kFqPiece * kFqPieces;             // 16 KB of text per workgroup (one entry of the sums)
 constexpr int kFqWaves = (int)(kFqThreads / kWave);
-static_assert(kFqPieces == 4, "the '\\r' test and the piece-major sums below are written for four pieces");
+static_assert(kFqPieces == 2 && kFqBytesPerThread == 32, "masks are 32 bits, the '\\r' test is written for two pieces");
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct Text32 {
+    uint32_t d[8];  // the thread's 32 text bytes of a piece, little-endian dwords
+};
 
-// the thread's 16 text bytes (zeros past the end of the text), from a bounds-checked view of the piece
-__device__ __forceinline__ u32x4 load16(const uint8_t *text, uint64_t n, uint64_t c0, uint32_t t) {
-    if (c0 >= n) return u32x4{0u, 0u, 0u, 0u};
+// the thread's 32 text bytes (zeros past the end of the text), from a bounds-checked view of the piece that starts at
+// byte c0 of the text
+__device__ __forceinline__ Text32 load32(const uint8_t *text, uint64_t n, uint64_t c0, uint32_t t) {
+    Text32 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.d[i] = 0u;
+    if (c0 >= n) return r;
     const uint64_t left = n - c0;
     const uint32_t here = left < kFqPiece ? (uint32_t)left : kFqPiece;
     // (the text pointer may have any alignment: the view starts at the dword that holds byte c0)
     const uintptr_t a = reinterpret_cast<uintptr_t>(text + c0);
     const uint32_t sh = (uint32_t)(a & 3u);
-    const __amdgpu_buffer_rsrc_t r =
+    const __amdgpu_buffer_rsrc_t rs =
         // (whole dwords: the bounds check drops a dword that is only partly inside, and the text's last dword may be)
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint32_t *>(a - sh), 0, (int)((here + sh + 3u) & ~3u), 0x00020000);
-    const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(r, t * 16u, 0, 0);
-    if (sh == 0) return lo;
-    const uint32_t nx = __builtin_amdgcn_raw_buffer_load_b32(r, t * 16u + 16u, 0, 0);
-    u32x4 v;
-    v.x = __builtin_amdgcn_alignbyte(lo.y, lo.x, sh);
-    v.y = __builtin_amdgcn_alignbyte(lo.z, lo.y, sh);
-    v.z = __builtin_amdgcn_alignbyte(lo.w, lo.z, sh);
-    v.w = __builtin_amdgcn_alignbyte(nx, lo.w, sh);
-    return v;
+    const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rs, t * 32u, 0, 0);
+    const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rs, t * 32u, 16, 0);
+    uint32_t w[9] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, 0u};
+    if (sh == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.d[i] = w[i];
+        return r;
+    }
+    w[8] = __builtin_amdgcn_raw_buffer_load_b32(rs, t * 32u, 32, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.d[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
+    return r;
 }
-__device__ __forceinline__ uint32_t byte_of(const u32x4 &v, int i) {
-    const uint32_t w = i < 4 ? v.x : i < 8 ? v.y : i < 12 ? v.z : v.w;
-    return (w >> (8 * (i & 3))) & 0xffu;
-}
+__device__ __forceinline__ uint32_t byte_of(const Text32 &v, int i) { return (v.d[i >> 2] >> (8 * (i & 3))) & 0xffu; }
 
 // 4-bit mask of the bytes of x that equal the byte replicated in pat (exact zero-byte test, then the four flag bits
 // at 7 / 15 / 23 / 31 gathered by one multiply: the partial products do not overlap)
@@ -79,18 +88,23 @@ __device__ __forceinline__ uint32_t eq4(uint32_t x, uint32_t pat) {
     const uint32_t z = x ^ pat;
     const uint32_t t = (z & 0x7f7f7f7fu) + 0x7f7f7f7fu;
     const uint32_t m = ~(t | z | 0x7f7f7f7fu);
-    return ((m >> 7) * 0x10204080u) >> 28;
+    return (m * 0x00204081u) >> 28;
 }
-__device__ __forceinline__ uint32_t eq16(const u32x4 &v, uint32_t pat) {
-    return eq4(v.x, pat) | (eq4(v.y, pat) << 4) | (eq4(v.z, pat) << 8) | (eq4(v.w, pat) << 12);
+__device__ __forceinline__ uint32_t eq32(const Text32 &v, uint32_t pat) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m |= eq4(v.d[i], pat) << (4 * i);
+    return m;
 }
-// does any byte of x equal the byte replicated in pat?  (three operations; exact as a yes / no)
-__device__ __forceinline__ uint32_t any_eq4(uint32_t x, uint32_t pat) {
-    const uint32_t z = x ^ pat;
-    return (z - 0x01010101u) & ~z & 0x80808080u;
-}
-__device__ __forceinline__ uint32_t any_eq16(const u32x4 &v, uint32_t pat) {
-    return any_eq4(v.x, pat) | any_eq4(v.y, pat) | any_eq4(v.z, pat) | any_eq4(v.w, pat);
+// does any byte equal the byte replicated in pat?  (three operations per dword; exact as a yes / no)
+__device__ __forceinline__ uint32_t any_eq32(const Text32 &v, uint32_t pat) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t z = v.d[i] ^ pat;
+        m |= (z - 0x01010101u) & ~z & 0x80808080u;
+    }
+    return m;
 }
 // inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (also of packed 16-bit fields whose
 // sums stay below 2^16)
@@ -103,16 +117,17 @@ __device__ __forceinline__ uint32_t fq_wave_scan(uint32_t v) {
     v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
     return v;
 }
-// inclusive prefix XOR of a 16-bit mask
-__device__ __forceinline__ uint32_t pxor16(uint32_t x) {
+// inclusive prefix XOR of a 32-bit mask
+__device__ __forceinline__ uint32_t pxor32(uint32_t x) {
     x ^= x << 1;
     x ^= x << 2;
     x ^= x << 4;
     x ^= x << 8;
-    return x & 0xffffu;
+    x ^= x << 16;
+    return x;
 }
 
-// What the 16 bytes of a thread are, as 16-bit masks (bit i = byte i), whatever line the first byte lies in:
+// What the 32 bytes of a thread are, as 32-bit masks (bit i = byte i), whatever line the first byte lies in:
 //   nl     '\n' bytes (inside the text)
 //   valid  bytes inside the text that are neither '\n' nor '\r'
 //   lo, hi the number of newlines among the bytes in front of byte i, mod 4 (bit 0 / bit 1)
@@ -120,28 +135,30 @@ __device__ __forceinline__ uint32_t pxor16(uint32_t x) {
 struct FqPiece {
     uint32_t nl, valid, lo, hi, first;
 };
-// (has_cr: wave-uniform, does any thread of the wave hold a '\r' in any of its pieces - most texts have none)
-__device__ __forceinline__ FqPiece analyse(const u32x4 &v, uint64_t b0, uint64_t n, bool starts_line, bool has_cr) {
+// (rel: the thread's first byte of the piece, from the chunk's first byte; left: text bytes from the chunk's first byte
+// on, capped at 2^31; has_cr: wave-uniform, does any thread of the wave hold a '\r' - most texts have none)
+__device__ __forceinline__ FqPiece analyse(const Text32 &v, uint32_t rel, uint32_t left, bool starts_line, bool has_cr) {
     FqPiece f;
-    const uint32_t inside = b0 >= n ? 0u : (n - b0 >= 16u ? 0xffffu : ((1u << (uint32_t)(n - b0)) - 1u));
-    f.nl = eq16(v, 0x0a0a0a0au) & inside;
-    const uint32_t cr = has_cr ? eq16(v, 0x0d0d0d0du) : 0u;
+    const uint32_t nin = rel >= left ? 0u : (left - rel >= 32u ? 32u : left - rel);
+    const uint32_t inside = nin >= 32u ? 0xffffffffu : ((1u << nin) - 1u);
+    f.nl = eq32(v, 0x0a0a0a0au) & inside;
+    const uint32_t cr = has_cr ? eq32(v, 0x0d0d0d0du) : 0u;
     f.valid = inside & ~f.nl & ~cr;
-    f.lo = (pxor16(f.nl) << 1) & 0xffffu;
-    f.hi = (pxor16(f.nl & f.lo) << 1) & 0xffffu;  // (the count's bit 1 flips where a newline arrives on an odd count)
-    f.first = ((f.nl << 1) | (starts_line ? 1u : 0u)) & 0xffffu;
+    f.lo = pxor32(f.nl) << 1;
+    f.hi = pxor32(f.nl & f.lo) << 1;  // (the count's bit 1 flips where a newline arrives on an odd count)
+    f.first = (f.nl << 1) | (starts_line ? 1u : 0u);
     return f;
 }
 // the bytes in front of which the newline count of the piece is t mod 4
 __device__ __forceinline__ uint32_t count_is(const FqPiece &f, uint32_t t) {
-    return (f.lo ^ ((t & 1u) ? 0u : 0xffffu)) & (f.hi ^ ((t & 2u) ? 0u : 0xffffu));
+    return (f.lo ^ ((t & 1u) ? 0u : 0xffffffffu)) & (f.hi ^ ((t & 2u) ? 0u : 0xffffffffu));
 }
 
 // does the thread's first byte of this piece start a line?  The byte in front of it is the last byte of the lane before
-// (one DPP-style shuffle); lane 0 of a wave reads it from memory.
-__device__ __forceinline__ bool starts_line_of(const uint8_t *text, uint64_t n, uint64_t b0, const u32x4 &v) {
+// (one shuffle); lane 0 of a wave reads it from memory.
+__device__ __forceinline__ bool starts_line_of(const uint8_t *text, uint64_t n, uint64_t b0, const Text32 &v) {
     const int lane = threadIdx.x & (kWave - 1);
-    uint32_t prev = __shfl_up(v.w >> 24, 1, kWave);
+    uint32_t prev = __shfl_up(v.d[7] >> 24, 1, kWave);
     if (lane == 0) prev = (b0 > 0 && b0 <= n) ? text[b0 - 1] : (uint32_t)'\n';
     return b0 == 0 || (b0 < n && prev == (uint32_t)'\n');
 }
@@ -185,6 +202,28 @@ __device__ __forceinline__ unsigned long long widen_fields(uint32_t x) {
            ((unsigned long long)(x & 0xff000000u) << 24);
 }
 
+// what both kernels start with: the chunk's text, its masks, the newlines in front of every piece of every thread
+struct FqChunk {
+    Text32 v[kFqPieces];
+    FqPiece f[kFqPieces];
+    uint32_t before[kFqPieces];  // newlines of the chunk in front of the thread's piece
+    uint32_t total_nl;
+};
+__device__ __forceinline__ void read_chunk(const uint8_t *text, uint64_t n, uint64_t c0, uint32_t (*s_part)[kFqWaves], FqChunk &c) {
+#pragma unroll
+    for (int p = 0; p < (int)kFqPieces; ++p) c.v[p] = load32(text, n, c0 + (uint64_t)p * kFqPiece, threadIdx.x);
+    const uint32_t left = n - c0 > 0x7fffffffull ? 0x7fffffffu : (uint32_t)(n - c0);
+    const bool has_cr = __ballot((any_eq32(c.v[0], 0x0d0d0d0du) | any_eq32(c.v[1], 0x0d0d0d0du)) != 0u) != 0ull;
+    uint32_t nls[kFqPieces];
+#pragma unroll
+    for (int p = 0; p < (int)kFqPieces; ++p) {
+        const uint32_t rel = (uint32_t)p * kFqPiece + threadIdx.x * kFqBytesPerThread;
+        c.f[p] = analyse(c.v[p], rel, left, starts_line_of(text, n, c0 + rel, c.v[p]), has_cr);
+        nls[p] = (uint32_t)__popc(c.f[p].nl);
+    }
+    c.total_nl = chunk_exclusive(nls, c.before, s_part);
+}
+
 // K1: per chunk the newlines, and sequence bytes / record starts for each of the four phases it may start in
 __global__ __launch_bounds__(kFqThreads) void fastq_count_kernel(const uint8_t *__restrict__ text, uint64_t n,
                                                                  unsigned long long *__restrict__ nl_count,
@@ -193,21 +232,8 @@ __global__ __launch_bounds__(kFqThreads) void fastq_count_kernel(const uint8_t *
     __shared__ uint32_t s_part[kFqPieces][kFqWaves];
     __shared__ unsigned long long s_red[2][kFqWaves];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const uint64_t c0 = (uint64_t)blockIdx.x * kFqChunk;
-    u32x4 v[kFqPieces];
-#pragma unroll
-    for (int p = 0; p < (int)kFqPieces; ++p) v[p] = load16(text, n, c0 + (uint64_t)p * kFqPiece, threadIdx.x);
-    FqPiece f[kFqPieces];
-    uint32_t nls[kFqPieces], before[kFqPieces];
-    const bool has_cr = __ballot((any_eq16(v[0], 0x0d0d0d0du) | any_eq16(v[1], 0x0d0d0d0du) | any_eq16(v[2], 0x0d0d0d0du) |
-                                  any_eq16(v[3], 0x0d0d0d0du)) != 0u) != 0ull;
-#pragma unroll
-    for (int p = 0; p < (int)kFqPieces; ++p) {
-        const uint64_t b0 = c0 + (uint64_t)p * kFqPiece + (uint64_t)threadIdx.x * kFqBytesPerThread;
-        f[p] = analyse(v[p], b0, n, starts_line_of(text, n, b0, v[p]), has_cr);
-        nls[p] = __popc(f[p].nl);
-    }
-    const uint32_t total_nl = chunk_exclusive(nls, before, s_part);
+    FqChunk c;
+    read_chunk(text, n, (uint64_t)blockIdx.x * kFqChunk, s_part, c);
     // Field s (chunk starts in phase s): this thread's byte i is a sequence byte iff s + before + count(i) == 1 mod 4.
     // P[j] = bytes whose own count is j; the answer for s is P[(1 - before - s) & 3]: the counts in the order
     // P[0], P[3], P[2], P[1], rotated up by (1 - before) & 3 fields.  Record starts: the same with 0 for 1.
@@ -217,13 +243,13 @@ __global__ __launch_bounds__(kFqThreads) void fastq_count_kernel(const uint8_t *
         uint32_t ps = 0, pr = 0;
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
-            const uint32_t m = count_is(f[p], j) & f[p].valid;
+            const uint32_t m = count_is(c.f[p], j) & c.f[p].valid;
             const uint32_t field = 8u * ((4u - j) & 3u);
             ps |= (uint32_t)__popc(m) << field;
-            pr |= (uint32_t)__popc(m & f[p].first) << field;
+            pr |= (uint32_t)__popc(m & c.f[p].first) << field;
         }
-        seq8 += rot_fields(ps, (1u - before[p]) & 3u);  // (a field stays below 4 x 16 = 64)
-        rec8 += rot_fields(pr, (0u - before[p]) & 3u);
+        seq8 += rot_fields(ps, (1u - c.before[p]) & 3u);  // (a field stays below 2 x 32 = 64)
+        rec8 += rot_fields(pr, (0u - c.before[p]) & 3u);
     }
     unsigned long long a = widen_fields(seq8), b = widen_fields(rec8);
 #pragma unroll
@@ -243,7 +269,7 @@ __global__ __launch_bounds__(kFqThreads) void fastq_count_kernel(const uint8_t *
             ta += s_red[0][w];
             tb += s_red[1][w];
         }
-        nl_count[blockIdx.x] = total_nl;
+        nl_count[blockIdx.x] = c.total_nl;
         seq_by_phase[blockIdx.x] = ta;  // (a field is at most 16 384: no carry between fields)
         rec_by_phase[blockIdx.x] = tb;
     }
@@ -364,66 +390,67 @@ __global__ __launch_bounds__(kFqThreads) void fastq_pack_kernel(const uint8_t *_
                                                                 unsigned long long *__restrict__ rec_pos,
                                                                 uint64_t max_records) {
     __shared__ uint32_t s_part[kFqPieces][kFqWaves];
+    // The chunk's output is assembled in LDS (at most 16 384 bases = 1024 dwords, + 1 for its bit offset, + 2 for the
+    // last thread's three-dword OR) and leaves as whole dwords; only the first and the last dword, which the chunk
+    // shares with its neighbours, are OR-ed into the cleared output.  (Every thread OR-ing its bits straight into
+    // global memory, three atomics per thread and piece, took the same time - the kernel is VALU-bound - but wrote
+    // 473 MB per GiB of text where this writes 190.)
+    constexpr uint32_t kOutDwords = kFqChunk / 16u + 4u;
+    __shared__ uint32_t s_out[kOutDwords];
+    for (uint32_t i = threadIdx.x; i < kOutDwords; i += kFqThreads) s_out[i] = 0u;  // (ordered by read_chunk's barriers)
     const uint64_t c0 = (uint64_t)blockIdx.x * kFqChunk;
     const uint64_t grp = blockIdx.x / kFqGroup;
     const uint32_t gphase = (uint32_t)(sc.g_nl[grp] & 3ull);  // phase the chunk's group starts in
     const uint32_t phase0 = (gphase + (uint32_t)sc.nl[blockIdx.x]) & 3u;
     const unsigned long long seq0 = sc.g_seq0[grp] + field32(sc.pre_seq[2ull * blockIdx.x], sc.pre_seq[2ull * blockIdx.x + 1], gphase);
     const unsigned long long rec0 = sc.g_rec0[grp] + field32(sc.pre_rec[2ull * blockIdx.x], sc.pre_rec[2ull * blockIdx.x + 1], gphase);
-    u32x4 v[kFqPieces];
-#pragma unroll
-    for (int p = 0; p < (int)kFqPieces; ++p) v[p] = load16(text, n, c0 + (uint64_t)p * kFqPiece, threadIdx.x);
-    FqPiece f[kFqPieces];
-    uint32_t nls[kFqPieces], before[kFqPieces];
-    const bool has_cr = __ballot((any_eq16(v[0], 0x0d0d0d0du) | any_eq16(v[1], 0x0d0d0d0du) | any_eq16(v[2], 0x0d0d0d0du) |
-                                  any_eq16(v[3], 0x0d0d0d0du)) != 0u) != 0ull;
-#pragma unroll
-    for (int p = 0; p < (int)kFqPieces; ++p) {
-        const uint64_t b0 = c0 + (uint64_t)p * kFqPiece + (uint64_t)threadIdx.x * kFqBytesPerThread;
-        f[p] = analyse(v[p], b0, n, starts_line_of(text, n, b0, v[p]), has_cr);
-        nls[p] = __popc(f[p].nl);
-    }
-    (void)chunk_exclusive(nls, before, s_part);
+    FqChunk c;
+    read_chunk(text, n, c0, s_part, c);
     uint32_t seq_mask[kFqPieces], start_mask[kFqPieces], both[kFqPieces], both_before[kFqPieces];
 #pragma unroll
     for (int p = 0; p < (int)kFqPieces; ++p) {
-        const uint32_t ph = (phase0 + before[p]) & 3u;  // phase of the thread's first byte
-        seq_mask[p] = count_is(f[p], (1u - ph) & 3u) & f[p].valid;
-        start_mask[p] = count_is(f[p], (0u - ph) & 3u) & f[p].valid & f[p].first;
+        const uint32_t ph = (phase0 + c.before[p]) & 3u;  // phase of the thread's first byte
+        seq_mask[p] = count_is(c.f[p], (1u - ph) & 3u) & c.f[p].valid;
+        start_mask[p] = count_is(c.f[p], (0u - ph) & 3u) & c.f[p].valid & c.f[p].first;
         both[p] = (uint32_t)__popc(seq_mask[p]) | ((uint32_t)__popc(start_mask[p]) << 16);  // (sums stay below 2^16)
     }
-    (void)chunk_exclusive(both, both_before, s_part);
+    const uint32_t chunk_seq = chunk_exclusive(both, both_before, s_part) & 0xffffu;  // sequence bytes of the chunk
+    const uint64_t q0 = seq0 >> 4;  // the chunk's first output dword
 #pragma unroll
     for (int p = 0; p < (int)kFqPieces; ++p) {
-        const uint64_t b0 = c0 + (uint64_t)p * kFqPiece + (uint64_t)threadIdx.x * kFqBytesPerThread;
         const unsigned long long o0 = seq0 + (both_before[p] & 0xffffu);  // first output base of the thread's piece
         const unsigned long long r0 = rec0 + (both_before[p] >> 16);
         const uint32_t sm = seq_mask[p];
-        // the thread's sequence bytes are consecutive in the output: at most 32 bits over one or two dwords
+        // the thread's sequence bytes are consecutive in the output: at most 64 bits over up to three dwords
         if (sm) {
-            // 2-bit codes of the 16 bytes, byte i at bits 2i (one multiply per dword gathers four codes)
+            // 2-bit codes of the 32 bytes, byte i at bits 2i (one multiply per dword gathers four codes)
             auto codes8 = [](uint32_t x) { return (((x >> 1) & 0x03030303u) * 0x01041040u) >> 24; };
-            const uint32_t codes = codes8(v[p].x) | (codes8(v[p].y) << 8) | (codes8(v[p].z) << 16) | (codes8(v[p].w) << 24);
+            const Text32 &v = c.v[p];
+            const uint32_t clo = codes8(v.d[0]) | (codes8(v.d[1]) << 8) | (codes8(v.d[2]) << 16) | (codes8(v.d[3]) << 24);
+            const uint32_t chi = codes8(v.d[4]) | (codes8(v.d[5]) << 8) | (codes8(v.d[6]) << 16) | (codes8(v.d[7]) << 24);
+            const unsigned long long codes = (unsigned long long)clo | ((unsigned long long)chi << 32);
             const uint32_t first = (uint32_t)__builtin_ctz(sm), run = sm >> first;
             unsigned long long bits;
             if ((run & (run + 1u)) == 0u) {  // ONE run of bytes (the rule: a piece of one sequence line)
                 const uint32_t len = (uint32_t)__popc(sm);
-                bits = (codes >> (2u * first)) & (len >= 16u ? 0xffffffffu : ((1u << (2u * len)) - 1u));
+                bits = (codes >> (2u * first)) & (len >= 32u ? ~0ull : ((1ull << (2u * len)) - 1ull));
             } else {  // ('\r' inside a line, or reads shorter than a piece)
                 bits = 0;
                 uint32_t k = 0;
 #pragma unroll
                 for (int i = 0; i < (int)kFqBytesPerThread; ++i)
                     if ((sm >> i) & 1u) {
-                        bits |= (unsigned long long)((codes >> (2 * i)) & 3u) << (2u * k);
+                        bits |= ((codes >> (2 * i)) & 3ull) << (2u * k);
                         ++k;
                     }
             }
-            const uint64_t q = o0 >> 4;
+            const uint32_t q = (uint32_t)((o0 >> 4) - q0);
             const uint32_t sh = 2u * (uint32_t)(o0 & 15ull);
-            const unsigned long long wide = bits << sh;  // (32 bits shifted by at most 30: fits 64)
-            if (q < out_dwords && (uint32_t)wide) atomicOr(&out32[q], (uint32_t)wide);
-            if (q + 1 < out_dwords && (uint32_t)(wide >> 32)) atomicOr(&out32[q + 1], (uint32_t)(wide >> 32));
+            const unsigned long long lo = bits << sh;                              // (64 bits shifted by at most 30:
+            const uint32_t top = sh ? (uint32_t)(bits >> (64u - sh)) : 0u;         //  96 bits over three dwords)
+            if ((uint32_t)lo) atomicOr(&s_out[q], (uint32_t)lo);
+            if ((uint32_t)(lo >> 32)) atomicOr(&s_out[q + 1], (uint32_t)(lo >> 32));
+            if (top) atomicOr(&s_out[q + 2], top);
         }
         // record table: a record's first base is the number of sequence bytes in front of its '@'
         uint32_t st = start_mask[p], k = 0;
@@ -433,9 +460,18 @@ __global__ __launch_bounds__(kFqThreads) void fastq_pack_kernel(const uint8_t *_
             const unsigned long long r = r0 + k++;
             if (r < max_records) {
                 rec_base[r] = o0 + (uint32_t)__popc(sm & ((1u << i) - 1u));
-                if (rec_pos) rec_pos[r] = b0 + i;
+                if (rec_pos) rec_pos[r] = c0 + (uint64_t)p * kFqPiece + (uint64_t)threadIdx.x * kFqBytesPerThread + i;
             }
         }
+    }
+    __syncthreads();
+    const uint32_t nd = chunk_seq ? (uint32_t)(((seq0 & 15ull) + chunk_seq + 15ull) >> 4) : 0u;  // dwords the chunk touches
+    for (uint32_t i = threadIdx.x; i < nd; i += kFqThreads) {
+        const uint32_t w = s_out[i];
+        const uint64_t q = q0 + i;
+        if (w == 0u || q >= out_dwords) continue;  // (the output was cleared)
+        if (i == 0 || i + 1 == nd) atomicOr(&out32[q], w);
+        else out32[q] = w;
     }
 }
 
