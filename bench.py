@@ -35,6 +35,7 @@ import os
 import statistics
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -618,10 +619,94 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         assert int(ok.item()) == 1, "a rank produced an implausible number of minimizers"
 
+    multi_extra = []
+    median5 = end_to_end = total_out = None
+    emit_state = {"done": False}
+    emit_lock = threading.Lock()
+
+    def emit_line():
+        """Rank 0 prints the ONE JSON line (once: the watchdog of the multi-GPU extras may get here first)."""
+        with emit_lock:
+            if emit_state["done"]:
+                return
+            emit_state["done"] = True
+            emit_state["by_watchdog"] = threading.current_thread() is not threading.main_thread()
+            if rank == 0:
+                bases_done = float(total_bases) * args.steps
+                # SURVEY.md §8(d): PackedSeq read + u32 positions written, for the units ONE launch of this rank processes
+                alg_bytes = (my_bases + 3) // 4 + 4 * n_out
+                kern_s = kern_ms / 1e3 / max(1, launches)
+                achieved = alg_bytes / kern_s / 1e9
+                traffic, valu, prov = (None, None, "not recorded for this workload")
+                if args.workload == "headline" and n == N_BASES:
+                    traffic, valu, prov = recorded_counters(kern_s * 1e3, live_clock)
+                config = {"workload": workload, "k": k, "w": w, "bases_per_gpu": my_bases, "outputs_per_gpu": n_out,
+                          "kernel": kernel_name, "parallelism": f"shard{world}"}
+                if args.workload == "strong":
+                    config["windows_per_rank"] = [e - a for a, e in plan_s["ranges"]]
+                    config["bases_total"] = plan_s["total_bases"]
+                if gather_ms is not None:
+                    config["gather_ms"] = round(gather_ms, 3)
+                    config["gather"] = ("all-reduce of the per-contig counts + dist.gather of the device-resident position "
+                                        f"buffers to rank 0 ({backend}); {total_out} positions in total; median of 3")
+                roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                            "kernel_ms": round(kern_s * 1e3, 4), "algorithmic_bytes": alg_bytes,
+                            "traffic_source": prov,
+                            "note": "HBM is the nominal bound (SURVEY.md 8d); the kernel is VALU-issue bound, see `valu` "
+                                    "(second bound: VALU-pipe time of one launch / kernel time) and DESIGN.md 4.1"}
+                if valu is not None:
+                    roofline["valu"] = valu
+                line = {
+                    "metric": METRIC,
+                    "value": round(bases_done / dt / 1e9, 3),
+                    "unit": "Gbases/s",
+                    "n_gpus": world,
+                    "steps": args.steps,
+                    "warmup": args.warmup,
+                    "ms_per_step": round(dt / args.steps * 1e3, 4),
+                    "higher_is_better": True,
+                    "scaling": scaling,
+                    "vs_baseline": None,
+                    "dtype": "u32",
+                    "data": "synthetic",
+                    "config": config,
+                    "roofline": roofline,
+                }
+                if median5 is not None:
+                    line["median_of_5"] = median5
+                if end_to_end is not None:
+                    line["end_to_end"] = end_to_end
+                if extras or multi_extra:
+                    line["extra"] = extras + multi_extra
+                if not args.no_cpu_baseline and world == 1:
+                    line["cpu_baseline"] = cpu_baseline()
+                sys.stdout.flush()
+                os.dup2(saved_stdout, 1)
+                print(json.dumps(line), flush=True)
+                os.dup2(2, 1)
+
+
     # ---------------------------------------------------------------- N > 1, default workload: the other two figures
     # (untimed region; the same barrier + max-over-ranks protocol, a handful of steps each)
-    multi_extra = []
     if distributed and args.workload == "strong" and not args.no_extra:
+        # The two extra figures run collectives that the default line does not need (barriers around a second and a
+        # third workload, point-to-point sends of the gather).  A rank that fails or hangs inside them must not take the
+        # headline down: after MM_BENCH_EXTRA_TIMEOUT seconds (default 240) rank 0 prints the line with what it has and
+        # every rank leaves.
+        extra_deadline = float(os.environ.get("MM_BENCH_EXTRA_TIMEOUT", "240"))
+
+        def watchdog():
+            time.sleep(extra_deadline)
+            if emit_state["done"]:
+                return
+            if rank == 0:
+                multi_extra.append({"config": "multi-GPU extras", "error": f"not finished after {extra_deadline:g} s (a rank "
+                                    "failed or hung in a collective); the headline figures of this line are complete"})
+                emit_line()
+            os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+
         def timed_all_ranks(fn, steps_x):
             for _ in range(3):
                 fn()
@@ -638,11 +723,14 @@ def main():
 
         steps_x = max(3, min(10, args.steps))
         # weak: every rank walks the whole 3.1 Gbp sequence by itself (independent genomes; linear by construction)
-        out_full = torch.empty(int(n * 2.3 / (w + 1)) + 4096, dtype=torch.int32, device=dev)
-        t_weak = timed_all_ranks(lambda: b.run_device(d_packed, n, out_full, sync=False, d_count=d_count), steps_x)
-        del out_full
-        multi_extra.append({"config": f"weak: one {n} bp sequence per GPU, {world} GPUs", "scaling": "weak",
-                            "ms_per_step": round(t_weak * 1e3, 4), "Gbases_per_s": round(n * world / t_weak / 1e9, 1)})
+        try:
+            out_full = torch.empty(int(n * 2.3 / (w + 1)) + 4096, dtype=torch.int32, device=dev)
+            t_weak = timed_all_ranks(lambda: b.run_device(d_packed, n, out_full, sync=False, d_count=d_count), steps_x)
+            del out_full
+            multi_extra.append({"config": f"weak: one {n} bp sequence per GPU, {world} GPUs", "scaling": "weak",
+                                "ms_per_step": round(t_weak * 1e3, 4), "Gbases_per_s": round(n * world / t_weak / 1e9, 1)})
+        except Exception as e:  # must never take the default line down
+            multi_extra.append({"config": "weak", "error": str(e)[:200]})
         # contigs (BASELINE config 4): 24 CHM13-like contigs placed greedily, one batch launch per rank, then the gather
         try:
             if n != N_BASES:
@@ -690,11 +778,8 @@ def main():
             del gathered
         gather_ms = statistics.median(times)
         total_out = int(sum(counts))
-    else:
-        total_out = None
 
     # ---------------------------------------------------------------- untimed extras (rank 0, N = 1)
-    median5 = end_to_end = None
     if rank == 0 and world == 1 and not args.no_extra:
         med, allms = timed_kernel_ms(step)
         median5 = {"kernel_ms": round(med, 4), "Gbases_per_s": round(my_bases / med / 1e6, 1),
@@ -799,62 +884,14 @@ def main():
             except Exception as e:  # host memory limits of the box
                 end_to_end = {"error": str(e)[:200]}
 
-    if rank == 0:
-        bases_done = float(total_bases) * args.steps
-        # PackedSeq read + u32 positions written, for the units ONE launch of this rank processes
-        alg_bytes = (my_bases + 3) // 4 + 4 * n_out
-        kern_s = kern_ms / 1e3 / max(1, launches)
-        achieved = alg_bytes / kern_s / 1e9
-        traffic, valu, prov = (None, None, "not recorded for this workload")
-        if args.workload == "headline" and n == N_BASES:
-            traffic, valu, prov = recorded_counters(kern_s * 1e3, live_clock)
-        config = {"workload": workload, "k": k, "w": w, "bases_per_gpu": my_bases, "outputs_per_gpu": n_out,
-                  "kernel": kernel_name, "parallelism": f"shard{world}"}
-        if args.workload == "strong":
-            config["windows_per_rank"] = [e - a for a, e in plan_s["ranges"]]
-            config["bases_total"] = plan_s["total_bases"]
-        if gather_ms is not None:
-            config["gather_ms"] = round(gather_ms, 3)
-            config["gather"] = ("all-reduce of the per-contig counts + dist.gather of the device-resident position "
-                                f"buffers to rank 0 ({backend}); {total_out} positions in total; median of 3")
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "kernel_ms": round(kern_s * 1e3, 4), "algorithmic_bytes": alg_bytes,
-                    "traffic_source": prov,
-                    "note": "HBM is the nominal bound (SURVEY.md 8d); the kernel is VALU-issue bound, see `valu` "
-                            "(second bound: VALU-pipe time of one launch / kernel time) and DESIGN.md 4.1"}
-        if valu is not None:
-            roofline["valu"] = valu
-        line = {
-            "metric": METRIC,
-            "value": round(bases_done / dt / 1e9, 3),
-            "unit": "Gbases/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": scaling,
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": config,
-            "roofline": roofline,
-        }
-        if median5 is not None:
-            line["median_of_5"] = median5
-        if end_to_end is not None:
-            line["end_to_end"] = end_to_end
-        if extras or multi_extra:
-            line["extra"] = extras + multi_extra
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        print(json.dumps(line), flush=True)
-        os.dup2(2, 1)
+    emit_line()
+    if emit_state.get("by_watchdog"):
+        time.sleep(60.0)  # (the watchdog thread is printing the line and ends the process)
     if distributed:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

@@ -303,6 +303,27 @@ def test_bench_world2_line_is_strong(sm, gpu):
     assert "weak" in kinds  # the weak figure rides along
 
 
+def test_bench_extras_cannot_take_the_line_down(sm, gpu):
+    """The two extra figures of the N > 1 default line run collectives of their own; a rank that hangs or fails inside
+    them must not cost the headline.  MM_BENCH_EXTRA_TIMEOUT=0 makes the watchdog fire before they finish: rank 0 still
+    prints the complete strong-split line, with an error entry in `extra`, and the job ends with exit code 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["MM_BENCH_BACKEND"] = "gloo"
+    env["MM_BENCH_EXTRA_TIMEOUT"] = "0"
+    n = 200_000_000
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--bases", str(n), "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["bases_total"] == n
+    assert any("error" in e and "multi-GPU extras" in e.get("config", "") for e in line.get("extra", [])), line.get("extra")
+
+
 def test_tapered_tail(sm, oracle, gpu, monkeypatch):
     """The last tiles of a launch walk half- and quarter-length lanes (plan_taper, mm_fused.hip).  MM_TAPER_SLOTS
     pretends the chip holds only a few workgroups, so that runs of a handful of tiles taper: every flavour, window
