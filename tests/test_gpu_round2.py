@@ -216,6 +216,8 @@ def test_async_status_is_observable(sm, gpu):
 def test_product_ignores_experiment_switches(sm, oracle, gpu, monkeypatch):
     """a leaked MM_DEBUG / MM_JIT_DEFS / MM_FASTA_DEBUG must not change what the product computes."""
     import torch
+    if os.path.basename(sm.LIB_PATH).endswith("_exp.so"):
+        pytest.skip("MM_LIB_PATH names the experiments build, which reads these switches by design")
     n, k, w = 1_000_003, 21, 11
     data = oracle.gen_packed(5, n)
     want = oracle.run(data, n, k, w, canonical=True)
