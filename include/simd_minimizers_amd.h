@@ -331,11 +331,13 @@ int mm_pack_ascii_n_device_async(mm_workspace_t *ws, const uint8_t *d_ascii, uin
  * [d_rec_base[r], d_rec_base[r + 1]) of it - pass d_packed + base / 4 with base_offset = base % 4 to
  * mm_run_batch_device.  d_rec_text_pos[r] (optional) = byte offset of the record's '>' in the text (the
  * caller slices the header from there).  d_counts[0] = bases, d_counts[1] = records found; records past
- * max_records are counted but not tabulated.  The text must be shorter than 2^32 bytes.  The text is read once
- * (one kernel, 32 KB chunks chained by a decoupled look-back); a text whose lines are shorter than 16 bytes on
- * average, or a device that does not start workgroups in index order, makes that kernel give up: the synchronous
- * call below then repeats the text with the three-pass kernels by itself, an asynchronous caller gets MM_ERR_ORDER
- * from mm_workspace_check() and repeats the call (MM_FASTA_ONEPASS=0 takes the three-pass kernels from the start). */
+ * max_records are counted but not tabulated.  The text must be shorter than 2^32 bytes.  Two passes over the text
+ * (mm_fasta2.hip: every 16 KB chunk's effect on the header / record state as a composable function, then the packing);
+ * nothing in them depends on line lengths or on the order workgroups start in, so the call has no failure mode of its
+ * own.  (MM_FASTA_KERNEL=lines selects the one-pass kernel of rounds 3-4, which gives up on texts whose lines are
+ * shorter than 16 bytes on average and on a look-back time-out - the synchronous call below then repeats the text with
+ * the three-pass kernels, an asynchronous caller gets MM_ERR_ORDER from mm_workspace_check(); MM_FASTA_KERNEL=three
+ * takes those from the start.  Both are kept as cross-checks.) */
 int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes,
                                uint8_t *d_packed, uint64_t packed_capacity_bytes,
                                uint64_t *d_rec_base /* [max_records + 1] */,

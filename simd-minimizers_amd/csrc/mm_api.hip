@@ -1793,6 +1793,19 @@ int mm_pack_ascii_device_async(mm_workspace_t *ws, const uint8_t *d_ascii, uint6
     return MM_OK;
 }
 
+// Which FASTA packer a call takes: 0 the two passes of mask arithmetic (mm_fasta2.hip: the default since late round 4 -
+// no look-back, no tables with limits, nothing to fall back from), 1 the one-pass kernel over lines (rounds 3-4's default;
+// MM_FASTA_KERNEL=lines or MM_FASTA_ONEPASS=1), 2 the three-pass kernels (MM_FASTA_KERNEL=three or MM_FASTA_ONEPASS=0;
+// also what the one-pass kernel falls back to).  The older two stay as cross-checks (tests/test_gpu_fasta.py).
+static int fasta_packer_choice(const mm_workspace_t *ws) {
+    const char *k = mm::mm_env("MM_FASTA_KERNEL"), *one = mm::mm_env("MM_FASTA_ONEPASS");
+    int c = 0;
+    if (k) c = !strcmp(k, "lines") ? 1 : (!strcmp(k, "three") ? 2 : 0);
+    else if (one) c = one[0] == '0' ? 2 : 1;
+    if (c == 1 && (ws->fasta_three_pass || ws->fasta_three_once)) c = 2;
+    return c;
+}
+
 int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes,
                                uint8_t *d_packed, uint64_t packed_capacity_bytes, uint64_t *d_rec_base,
                                uint64_t *d_rec_text_pos, uint64_t max_records, uint64_t *d_counts) {
@@ -1808,16 +1821,25 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
     }
     if (!d_text || (!d_packed && packed_capacity_bytes)) return MM_ERR_NULL;
     uint8_t *sp = reinterpret_cast<uint8_t *>(ws->scratch);
-    const int r = grow(sp, ws->scratch_bytes, mm::fasta_scratch_bytes(n_bytes), 1);
+    const uint64_t need_a = mm::fasta_scratch_bytes(n_bytes), need_b = mm::fasta2_scratch_bytes(n_bytes);
+    const int r = grow(sp, ws->scratch_bytes, need_a > need_b ? need_a : need_b, 1);
     ws->scratch = sp;
     if (r) return r;
+    const int choice = fasta_packer_choice(ws);
+    if (choice == 0) {
+        if (mm::launch_fasta_pack2(d_text, n_bytes, d_packed, packed_capacity_bytes & ~3ull,
+                                   reinterpret_cast<unsigned long long *>(d_rec_base),
+                                   reinterpret_cast<unsigned long long *>(d_rec_text_pos), max_records,
+                                   reinterpret_cast<unsigned long long *>(d_counts), ws->scratch, ws->stream))
+            return hip_fail(hipGetLastError(), "fasta_pack2");
+        return MM_OK;
+    }
     // The one-pass kernel over lines (mm_fasta.hip: the text read once, one decoupled look-back between 32 KB chunks)
     // is the default since its third version (round 3: 0.96 ms for 1 GiB of 60-base lines against 1.66 ms for the
     // three passes); MM_FASTA_ONEPASS=0 takes the three-pass kernels, which also serve texts the one-pass kernel
     // gives up on (lines shorter than 16 bytes on average - more than 2 048 line segments in a chunk; a look-back
     // time-out).
-    const char *env_one = mm::mm_env("MM_FASTA_ONEPASS");
-    const bool one_pass = !(env_one && env_one[0] == '0') && !ws->fasta_three_pass && !ws->fasta_three_once;
+    const bool one_pass = choice == 1;
     if (one_pass) MM_HIP(hipMemsetAsync(ws->total + 1, 0, sizeof(unsigned long long), ws->stream));
     if (mm::launch_fasta_pack(d_text, n_bytes, d_packed, packed_capacity_bytes & ~3ull,
                               reinterpret_cast<unsigned long long *>(d_rec_base),
@@ -1889,8 +1911,7 @@ int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_b
         if (r) return r;
         // (only an attempt that launched the one-pass kernel cleared the error word and may consult it: the three-pass
         // kernels neither clear nor raise it, and a word left by an earlier failed run is not theirs - ADVICE r3)
-        const char *env_one = mm::mm_env("MM_FASTA_ONEPASS");
-        const bool was_one_pass = n_bytes != 0 && !(env_one && env_one[0] == '0') && !ws->fasta_three_pass && !ws->fasta_three_once;
+        const bool was_one_pass = n_bytes != 0 && fasta_packer_choice(ws) == 1;
         MM_HIP(hipMemcpyAsync(out_counts, d_counts, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ws->stream));
         MM_HIP(hipMemcpyAsync(ws->h_total + 1, ws->total + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                               ws->stream));

@@ -8,7 +8,9 @@
 // All records are packed back to back into ONE 2-bit buffer (record r = bases [rec_base[r], rec_base[r+1]) of it,
 // any base offset - what mm_run_batch_device takes), so the job is a stream compaction of the text.
 //
-// THE DEFAULT (round 3) is the ONE-PASS kernel fasta_lines_kernel further down ("the one-pass kernel over lines"):
+// SINCE LATE ROUND 4 THE DEFAULT IS mm_fasta2.hip (two passes of mask arithmetic, no look-back, no limits); this file
+// holds the packers of rounds 2-4, kept as its cross-checks (MM_FASTA_KERNEL=lines / three, MM_FASTA_ONEPASS=1 / 0).
+// The default of rounds 3-4 is the ONE-PASS kernel fasta_lines_kernel further down ("the one-pass kernel over lines"):
 // the text is read once, every 32 KB chunk is staged in LDS, cut into line segments with a SWAR separator scan and
 // packed to its final place, and the chunks are chained by ONE decoupled look-back whose status word carries the line
 // / header context, the bases and the records before the chunk (a look-back over functions, not only over sums).

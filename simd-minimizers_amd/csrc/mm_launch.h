@@ -142,6 +142,12 @@ int launch_fasta_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed
                       unsigned long long *d_rec_base, unsigned long long *d_rec_pos, uint64_t max_records,
                       unsigned long long *d_counts, void *scratch, hipStream_t stream, bool one_pass = false,
                       uint32_t *d_error = nullptr);
+// ---- the same in two passes of mask arithmetic (mm_fasta2.hip; the default since late round 4)
+uint64_t fasta2_scratch_bytes(uint64_t n_bytes);
+int launch_fasta_pack2(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed, uint64_t packed_capacity_bytes,
+                       unsigned long long *d_rec_base, unsigned long long *d_rec_pos, uint64_t max_records,
+                       unsigned long long *d_counts, void *scratch, hipStream_t stream);
+
 // ---- FASTQ text -> packed records (mm_fastq.hip): four-line records, the sequences of lines 4r + 1
 uint64_t fastq_scratch_bytes(uint64_t n_bytes);
 int launch_fastq_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed, uint64_t packed_capacity_bytes,

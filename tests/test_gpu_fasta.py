@@ -8,12 +8,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["three-pass", "one-pass"])
+@pytest.fixture(autouse=True, params=["three-pass", "one-pass", "two-pass"])
 def packer_flavour(request, monkeypatch):
-    """Every test runs with the one-pass kernel over lines (the default: the text read once, one decoupled look-back
-    between 16 KB chunks) and with the three-pass kernels (MM_FASTA_ONEPASS=0; also the fallback for texts whose lines
-    are shorter than 16 bytes on average - DESIGN.md 4.3a)."""
-    monkeypatch.setenv("MM_FASTA_ONEPASS", "1" if request.param == "one-pass" else "0")
+    """Every test runs with all three packers: the two passes of mask arithmetic (mm_fasta2.hip, the default since late
+    round 4: no environment switch), the one-pass kernel over lines (MM_FASTA_ONEPASS=1: the text read once, one decoupled
+    look-back between chunks) and the three-pass kernels (MM_FASTA_ONEPASS=0; also what the one-pass kernel falls back
+    to for texts whose lines are shorter than 16 bytes on average - DESIGN.md 4.3a)."""
+    if request.param == "two-pass":
+        monkeypatch.delenv("MM_FASTA_ONEPASS", raising=False)
+        monkeypatch.delenv("MM_FASTA_KERNEL", raising=False)
+    else:
+        monkeypatch.setenv("MM_FASTA_ONEPASS", "1" if request.param == "one-pass" else "0")
 
 
 def expect(oracle, text):

@@ -150,7 +150,7 @@ def _random_fasta(rng, n):
 
 
 def test_fasta_packers_agree_on_random_texts(sm, oracle, gpu, monkeypatch):
-    """one-pass packer == three-pass kernels (packed bytes, record tables, counts) on random texts around chunk
+    """two-pass packer == one-pass packer == three-pass kernels (packed bytes, record tables, counts) on random texts around chunk
     multiples (tests/test_gpu_fasta.py holds both against the oracle's reader)"""
     import torch
     rng = np.random.default_rng(7)
@@ -158,7 +158,10 @@ def test_fasta_packers_agree_on_random_texts(sm, oracle, gpu, monkeypatch):
     ws = sm.Workspace(0, torch.cuda.current_stream().cuda_stream)
 
     def run(t_dev, flav):
-        monkeypatch.setenv("MM_FASTA_ONEPASS", flav)
+        if flav is None:  # (the default: the two passes of mask arithmetic, mm_fasta2.hip)
+            monkeypatch.delenv("MM_FASTA_ONEPASS", raising=False)
+        else:
+            monkeypatch.setenv("MM_FASTA_ONEPASS", flav)
         n = t_dev.numel()
         packed = torch.zeros(n // 4 + 64, dtype=torch.uint8, device="cuda")
         cap = n // 2 + 2
@@ -178,9 +181,10 @@ def test_fasta_packers_agree_on_random_texts(sm, oracle, gpu, monkeypatch):
         n = max(1, base * int(rng.integers(1, 4)) + int(rng.integers(-40, 40)))
         t = _random_fasta(rng, n)
         td = torch.from_numpy(t).cuda()
-        a, b = run(td, "0"), run(td, "1")
-        assert a[0] == b[0] and a[1] == b[1], (it, n, a[:2], b[:2])
-        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]), (it, n)
+        a = run(td, "0")
+        for b in (run(td, "1"), run(td, None)):
+            assert a[0] == b[0] and a[1] == b[1], (it, n, a[:2], b[:2])
+            assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]), (it, n)
         compared += 1
     monkeypatch.delenv("MM_FASTA_ONEPASS", raising=False)
     ws.close()
