@@ -81,6 +81,22 @@ __device__ __forceinline__ uint32_t header_mask32(uint32_t rs, uint32_t ls, uint
     return (uint32_t)((((r ^ z) | a) & z) >> 1);
 }
 
+// '\n' mask of the thread's 32 bytes (as eq32) and, OR-ed into `special`, a flag for every byte below 0x40 (or in
+// 0x80..0xbf) that is NOT a '\n': sequence lines hold none, so a wave without one holds neither a '\r' nor a '>' and
+// skips their exact masks - three operations per dword where the two exact yes / no tests took six.
+__device__ __forceinline__ uint32_t newline_mask32(const Text32 &v, uint32_t &special) {
+    uint32_t mask = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t x = v.d[i], z = x ^ 0x0a0a0a0au;
+        const uint32_t t = (z & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+        const uint32_t m = ~(t | z | 0x7f7f7f7fu);  // 0x80 where the byte is '\n'
+        special |= ~x & 0x40404040u & ~(m >> 1);
+        mask |= ((m * 0x00204081u) >> 28) << (4 * i);
+    }
+    return mask;
+}
+
 constexpr uint32_t kUnknown = 3u;  // "no line start / no record start in front of this inside the chunk"
 
 // what both kernels start with: the chunk's text and every thread's class masks per piece
@@ -96,10 +112,12 @@ __device__ __forceinline__ void fa_read_chunk(const uint8_t *text, uint64_t n, u
 #pragma unroll
     for (int p = 0; p < (int)kFqPieces; ++p) c.v[p] = load32(text, n, c0 + (uint64_t)p * kFqPiece, threadIdx.x);
     const uint32_t left = n - c0 > 0x7fffffffull ? 0x7fffffffu : (uint32_t)(n - c0);
-    // ('\r' and '>' are rare: their exact masks only in waves that hold one)
-    const bool has_cr = __ballot((any_eq32(c.v[0], 0x0d0d0d0du) | any_eq32(c.v[1], 0x0d0d0d0du)) != 0u) != 0ull;
-    const bool has_gt = __ballot((any_eq32(c.v[0], 0x3e3e3e3eu) | any_eq32(c.v[1], 0x3e3e3e3eu)) != 0u) != 0ull;
     uint32_t nl[kFqPieces], valid[kFqPieces], ls[kFqPieces], ctx_line[kFqPieces], ctx_rec[kFqPieces];
+    // ('\r' and '>' are rare: their exact masks only in waves that hold a byte that could be one)
+    uint32_t special = 0;
+#pragma unroll
+    for (int p = 0; p < (int)kFqPieces; ++p) nl[p] = newline_mask32(c.v[p], special);
+    const bool has_cr = __ballot(special != 0u) != 0ull, has_gt = has_cr;
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;  // lanes in front of this one
 #pragma unroll
     for (int p = 0; p < (int)kFqPieces; ++p) {
@@ -107,7 +125,7 @@ __device__ __forceinline__ void fa_read_chunk(const uint8_t *text, uint64_t n, u
         const uint32_t nin = rel >= left ? 0u : (left - rel >= 32u ? 32u : left - rel);
         const uint32_t inside = nin >= 32u ? 0xffffffffu : ((1u << nin) - 1u);
         const bool sl = starts_line_of(text, n, c0 + rel, c.v[p]);
-        nl[p] = eq32(c.v[p], 0x0a0a0a0au) & inside;
+        nl[p] &= inside;
         const uint32_t cr = has_cr ? eq32(c.v[p], 0x0d0d0d0du) : 0u;
         const uint32_t gt = has_gt ? eq32(c.v[p], 0x3e3e3e3eu) : 0u;
         valid[p] = inside & ~nl[p] & ~cr;
