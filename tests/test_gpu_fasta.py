@@ -105,6 +105,24 @@ def random_fasta(rng, n_target):
     return bytes(out)
 
 
+def test_fasta_state_across_groups(sm, oracle, gpu):
+    """The header / record state carried over more than a GROUP of 256 chunks (4 MB; mm_fasta2.hip composes the chunks'
+    state functions per group and then the groups): a header line, a sequence line and the text in front of the first
+    header longer than that, a text that is one header without a newline, and 8.8 MB of 40-base records."""
+    rng = np.random.default_rng(31)
+    acgt = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)
+
+    def seq(n):
+        return acgt[rng.integers(0, 9, n)].tobytes()
+    big = 4_500_000
+    check(sm, oracle, b">" + b"h" * big + b"\n" + seq(1000) + b"\n>b\n" + seq(77) + b"\n")
+    check(sm, oracle, b">a\n" + seq(big) + b"\n>b desc\n" + seq(3) + b"\n")
+    check(sm, oracle, seq(big) + b"\n>a\n" + seq(100) + b"\n")
+    check(sm, oracle, b">a\n" + seq(big))
+    check(sm, oracle, b">" + b"h" * big)
+    check(sm, oracle, (b">r\n" + seq(40) + b"\n") * 200_000, max_records=1 << 18)
+
+
 def test_fasta_random(sm, oracle, gpu):
     rng = np.random.default_rng(2024)
     sizes = [1, 15, 16, 17, 4095, 4096, 4097, 16383, 16384, 16385, 32767, 32768, 32769, 65536 + 3, 200_000, 1_000_000]
