@@ -422,6 +422,13 @@ int mm_run_batch_sharded_host(const mm_plan_t *plan, mm_device_group_t *group, u
  * sequence, not owned by the group.  (Every entry addresses the whole sequence so that positions are absolute;
  * an entry only READS the bytes of its own window range and a halo of k + w - 1 bases.) */
 int mm_device_group_upload(mm_device_group_t *group, const uint8_t *packed, uint64_t packed_bytes);
+/* The same for ONE run shape: every entry receives only the bytes its window range of an N-way split of
+ * (base_offset, n_bases) can read - its share plus a halo that covers any k + w - 1 below 2^17 - so the sequence crosses
+ * the host link once in total, not once per device (the whole extent is still allocated on every device: offsets stay
+ * absolute).  mm_run_sharded_device refuses (MM_ERR_NULL, mm_last_error() names the ranges) a run whose shape needs bytes
+ * an entry does not hold.  MM_ERR_CAPACITY: the bases do not fit packed_bytes. */
+int mm_device_group_upload_range(mm_device_group_t *group, const uint8_t *packed, uint64_t packed_bytes,
+                                 uint64_t base_offset, uint64_t n_bases);
 int mm_device_group_adopt(mm_device_group_t *group, const void *const *d_packed /* [size] */, uint64_t packed_bytes);
 /* Builder::run over the resident sequence, cut into mm_device_group_size(group) equal window ranges (absolute
  * positions, exact seam: range i starts by comparing with the window before it, src/collect.rs:265-271, so the

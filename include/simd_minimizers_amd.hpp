@@ -328,6 +328,10 @@ class DeviceGroup {
     // ---- device-resident shards (round 4): the sequence lives in HBM on every device of the group, every device
     // walks its window range with one asynchronous launch, the positions stay where they were made
     void upload(PackedSeq seq) { check(mm_device_group_upload(g_, seq.data, (seq.offset + seq.len + 3) / 4)); }
+    /// Every device receives only what its share of an N-way split of `seq` reads (one crossing of the host link in total).
+    void upload_shares(PackedSeq seq) {
+        check(mm_device_group_upload_range(g_, seq.data, (seq.offset + seq.len + 3) / 4, seq.offset, seq.len));
+    }
     void adopt(const std::vector<const void *> &d_packed, uint64_t packed_bytes) {
         check(mm_device_group_adopt(g_, d_packed.data(), packed_bytes));
     }

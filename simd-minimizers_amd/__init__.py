@@ -100,6 +100,8 @@ def lib():
         L.mm_run_batch_sharded_host.argtypes = [vp, vp, C.c_uint64, C.POINTER(u8p), u64p, u64p, u32p, u32p, C.c_uint64, u64p]
         if hasattr(L, "mm_run_sharded_device"):  # (absent from the round-3 library kept for A/B runs under tools/ab/)
             L.mm_device_group_upload.argtypes = [vp, u8p, C.c_uint64]
+            if hasattr(L, "mm_device_group_upload_range"):
+                L.mm_device_group_upload_range.argtypes = [vp, u8p, C.c_uint64, C.c_uint64, C.c_uint64]
             L.mm_device_group_adopt.argtypes = [vp, C.POINTER(vp), C.c_uint64]
             L.mm_run_sharded_device.argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.c_int, u64p, u64p]
             L.mm_device_group_result.argtypes = [vp, C.c_int, C.POINTER(u32p), C.POINTER(u32p), u64p, u64p, u64p]
@@ -193,7 +195,7 @@ EXPORTED_SYMBOLS = [
     "mm_clock_probe_begin", "mm_clock_probe_end",
     "mm_device_group_create", "mm_device_group_destroy", "mm_device_group_size", "mm_run_sharded_host",
     "mm_run_batch_sharded_host",
-    "mm_device_group_upload", "mm_device_group_adopt", "mm_run_sharded_device", "mm_device_group_result",
+    "mm_device_group_upload", "mm_device_group_upload_range", "mm_device_group_adopt", "mm_run_sharded_device", "mm_device_group_result",
     "mm_device_group_gather",
     "mm_device_group_upload_batch", "mm_run_batch_sharded_device", "mm_device_group_batch_result",
     "mm_device_group_gather_batch", "mm_debug_launch_plan",
@@ -436,6 +438,13 @@ class DeviceGroup:
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         _check(lib().mm_device_group_upload(self.h, packed.ctypes.data_as(C.POINTER(C.c_uint8)), packed.size))
 
+    def upload_range(self, packed: np.ndarray, n_bases: int, base_offset: int = 0):
+        """``mm_device_group_upload_range``: every entry receives only the bytes its share of an N-way split of
+        (base_offset, n_bases) reads (+ a halo): the sequence crosses the host link once in total."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        _check(lib().mm_device_group_upload_range(self.h, packed.ctypes.data_as(C.POINTER(C.c_uint8)), packed.size,
+                                                  base_offset, n_bases))
+
     def adopt(self, device_tensors):
         """Device buffers the caller already holds (one per entry, on that entry's device, same bytes)."""
         self._adopted = list(device_tensors)  # keep them alive
@@ -448,8 +457,11 @@ class DeviceGroup:
         n = len(self)
         counts = (C.c_uint64 * n)()
         total = C.c_uint64()
-        _check(lib().mm_run_sharded_device(builder.plan().h, self.h, base_offset, n_bases,
-                                           1 if builder._sk is not None else 0, counts, C.byref(total)))
+        code = lib().mm_run_sharded_device(builder.plan().h, self.h, base_offset, n_bases,
+                                           1 if builder._sk is not None else 0, counts, C.byref(total))
+        if code == ERR["NULL"]:  # (no resident sequence, or one whose resident ranges do not cover this run: the library says which)
+            raise MinimizerError(code, lib().mm_strerror(code).decode() + ": " + lib().mm_last_error().decode())
+        _check(code)
         return [int(c) for c in counts]
 
     def result(self, entry: int):

@@ -1981,6 +1981,9 @@ struct mm_device_group {
     std::vector<void *> d_seq;     // the packed sequence as entry i's device addresses it
     std::vector<char> own_seq;     // uploaded by the group (freed with it) / adopted from the caller
     uint64_t seq_bytes = 0;
+    // bytes of the sequence that are RESIDENT on entry i ([0, seq_bytes) after _upload / _adopt; the entry's own share
+    // plus a halo after mm_device_group_upload_range)
+    std::vector<uint64_t> res_lo, res_hi;
     struct Shard {
         uint32_t *d_pos = nullptr, *d_sk = nullptr;  // result buffers on the entry's device, grown as needed
         uint64_t cap_pos = 0, cap_sk = 0;
@@ -2064,6 +2067,8 @@ static void group_drop_sequence(mm_device_group *g) {
         }
     g->d_seq.assign(g->ws.size(), nullptr);
     g->own_seq.assign(g->ws.size(), 0);
+    g->res_lo.assign(g->ws.size(), 0);
+    g->res_hi.assign(g->ws.size(), 0);
     g->seq_bytes = 0;
 }
 
@@ -2109,6 +2114,59 @@ int mm_device_group_upload(mm_device_group_t *g, const uint8_t *packed, uint64_t
         MM_HIP(hipStreamSynchronize(g->ws[i]->stream));
     }
     g->seq_bytes = packed_bytes;
+    g->res_hi.assign(g->ws.size(), packed_bytes);
+    return MM_OK;
+}
+
+
+// The bytes entry i of an N-way window split can read, for ANY plan (k + w - 1 below 2^17): its share of the bases,
+// the largest window in front and behind, a lane's over-read behind a range (the walk of a lane that starts inside the
+// range runs its whole length: below 60 000 bases) and the look-ahead of the loads.
+static void resident_range(uint64_t base_offset, uint64_t n_bases, uint64_t N, uint64_t i, uint64_t total_bytes, uint64_t *lo,
+                           uint64_t *hi) {
+    const uint64_t kMaxL = 1ull << 17, kOver = 70000ull;
+    const uint64_t nb_lo = n_bases > kMaxL ? n_bases - kMaxL : 0;
+    uint64_t first = base_offset + nb_lo / N * i;
+    first = first / 4 > 64 ? first / 4 - 64 : 0;
+    *lo = first & ~255ull;
+    const uint64_t last = (base_offset + n_bases / N * (i + 1) + n_bases % N + kMaxL + kOver) / 4 + 4096;
+    *hi = (i + 1 == N || last > total_bytes) ? total_bytes : last;
+}
+
+int mm_device_group_upload_range(mm_device_group_t *g, const uint8_t *packed, uint64_t packed_bytes, uint64_t base_offset,
+                                 uint64_t n_bases) {
+    if (!g || g->ws.empty() || !packed || packed_bytes == 0) return MM_ERR_NULL;
+    if ((base_offset + n_bases + 3) / 4 > packed_bytes) return MM_ERR_CAPACITY;
+    group_drop_sequence(g);
+    const uint64_t N = g->ws.size();
+    for (uint64_t i = 0; i < N; ++i) {
+        MM_HIP(hipSetDevice(g->ws[i]->device));
+        void *p = nullptr;
+        // (the whole extent is ALLOCATED on every device so that offsets stay absolute; only the entry's range crosses
+        // the host link.  What is not uploaded is filled with a pattern: a run can never depend on stale memory.)
+        hipError_t e = hipMalloc(&p, packed_bytes + 64);
+        if (e != hipSuccess) {
+            g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+            group_drop_sequence(g);
+            return MM_ERR_ALLOC;
+        }
+        g->d_seq[i] = p;
+        g->own_seq[i] = 1;
+        uint64_t lo, hi;
+        resident_range(base_offset, n_bases, N, i, packed_bytes, &lo, &hi);
+        g->res_lo[i] = lo;
+        g->res_hi[i] = hi;
+        uint8_t *d = static_cast<uint8_t *>(p);
+        if (lo) MM_HIP(hipMemsetAsync(d, 0xA5, lo, g->ws[i]->stream));
+        if (hi < packed_bytes) MM_HIP(hipMemsetAsync(d + hi, 0xA5, packed_bytes - hi, g->ws[i]->stream));
+        MM_HIP(hipMemsetAsync(d + packed_bytes, 0, 64, g->ws[i]->stream));
+        MM_HIP(hipMemcpyAsync(d + lo, packed + lo, hi - lo, hipMemcpyHostToDevice, g->ws[i]->stream));
+    }
+    for (uint64_t i = 0; i < N; ++i) {
+        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(hipStreamSynchronize(g->ws[i]->stream));
+    }
+    g->seq_bytes = packed_bytes;
     return MM_OK;
 }
 
@@ -2118,6 +2176,7 @@ int mm_device_group_adopt(mm_device_group_t *g, const void *const *d_packed, uin
         if (!d_packed[i]) return MM_ERR_NULL;
     group_drop_sequence(g);
     for (size_t i = 0; i < g->ws.size(); ++i) g->d_seq[i] = const_cast<void *>(d_packed[i]);
+    g->res_hi.assign(g->ws.size(), packed_bytes);
     g->seq_bytes = packed_bytes;
     return MM_OK;
 }
@@ -2275,6 +2334,19 @@ int mm_run_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, uint64_t 
         s.count = 0;
         s.has_sk = want_superkmers != 0;
         if (s.win_begin >= s.win_end) continue;
+        {   // what this entry's run reads must be resident on it (mm_device_group_upload_range uploads a share + halo)
+            const uint64_t lw = (uint64_t)plan->k + plan->w - 1;
+            const uint64_t need_lo = (base_offset + (s.win_begin ? s.win_begin - 1 : 0)) / 4;
+            uint64_t need_hi = (base_offset + s.win_end + lw - 2) / 4 + 1 + 24576;
+            if (need_hi > g->seq_bytes) need_hi = g->seq_bytes;
+            if (need_lo < g->res_lo[i] || need_hi > g->res_hi[i]) {
+                g_last_error = "mm_run_sharded_device: entry " + std::to_string(i) + " holds bytes [" + std::to_string(g->res_lo[i]) +
+                               ", " + std::to_string(g->res_hi[i]) + ") of the sequence, this run reads [" + std::to_string(need_lo) +
+                               ", " + std::to_string(need_hi) + "): upload the range this run covers (mm_device_group_upload_range) "
+                               "or the whole sequence (mm_device_group_upload)";
+                return MM_ERR_NULL;
+            }
+        }
         const uint64_t nw = s.win_end - s.win_begin;
         uint64_t want = (uint64_t)(dens * 1.15 * (double)nw) + 4096;
         if (want > nw) want = nw;

@@ -586,6 +586,40 @@ def test_fastq_packer(sm, oracle, gpu):
         assert np.array_equal(flat2[offs2[r]: offs2[r + 1]], w_r), r
 
 
+def test_device_resident_shares(sm, oracle, gpu):
+    """mm_device_group_upload_range: every entry holds only the bytes its share of the N-way split reads (+ a halo; the
+    rest of its buffer is a fill pattern), so the sequence crosses the host link once in total.  Runs of that shape with
+    several plans - small and large windows, super-k-mers, syncmers, an odd base offset - equal the oracle; a run of
+    another shape is refused with the ranges named."""
+    import torch
+    n, off = 40_000_003, 3
+    host = oracle.gen_packed(17, n + off + 64)
+    g = sm.DeviceGroup([0, 0, 0, 0])
+    g.upload_range(host[: (n + off + 3) // 4 + 1], n, base_offset=off)
+    for (k, w, canonical, mode, sk) in ((21, 11, True, 0, False), (31, 51, True, 0, False), (21, 11, False, 0, True),
+                                        (15, 17, True, 1, False), (5, 3, False, 0, False)):
+        b = sm.Builder(k, w, canonical, mode)
+        sk_list = []
+        if sk:
+            b = b.super_kmers(sk_list)
+        counts = g.run_device(b, n, base_offset=off)
+        if sk:
+            want, wsk = oracle.run(host, n, k, w, canonical=canonical, mode=mode, base_offset=off, super_kmers=True)
+        else:
+            want = oracle.run(host, n, k, w, canonical=canonical, mode=mode, base_offset=off)
+        assert sum(counts) == len(want), (k, w, mode)
+        dst = torch.zeros(len(want) + 1, dtype=torch.int32, device="cuda")
+        dsk = torch.zeros(len(want) + 1, dtype=torch.int32, device="cuda") if sk else None
+        assert g.gather(0, dst, dsk) == len(want)
+        assert np.array_equal(_dev(dst, len(want)), want), (k, w, mode)
+        if sk:
+            assert np.array_equal(_dev(dsk, len(want)), wsk)
+    with pytest.raises(sm.MinimizerError) as e:  # another shape: its shares lie elsewhere
+        g.run_device(sm.minimizers(21, 11), n // 2, base_offset=off)
+    assert e.value.code == sm.ERR["NULL"] and "holds bytes" in str(e.value)
+    g.close()
+
+
 def test_fastq_packer_large(sm, gpu):
     """More than 1 GiB of FASTQ text (more than 256 groups of 256 chunks: the second round of the resolve step's single
     workgroup), records of one shape, checked on the device: counts, every record's first base and byte offset, and the

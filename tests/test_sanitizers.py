@@ -97,6 +97,14 @@ for _ in range(3):
 want = oracle.run(data, 4_000_003, k, w, canonical=True)
 dst = torch.zeros(len(want) + 8, dtype=torch.int32, device="cuda")
 assert g.gather(1, dst) == len(want) and np.array_equal(dst[: len(want)].cpu().numpy().view(np.uint32), want)
+g.upload_range(data[: (4_000_003 + 3) // 4 + 1], 4_000_003)   # every entry only its share (+ halo) of the bytes
+g.run_device(b, 4_000_003)
+assert g.gather(0, dst) == len(want) and np.array_equal(dst[: len(want)].cpu().numpy().view(np.uint32), want)
+try:
+    g.run_device(b, 1_000_000)   # another shape: refused, the ranges named
+    raise SystemExit("a run outside the resident ranges was accepted")
+except sm.MinimizerError as e_:
+    assert "holds bytes" in str(e_)
 lens = [300_000, 7, 0, 1_000_001, 250_000]
 seqs = [oracle.gen_packed(60 + i, m + 3) for i, m in enumerate(lens)]
 g.upload_batch([s_[: (m + 3) // 4 + 1] for s_, m in zip(seqs, lens)])
