@@ -256,7 +256,7 @@ def recorded_counters(kernel_ms, live_clock_ghz=None):
 def single_process(args):
     """`--single-process --gpus N`: the several-device entry points a C / Rust caller uses, driven from THIS process
     through the C ABI's device group (no torch.distributed).  `value`: mm_run_sharded_device - the sequence resident on
-    every device (mm_device_group_upload, once, untimed), one asynchronous launch per device over its window range, the
+    the devices (mm_device_group_upload_range: every device its share, once, untimed), one asynchronous launch per device over its window range, the
     positions left on the devices - with the device-to-device gather (mm_device_group_gather) timed
     beside it; `extra`: the host-buffer call mm_run_sharded_host (H2D + kernel + D2H per shard: PCIe-bound)."""
     import numpy as np
@@ -276,7 +276,7 @@ def single_process(args):
     hp[:] = d.cpu().numpy()
     g = sm.DeviceGroup(devices)
     b = sm.canonical_minimizers(K, W)
-    g.upload(hp[: (n + 3) // 4 + 1])
+    g.upload_range(hp[: (n + 3) // 4 + 1], n)  # (every device only its share of the split + halo)
     for _ in range(max(3, args.warmup)):
         counts = g.run_device(b, n)
     t0 = time.perf_counter()
@@ -351,7 +351,7 @@ def single_process(args):
         "value": round(n / dt / 1e9, 3), "unit": "Gbases/s", "n_gpus": args.gpus, "steps": args.steps,
         "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"ONE {n} bp PackedSeq resident on every device of the group (mm_device_group_upload, untimed), cut "
+        "config": {"workload": f"ONE {n} bp PackedSeq, every device holding its share (mm_device_group_upload_range, untimed), cut "
                                f"into {args.gpus} window ranges by mm_run_sharded_device: one asynchronous launch per entry from "
                                "one host thread, positions left on the devices, absolute, exact seam",
                    "devices": devices, "distinct_devices": len(set(devices)), "outputs": int(total),
