@@ -867,7 +867,8 @@ def main():
                     except Exception:
                         gpu_node = None
                     try:
-                        cpu = os.sched_getcpu()
+                        # (the CPU this thread last ran on: field 39 of /proc/self/stat, counted behind the ")" of the name)
+                        cpu = int(open("/proc/self/stat").read().rsplit(")", 1)[1].split()[36])
                         import glob as _glob
                         nodes = _glob.glob(f"/sys/devices/system/cpu/cpu{cpu}/node*")
                         cpu_node = int(os.path.basename(nodes[0])[4:]) if nodes else None
