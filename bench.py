@@ -451,15 +451,17 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra and args.workload == "headline" and args.bases == N_BASES and not os.environ.get("MM_BENCH_SKIP_SECONDARY"):
         # Secondary configurations of BASELINE.json (untimed region, before the headline so that they
         # also bring the clocks up): kernel time by HIP events, median of 5 after 12 warm-up steps.
-        def secondary(name, builder, n, seed, density, contigs=None):
+        def secondary(name, builder, n, seed, density, contigs=None, super_kmers=False):
             b = builder.workspace(ws)
+            sk = None
             if contigs is None:
                 d = generate(n, seed)
                 out = torch.empty(int(n * density * 1.15) + 4096, dtype=torch.int32, device=dev)
+                sk = torch.empty_like(out) if super_kmers else None
                 cnt = torch.zeros(1, dtype=torch.int64, device=dev)
 
                 def step():
-                    b.run_device(d, n, out, sync=False, d_count=cnt)
+                    b.run_device(d, n, out, sync=False, d_count=cnt, out_sk=sk)
             else:
                 d = [generate(m, sharding.CHM13_CONTIG_SEED0 + i) for i, m in enumerate(contigs)]
                 n = sum(contigs)
@@ -481,11 +483,11 @@ def main():
             med, _ = timed_kernel_ms(step)
             ws.check()
             n_out = int(cnt.item()) if contigs is None else int(offs[-1])
-            alg = (n + 3) // 4 + 4 * n_out
+            alg = (n + 3) // 4 + 4 * n_out * (2 if super_kmers else 1)  # + 4 n_out with super-k-mer indices
             extras.append({"config": name, "bases": n, "outputs": n_out, "kernel_ms": round(med, 4),
-                           "Gbases_per_s": round(n / med / 1e6, 1),
+                           "Gbases_per_s": round(n / med / 1e6, 1), "algorithmic_bytes": alg,
                            "frac": round(alg / (med * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
-            del d, out
+            del d, out, sk
             torch.cuda.empty_cache()
 
         secondary("C2 forward minimizers k=21 w=11, 256 Mbp (G seed 2)", sm.minimizers(21, 11), 268_435_456, 2, 2 / 12)
@@ -494,6 +496,11 @@ def main():
                   sm.canonical_minimizers(31, 51), 0, 0, 2 / 52, contigs=sharding.CHM13_CONTIG_LENGTHS)
         secondary("C5 canonical closed syncmers k=15 w=17, 3.1 Gbp (G seed 3)", sm.canonical_closed_syncmers(15, 17),
                   N_BASES, SEED, 2 / 17)
+        # BASELINE config 5 says "with super-k-mer boundary emission"; the reference refuses .super_kmers() on syncmer
+        # builders (src/lib.rs:339,496-500), so the conformant operation at that size is the minimizer builder's:
+        # canonical_minimizers(21, 11).super_kmers(&mut sk) on the headline sequence (src/lib.rs:341-351,545-576)
+        secondary("SK canonical minimizers k=21 w=11 + super-k-mer indices (.super_kmers), 3.1 Gbp (G seed 3)",
+                  sm.canonical_minimizers(21, 11), N_BASES, SEED, 2 / 12, super_kmers=True)
         # The rows either side of the path: whole-call device time (torch events on the workspace's
         # stream, median of 5 after 3 warm-up calls), algorithmic bytes and their fraction of the HBM peak
         from simd_minimizers_amd import workloads
@@ -830,30 +837,28 @@ def main():
                         e2e.append((time.perf_counter() - te) * 1e3)
                 assert cnt.value == n_out
                 m = statistics.median(e2e)
-                # the link itself, measured beside it (this figure moved 39.6 -> 71.4 ms between two driver boxes):
-                # 512 MiB each way between the same page-locked buffers and the device, best of 3
+                # the link itself, measured beside it (this figure moved 39.6 -> 71.4 ms between two driver boxes of round
+                # 4): 512 MiB each way between the same page-locked buffers and the device - each direction alone and,
+                # since round 5, BOTH AT ONCE (mm_link_probe: the copy engines on two streams).  The two directions do not
+                # add up (97 GB/s together against 57.6 + 57.1 alone on round 5's boxes), so the call's floor is priced with
+                # the rate they reach together: both run at half of it until the upload is through, the rest of the
+                # positions then leaves at the one-way rate.
                 link = {}
                 try:
-                    nb = min(512 << 20, hp.nbytes)
-                    dbuf = torch.empty(nb, dtype=torch.uint8, device=dev)
-                    hview = torch.from_numpy(hp[:nb])  # (page-locked by mm_host_alloc: the runtime copies it directly)
-                    for name, kind in (("h2d_GBps", 1), ("d2h_GBps", 2)):
-                        best = None
-                        for _ in range(3):
-                            torch.cuda.synchronize(dev)
-                            tl = time.perf_counter()
-                            if kind == 1:
-                                dbuf.copy_(hview)
-                            else:
-                                hview.copy_(dbuf)
-                            torch.cuda.synchronize(dev)
-                            el = time.perf_counter() - tl
-                            best = el if best is None or el < best else best
-                        link[name] = round(nb / best / 1e9, 1)
-                    # (what the call moves: the packed bytes in, the positions out, full duplex at best)
-                    link["floor_ms_at_these_rates"] = round(max((n / 4) / (link["h2d_GBps"] * 1e9),
-                                                                (4 * n_out) / (link["d2h_GBps"] * 1e9)) * 1e3, 2)
-                    del dbuf
+                    nb = min(512 << 20, hp.nbytes, ho.nbytes)
+                    rates = (C.c_double * 3)()
+                    sm._check(L.mm_link_probe(ws.h, C.c_void_p(hp.ctypes.data), C.c_void_p(ho.ctypes.data), nb, rates))
+                    link["h2d_GBps"], link["d2h_GBps"] = round(rates[0], 1), round(rates[1], 1)
+                    link["both_directions_GBps"] = round(rates[2], 1)
+                    b_in, b_out = n / 4.0, 4.0 * n_out
+                    half = rates[2] * 1e9 / 2.0
+                    t_overlap = min(b_in, b_out) / half
+                    rest = (b_out - b_in) / (rates[1] * 1e9) if b_out > b_in else (b_in - b_out) / (rates[0] * 1e9)
+                    link["floor_ms_at_these_rates"] = round((t_overlap + rest) * 1e3, 2)
+                    link["floor_ms_if_full_duplex"] = round(max(b_in / (rates[0] * 1e9), b_out / (rates[1] * 1e9)) * 1e3, 2)
+                    link["floor_what"] = ("both directions at half of both_directions_GBps until the smaller transfer is through, the "
+                                          "rest at its one-way rate; floor_ms_if_full_duplex = max of the two one-way times, the "
+                                          "figure of rounds 3-4, which no call can reach on a link that does not run 2 x one-way")
                     # where this process sits relative to the GPU: a page-locked buffer on the OTHER socket's memory makes
                     # every transfer cross the inter-socket link as well (the same code measured 39.6 and 71.5 ms on boxes
                     # of this pool whose one-way rates were both 57 GB/s)
@@ -879,8 +884,12 @@ def main():
                     link = {"error": str(e)[:120]}
                 end_to_end = {"ms": round(m, 2), "Gbases_per_s": round(n / m / 1e6, 1), "link": link,
                               "what": "mm_run_host: H2D of the packed bytes + kernel + D2H of the positions, "
-                                      "page-locked caller buffers (mm_host_alloc), pipelined in 16 chunks; "
-                                      "median of 3 after 1 warm-up; PCIe-bound, never part of `value`"}
+                                      "page-locked caller buffers (mm_host_alloc), pipelined in 16 chunks (at most two "
+                                      "uploads and two downloads in the runtime's hands at a time, counts polled from "
+                                      "page-locked words the kernels store); median of 3 after 1 warm-up; PCIe-bound, "
+                                      "never part of `value`",
+                              "ms_over_floor": (round(m / link["floor_ms_at_these_rates"], 3)
+                                                if isinstance(link.get("floor_ms_at_these_rates"), float) else None)}
                 del hp, ho, hp_owner, ho_owner
             except Exception as e:  # host memory limits of the box
                 end_to_end = {"error": str(e)[:200]}

@@ -383,7 +383,9 @@ int mm_run_packed_reads_host(const mm_plan_t *plan, mm_workspace_t *ws, const ui
  * packed like a FASTA record's, same output layout: record r = bases [d_rec_base[r], d_rec_base[r + 1]),
  * d_rec_text_pos[r] = byte offset of its '@', d_counts = {bases, records}.  Reads of one length go straight into
  * mm_run_reads_device (read_stride = read_len), any lengths into mm_run_batch_device.  needletail is not in the
- * reference tree: parity unpinned like the FASTA packer's; no validation of '+' lines or quality lengths. */
+ * reference tree: parity unpinned like the FASTA packer's; no validation of '+' lines or quality lengths.
+ * The text has to START with the first record's '@' (a line's role is the number of newlines in front of it mod 4);
+ * mm_fasta_pack_device cuts blank bytes in front of it off before it calls this and keeps the text positions absolute. */
 int mm_fastq_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes,
                                uint8_t *d_packed, uint64_t packed_capacity_bytes,
                                uint64_t *d_rec_base /* [max_records + 1] */,
@@ -482,6 +484,11 @@ int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n
  * single-wave workgroups on a stream of the workspace's own that sample the shader cycle counter against the
  * 100 MHz real-time counter for duration_us; _end waits for them and returns the mean clock in GHz (bench.py
  * brackets its timed loop with the pair: the VALU bound of roofline.valu is priced at THIS clock). */
+/* Diagnostics: the host link of this box - host -> device alone, device -> host alone and BOTH AT ONCE (copy engines, two
+ * streams), `bytes` each way between the caller's (page-locked) buffers and device memory the call allocates.
+ * out_GBps[0..2] = the two one-way rates and the SUM of both directions while they run together; the floor of
+ * mm_run_host follows from the third, which is less than the sum of the first two (bench.py: end_to_end.link). */
+int mm_link_probe(mm_workspace_t *ws, const void *host_in, void *host_out, uint64_t bytes, double *out_GBps /* [3] */);
 int mm_clock_probe_begin(mm_workspace_t *ws, uint64_t duration_us);
 int mm_clock_probe_end(mm_workspace_t *ws, double *ghz);
 /* Deterministic synthetic PackedSeq generator G of BASELINE.md §4, written on the device. */

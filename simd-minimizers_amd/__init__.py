@@ -119,6 +119,7 @@ def lib():
                                                C.c_uint64, u64p]
         L.mm_clock_probe_begin.argtypes = [vp, C.c_uint64]
         L.mm_clock_probe_end.argtypes = [vp, C.POINTER(C.c_double)]
+        L.mm_link_probe.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(C.c_double)]
         L.mm_workspace_force_generic.argtypes = [vp, C.c_int]
         L.mm_workspace_set_blocks_per_lane.argtypes = [vp, C.c_uint32]
         L.mm_workspace_enable_timing.argtypes = [vp, C.c_int]
@@ -192,7 +193,7 @@ EXPORTED_SYMBOLS = [
     "mm_run_reads_skip_ambiguous_device", "mm_pack_ascii_n_device_async", "mm_pack_ascii_device_async",
     "mm_host_alloc", "mm_host_free",
     "mm_generate_device_async", "mm_fasta_pack_device_async", "mm_fasta_pack_device", "mm_fastq_pack_device_async",
-    "mm_clock_probe_begin", "mm_clock_probe_end",
+    "mm_clock_probe_begin", "mm_clock_probe_end", "mm_link_probe",
     "mm_device_group_create", "mm_device_group_destroy", "mm_device_group_size", "mm_run_sharded_host",
     "mm_run_batch_sharded_host",
     "mm_device_group_upload", "mm_device_group_upload_range", "mm_device_group_adopt", "mm_run_sharded_device", "mm_device_group_result",

@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <algorithm>
@@ -142,8 +143,10 @@ struct mm_workspace {
     uint64_t wamb_dwords = 0;
     // pipelined host entry point: copy streams, per-chunk events and pinned running totals
     hipStream_t copy_in = nullptr, copy_out = nullptr;
-    hipEvent_t ev_in[16] = {}, ev_k[16] = {};
-    unsigned long long *h_pipe = nullptr;  // [16][2]
+    hipEvent_t ev_in[64] = {}, ev_k[64] = {}, ev_out[64] = {};
+    unsigned long long *h_pipe = nullptr;      // [64] page-locked: chunk c's kernel stores its running total here
+    unsigned long long *h_pipe_dev = nullptr;  // the same words as the device addresses them
+    unsigned long long *d_pipe = nullptr;      // [65] device: [0] = 0, [c + 1] = running total after chunk c (blit mode)
     // batch mode tables (sequence descriptors, tile -> sequence, per-sequence offsets)
     mm::BatchSeq *batch_seqs = nullptr;
     uint64_t batch_seqs_n = 0;
@@ -223,7 +226,10 @@ int next_status_epoch(mm_workspace *ws, uint32_t *epoch) {
     return MM_OK;
 }
 
-// Buffers, second stream and events of the split path, grown to what the run needs.
+#ifdef MM_EXPERIMENTS
+// Buffers, second stream and events of the split path, grown to what the run needs.  (The split path - walk kernel +
+// expander, mm_split.hip - measured slower than the fused kernel in round 3 and is a cross-check since: round 5 moved it
+// out of the shipped library, it exists in the EXPERIMENTS build only)
 int prepare_split(mm_workspace *ws, uint64_t tiles, uint64_t dump_bytes) {
     mm::SplitBuffers &b = ws->split;
     if (!b.aux) {
@@ -248,6 +254,7 @@ int prepare_split(mm_workspace *ws, uint64_t tiles, uint64_t dump_bytes) {
     b.redo_entries = have;
     return r;
 }
+#endif
 
 int make_view(const void *d_packed, uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
               mm::SeqView *v) {
@@ -290,6 +297,9 @@ int judge_run_error(mm_workspace *ws) {
     // asynchronous run that has not been checked yet may have raised it too (then the check reports it: at
     // worst valid work is repeated).
     if (!ws->async_unchecked) (void)hipMemsetAsync(ws->total + 2, 0, sizeof(unsigned long long), ws->stream);
+    // (the device's copy of the per-run word: consumed with the host's, so that no entry point that reads it back -
+    // the pipelined host path, the FASTA wrapper - ever meets a stale code.  ADVICE r4)
+    (void)hipMemsetAsync(ws->total + 1, 0, sizeof(unsigned long long), ws->stream);
     if (code == 1u) {
         if (ws->last_path == MM_PATH_SPLIT && !ws->no_split) {
             // the expander gave up waiting for a tile of the walk: this workspace keeps to the fused kernel
@@ -524,11 +534,13 @@ void mm_workspace_destroy(mm_workspace_t *ws) {
     if (ws->wamb) hipFree(ws->wamb);
     if (ws->copy_in) hipStreamDestroy(ws->copy_in);
     if (ws->copy_out) hipStreamDestroy(ws->copy_out);
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < 64; ++i) {
         if (ws->ev_in[i]) hipEventDestroy(ws->ev_in[i]);
         if (ws->ev_k[i]) hipEventDestroy(ws->ev_k[i]);
+        if (ws->ev_out[i]) hipEventDestroy(ws->ev_out[i]);
     }
     if (ws->h_pipe) hipHostFree(ws->h_pipe);
+    if (ws->d_pipe) hipFree(ws->d_pipe);
     if (ws->batch_seqs) hipFree(ws->batch_seqs);
     if (ws->batch_tiles) hipFree(ws->batch_tiles);
     if (ws->batch_offsets) hipFree(ws->batch_offsets);
@@ -707,7 +719,10 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
                                  uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
                                  uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
                                  uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_count,
-                                 bool append, const AmbArgs *amb = nullptr, bool *host_total_written = nullptr) {
+                                 bool append, const AmbArgs *amb = nullptr, bool *host_total_written = nullptr,
+                                 unsigned long long *host_word_dev = nullptr) {
+    // (host_word_dev: another page-locked word - as the device addresses it - to receive the total instead of
+    // ws->h_total[0]: the pipelined host path gives every chunk its own)
     // Stream operations of one run (round 4): the fused kernel alone.  Its look-back words are epoch-tagged (no
     // clear), a run that does not append ignores the old total (no clear), and its last tile stores the total to
     // d_count and - for the synchronous entry points, host_total_written != null - to the page-locked host word
@@ -785,6 +800,7 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
         }
         int lr = 0;
         bool split = false;
+#ifdef MM_EXPERIMENTS
         if (fused && !ws->no_split && mm::split_wanted(a)) {
             // split path: the walk dumps its lists, expander workgroups on a second stream write the positions
             uint64_t tiles = 0, dump_bytes = 0;
@@ -800,6 +816,7 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
                 if (lr == -2) lr = 0;  // no walk kernel for this plan: the fused kernel below
             }
         }
+#endif
         if (fused && !split && lr == 0) {
             r = grow_status(ws, mm::fused_status_words(a));
             if (r) return r;
@@ -808,11 +825,11 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
             r = next_status_epoch(ws, &a.status_epoch);
             if (r) return r;
             a.out.count_out = reinterpret_cast<unsigned long long *>(d_count);
-            a.out.total_host = host_total_written ? ws->h_total_dev : nullptr;
+            a.out.total_host = host_total_written ? (host_word_dev ? host_word_dev : ws->h_total_dev) : nullptr;
             lr = mm::launch_fused(a, ws->stream);
             if (lr == 0) {
                 count_stored = d_count != nullptr;
-                if (host_total_written && ws->h_total_dev) *host_total_written = true;
+                if (host_total_written && a.out.total_host) *host_total_written = true;
             }
             a.out.count_out = a.out.total_host = nullptr;
             if (lr == -2) {
@@ -1336,6 +1353,10 @@ static int run_device_sync(const mm_plan_t *plan, mm_workspace_t *ws, const void
         // page-locked word h_total[0] and a tile that raises an error stores the code into h_total[1] (flag_error),
         // so the host only waits for the stream.  (Rounds 1-3: two clears, the kernel, a copy - about 33 us a call.)
         bool host_written = false;
+        // (an *_async run that is still executing on this stream stores its error code into the same page-locked
+        // word: let it finish before the word is cleared for THIS run, or its error would be taken for ours - the
+        // sticky word keeps it for mm_workspace_check.  ADVICE r4)
+        if (ws->async_unchecked) MM_HIP(hipStreamSynchronize(ws->stream));
         ws->h_total[0] = 0;
         ws->h_total[1] = 0;
         // (no mapped host words on this runtime: the device's error word is read back below, so clear it first)
@@ -1408,105 +1429,233 @@ static int run_host_common(const mm_plan_t *plan, mm_workspace_t *ws, const void
     return MM_OK;
 }
 
-// Host entry point for long sequences, pipelined: the window range is cut into chunks; while chunk
-// c is computed, chunk c+1's bytes travel host -> device and chunk c-1's positions device -> host
-// on two copy streams (the link is full duplex; the kernel itself is ~2 % of the call).
-// Returns MM_PIPE_FALLBACK if the caller should take the one-shot path instead.
+// Host entry point for long sequences, pipelined: the window range is cut into chunks; while chunk c is computed,
+// the bytes of the chunks behind it travel host -> device and the positions of the chunks before it device -> host
+// (the link is full duplex; the kernel itself is ~4 % of the call).
+//
+// Round 5.  The first version waited for chunk c - 1's kernel on the host (an event), read its
+// total from a 16-byte device -> host copy queued on the kernel's stream, and only then queued that chunk's
+// device -> host copy and the NEXT chunk's upload and kernel.  The trace of a call (profiles/r05_host_path.txt) showed
+// what that costs: the 16-byte copy goes through the same copy engine as the 129 MB position copies and waits behind
+// them, the next kernel waits behind IT in stream order, and the host wakes up once per chunk - uploads 2.5 ms apart
+// instead of back to back.  Now the whole call is queued at once: all uploads, all kernels (each stores its running
+// total into a page-locked word of its own: no copies on the kernels' stream), and the host only polls those words to
+// size each chunk's device -> host copy, which waits for its kernel through an event on the device side.
+// The mechanisms of the two legs can be switched (results identical; A/B per box, tools/host_link_diag.sh):
+//   MM_HOST_OUT=engine (default: hipMemcpyAsync, a copy engine) | blit (a copy kernel that reads its range from device
+//   memory and stores into the caller's page-locked buffer: no host involvement at all) | direct (the fused kernel's own
+//   copy-out stores go straight into the caller's page-locked buffer);  MM_HOST_IN=engine | blit;  MM_PIPE_CHUNKS=n.
+// blit / direct need buffers the device can address (mm_host_alloc, hipHostMalloc, hipHostRegister); other buffers
+// keep the engines.  Returns MM_PIPE_FALLBACK if the caller should take the one-shot path instead.
 static const int MM_PIPE_FALLBACK = 1;
 static const uint64_t kPipeMinWindows = 48ull << 20;
+static const int kPipeMaxChunks = 64;
+static const unsigned long long kPipeUnset = ~0ull;
+
+// the device's address of page-locked host memory, or null (pageable memory, or the runtime does not say)
+static void *device_alias_of_host(const void *p) {
+    if (!p) return nullptr;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    return at.devicePointer;
+}
 
 static int run_host_pipelined(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed,
                               uint64_t base_offset, uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk,
                               uint64_t capacity, uint64_t *out_count) {
     const uint64_t l = (uint64_t)plan->k + plan->w - 1;
     const uint64_t n_w = n_bases >= l ? n_bases - l + 1 : 0;
-    if (!out_pos || n_w < kPipeMinWindows || mm::mm_env("MM_NO_PIPELINE")) return MM_PIPE_FALLBACK;
+    if (!out_pos || n_w < kPipeMinWindows || mm::mm_env("MM_NO_PIPELINE") || !ws->h_total_dev) return MM_PIPE_FALLBACK;
     const uint64_t cap = capacity < n_w ? capacity : n_w;
     if (cap == 0) return MM_PIPE_FALLBACK;
     const uint64_t bytes = (base_offset + n_bases + 3) / 4;
-    int r = grow(ws->d_out, ws->d_out_elems, cap, sizeof(uint32_t));
-    if (r) return r;
-    if (out_sk) {
-        r = grow(ws->d_sk, ws->d_sk_elems, cap, sizeof(uint32_t));
-        if (r) return r;
-    }
     if (!ws->copy_in) {
         MM_HIP(hipStreamCreateWithFlags(&ws->copy_in, hipStreamNonBlocking));
         MM_HIP(hipStreamCreateWithFlags(&ws->copy_out, hipStreamNonBlocking));
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < kPipeMaxChunks; ++i) {
             MM_HIP(hipEventCreateWithFlags(&ws->ev_in[i], hipEventDisableTiming));
             MM_HIP(hipEventCreateWithFlags(&ws->ev_k[i], hipEventDisableTiming));
+            MM_HIP(hipEventCreateWithFlags(&ws->ev_out[i], hipEventDisableTiming));
         }
-        MM_HIP(hipHostMalloc(reinterpret_cast<void **>(&ws->h_pipe), 16 * 2 * sizeof(unsigned long long),
-                             hipHostMallocDefault));
+        MM_HIP(hipHostMalloc(reinterpret_cast<void **>(&ws->h_pipe), kPipeMaxChunks * sizeof(unsigned long long),
+                             hipHostMallocMapped | hipHostMallocCoherent));
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, ws->h_pipe, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            dp = nullptr;
+        }
+        ws->h_pipe_dev = reinterpret_cast<unsigned long long *>(dp);
+        MM_HIP(hipMalloc(reinterpret_cast<void **>(&ws->d_pipe), (kPipeMaxChunks + 1) * sizeof(unsigned long long)));
     }
+    if (!ws->h_pipe_dev) return MM_PIPE_FALLBACK;
+    // mechanisms of the two legs
+    int out_mode = 0, in_mode = 0;  // 0 engine, 1 blit kernel, 2 (out only) the fused kernel's own stores
+    if (const char *e = mm::mm_env("MM_HOST_OUT")) out_mode = !strcmp(e, "blit") ? 1 : (!strcmp(e, "direct") ? 2 : 0);
+    if (const char *e = mm::mm_env("MM_HOST_IN")) in_mode = !strcmp(e, "blit") ? 1 : 0;
+    uint32_t *pos_alias = nullptr, *sk_alias = nullptr;
+    if (out_mode) {
+        pos_alias = static_cast<uint32_t *>(device_alias_of_host(out_pos));
+        sk_alias = out_sk ? static_cast<uint32_t *>(device_alias_of_host(out_sk)) : nullptr;
+        if (!pos_alias || (out_sk && !sk_alias)) out_mode = 0;
+    }
+    const uint8_t *in_alias = nullptr;
+    if (in_mode) {
+        in_alias = static_cast<const uint8_t *>(device_alias_of_host(packed));
+        if (!in_alias || (reinterpret_cast<uintptr_t>(in_alias) & 15u)) in_mode = 0;
+    }
+    int r = MM_OK;
+    if (out_mode != 2) {
+        r = grow(ws->d_out, ws->d_out_elems, cap, sizeof(uint32_t));
+        if (r == MM_OK && out_sk) r = grow(ws->d_sk, ws->d_sk_elems, cap, sizeof(uint32_t));
+        if (r) return r;
+    }
+    uint32_t *const k_pos = out_mode == 2 ? pos_alias : ws->d_out;
+    uint32_t *const k_sk = out_sk ? (out_mode == 2 ? sk_alias : ws->d_sk) : nullptr;
     uint64_t n_chunks = n_w / (24ull << 20);
-    if (n_chunks < 2) n_chunks = 2;
     if (n_chunks > 16) n_chunks = 16;
+    if (const char *e = mm::mm_env("MM_PIPE_CHUNKS")) n_chunks = (uint64_t)atoi(e);
+    if (n_chunks < 2) n_chunks = 2;
+    if (n_chunks > (uint64_t)kPipeMaxChunks) n_chunks = kPipeMaxChunks;
     const uint64_t chunk = (n_w + n_chunks - 1) / n_chunks;
+    n_chunks = (n_w + chunk - 1) / chunk;
     uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
+    const uint32_t kCopyWorkgroups = 64;
 
-    // (the chunk runs do not clear the per-run error word themselves; every chunk's copy of it is read below)
-    MM_HIP(hipMemsetAsync(ws->total + 1, 0, sizeof(unsigned long long), ws->stream));
-    uint64_t sent = 0;        // bytes already on their way to the device
-    uint64_t done_total = 0;  // running total after the last drained chunk
-    bool failed = false, over = false;
-    auto drain = [&](uint64_t c) -> int {
-        MM_HIP(hipEventSynchronize(ws->ev_k[c]));
-        const uint64_t tot = ws->h_pipe[2 * c], err = ws->h_pipe[2 * c + 1];
-        if (err) failed = true;
-        if (tot > cap) over = true;
-        if (!failed && !over && tot > done_total) {
-            MM_HIP(hipStreamWaitEvent(ws->copy_out, ws->ev_k[c], 0));
-            MM_HIP(hipMemcpyAsync(out_pos + done_total, ws->d_out + done_total,
-                                  (tot - done_total) * sizeof(uint32_t), hipMemcpyDeviceToHost, ws->copy_out));
-            if (out_sk)
-                MM_HIP(hipMemcpyAsync(out_sk + done_total, ws->d_sk + done_total,
-                                      (tot - done_total) * sizeof(uint32_t), hipMemcpyDeviceToHost, ws->copy_out));
-        }
-        done_total = tot;
-        return MM_OK;
-    };
-    for (uint64_t c = 0; c < n_chunks; ++c) {
+    // the per-run error word: raised by any chunk's kernel (flag_error stores the code into the page-locked word
+    // too), read once at the end.  An *_async run still in flight on this stream would raise it into the same word.
+    if (ws->async_unchecked) MM_HIP(hipStreamSynchronize(ws->stream));
+    ws->h_total[1] = 0;
+    for (uint64_t c = 0; c < n_chunks; ++c) ws->h_pipe[c] = kPipeUnset;
+    if (out_mode == 1) MM_HIP(hipMemsetAsync(ws->d_pipe, 0, sizeof(unsigned long long), ws->stream));  // (range of chunk 0 starts at 0)
+
+    // One host loop drives the call.  It queues uploads + kernels ahead (each kernel waits for its upload through an
+    // event on the device side and stores its running total into its own page-locked word), polls those words, and
+    // queues every chunk's device -> host copy the moment its size is known (the copy waits for its kernel on the
+    // device side).  ENGINE copies are throttled: at most `lim_in` uploads and `lim_out` downloads are in the runtime's
+    // hands at any time.  Measured (profiles/r05_host_path.txt): with all 16 uploads queued at once the call takes
+    // 49.6 ms - the sum of the two directions, no overlap at all - and 75 ms with 32 or 64, against 40.1 ms with 8; the
+    // runtime picks a copy engine per copy when it is QUEUED, queued uploads occupy engines while they wait for one
+    // another in stream order, and the downloads then land behind them.  A copy KERNEL has no such arbitration.
+    uint64_t lim_in = 2, lim_out = 2;
+    if (const char *e = mm::mm_env("MM_PIPE_IN_FLIGHT")) lim_in = (uint64_t)atoi(e);
+    if (const char *e = mm::mm_env("MM_PIPE_OUT_FLIGHT")) lim_out = (uint64_t)atoi(e);
+    if (in_mode == 1) lim_in = 0;    // (copy kernels: queue everything)
+    if (out_mode != 0) lim_out = 0;
+    uint64_t sent = 0;  // bytes already on their way to the device
+    auto submit_chunk = [&](uint64_t c) -> int {
         const uint64_t wb = c * chunk, we = (wb + chunk < n_w) ? wb + chunk : n_w;
-        if (wb >= we) {
-            n_chunks = c;
-            break;
-        }
-        // bytes that hold the bases of windows < we (the last one ends at base we + l - 2)
-        uint64_t need = (base_offset + we + l - 2) / 4 + 1;
+        // bytes that hold the bases of windows < we (the last one ends at base we + l - 2), in whole 16-byte units
+        uint64_t need = ((base_offset + we + l - 2) / 4 + 1 + 15) & ~15ull;
         if (need > bytes || we == n_w) need = bytes;
         if (need > sent) {
-            MM_HIP(hipMemcpyAsync(din + sent, packed + sent, need - sent, hipMemcpyHostToDevice, ws->copy_in));
+            if (in_mode == 1 && (need - sent) >= 16) {
+                const uint64_t n16 = (need - sent) / 16;  // (sent stays a multiple of 16 until the last chunk)
+                if (mm::launch_copy16(in_alias + sent, din + sent, n16, kCopyWorkgroups, ws->copy_in))
+                    return hip_fail(hipGetLastError(), "copy16");
+                if ((need - sent) % 16)
+                    MM_HIP(hipMemcpyAsync(din + sent + 16 * n16, packed + sent + 16 * n16, (need - sent) % 16,
+                                          hipMemcpyHostToDevice, ws->copy_in));
+            } else {
+                MM_HIP(hipMemcpyAsync(din + sent, packed + sent, need - sent, hipMemcpyHostToDevice, ws->copy_in));
+            }
             sent = need;
         }
         MM_HIP(hipEventRecord(ws->ev_in[c], ws->copy_in));
         MM_HIP(hipStreamWaitEvent(ws->stream, ws->ev_in[c], 0));
-        r = run_device_async_impl(plan, ws, ws->d_in, bytes + 16, base_offset, n_bases, wb, we, ws->d_out,
-                                  out_sk ? ws->d_sk : nullptr, cap, nullptr, c != 0);
-        if (r) return r;
-        MM_HIP(hipMemcpyAsync(&ws->h_pipe[2 * c], ws->total, 2 * sizeof(unsigned long long),
-                              hipMemcpyDeviceToHost, ws->stream));
+        bool hw = false;
+        const int rr = run_device_async_impl(plan, ws, ws->d_in, bytes + 16, base_offset, n_bases, wb, we, k_pos, k_sk, cap,
+                                             out_mode == 1 ? reinterpret_cast<uint64_t *>(ws->d_pipe + c + 1) : nullptr, c != 0,
+                                             nullptr, &hw, ws->h_pipe_dev + c);
+        if (rr) return rr;
+        // (families whose kernels do not store the total themselves: the device word, copied)
+        if (!hw)
+            MM_HIP(hipMemcpyAsync(&ws->h_pipe[c], ws->total, sizeof(unsigned long long), hipMemcpyDeviceToHost, ws->stream));
         MM_HIP(hipEventRecord(ws->ev_k[c], ws->stream));
-        if (c > 0) {
-            r = drain(c - 1);
+        if (out_mode == 1) {
+            MM_HIP(hipStreamWaitEvent(ws->copy_out, ws->ev_k[c], 0));
+            if (mm::launch_copy_range(ws->d_out, pos_alias, ws->d_pipe + c, cap, kCopyWorkgroups, ws->copy_out) ||
+                (out_sk && mm::launch_copy_range(ws->d_sk, sk_alias, ws->d_pipe + c, cap, kCopyWorkgroups, ws->copy_out)))
+                return hip_fail(hipGetLastError(), "copy_range");
+        }
+        return MM_OK;
+    };
+    auto done = [&](hipEvent_t ev, bool *yes) -> int {
+        const hipError_t q = hipEventQuery(ev);
+        *yes = q == hipSuccess;
+        if (q != hipSuccess && q != hipErrorNotReady) return hip_fail(q, "hipEventQuery");
+        if (q != hipSuccess) (void)hipGetLastError();
+        return MM_OK;
+    };
+    uint64_t next_in = 0, in_retired = 0;    // chunks submitted / whose upload is known to be complete
+    uint64_t next_out = 0, out_retired = 0;  // chunks whose count was taken / whose download is known to be complete
+    uint64_t done_total = 0;
+    bool over = false, broken = false;
+    uint32_t idle = 0;
+    while (next_out < n_chunks && !broken) {
+        bool progress = false;
+        while (next_in < n_chunks && (lim_in == 0 || next_in - in_retired < lim_in)) {
+            r = submit_chunk(next_in++);
             if (r) return r;
+            progress = true;
         }
+        bool yes = false;
+        if (lim_in && in_retired < next_in) {
+            r = done(ws->ev_in[in_retired], &yes);
+            if (r) return r;
+            if (yes) ++in_retired, progress = true;
+        }
+        if (lim_out && out_retired < next_out) {
+            r = done(ws->ev_out[out_retired], &yes);
+            if (r) return r;
+            if (yes) ++out_retired, progress = true;
+        }
+        if (next_out < next_in && (lim_out == 0 || next_out - out_retired < lim_out)) {
+            const uint64_t c = next_out;
+            volatile unsigned long long *word = ws->h_pipe + c;
+            unsigned long long tot = *word;
+            if (tot == kPipeUnset && (++idle & 255u) == 0u) {
+                r = done(ws->ev_k[c], &yes);
+                if (r) return r;
+                if (yes) {  // the kernel is done: the word is final
+                    tot = *word;
+                    if (tot == kPipeUnset) broken = true;  // (no kernel stored it - a failed launch the error word names)
+                }
+            }
+            if (tot != kPipeUnset) {
+                if (tot < done_total) {
+                    broken = true;
+                } else {
+                    if (tot > cap) over = true;
+                    const uint64_t upto = tot < cap ? tot : cap;
+                    if (out_mode == 0 && upto > done_total) {
+                        MM_HIP(hipStreamWaitEvent(ws->copy_out, ws->ev_k[c], 0));
+                        MM_HIP(hipMemcpyAsync(out_pos + done_total, ws->d_out + done_total,
+                                              (upto - done_total) * sizeof(uint32_t), hipMemcpyDeviceToHost, ws->copy_out));
+                        if (out_sk)
+                            MM_HIP(hipMemcpyAsync(out_sk + done_total, ws->d_sk + done_total,
+                                                  (upto - done_total) * sizeof(uint32_t), hipMemcpyDeviceToHost, ws->copy_out));
+                    }
+                    if (lim_out) MM_HIP(hipEventRecord(ws->ev_out[c], ws->copy_out));
+                    done_total = tot;
+                    ++next_out;
+                    progress = true;
+                }
+            }
+        }
+        if (!progress) __builtin_ia32_pause();
     }
-    if (n_chunks > 0) {
-        r = drain(n_chunks - 1);
-        if (r) return r;
-    }
-    MM_HIP(hipStreamSynchronize(ws->copy_out));
     MM_HIP(hipStreamSynchronize(ws->stream));
-    if (failed) {
-        // a look-back spin ran out in some chunk: redo the whole call in ticket mode, one shot
-        if (ws->force_ticket) {
-            g_last_error = "look-back scan timed out in ticket mode";
-            return MM_ERR_HIP;
-        }
-        ws->force_ticket = true;
-        return MM_PIPE_FALLBACK;
+    MM_HIP(hipStreamSynchronize(ws->copy_out));
+    const int je = judge_run_error(ws);
+    if (je < 0) return je;
+    if (je == 1) return MM_PIPE_FALLBACK;  // a look-back spin ran out in some chunk: the whole call again, one shot, ticket mode
+    if (broken) {
+        g_last_error = "mm_run_host: a chunk's kernel finished without storing its count";
+        return MM_ERR_HIP;
     }
     if (out_count) *out_count = done_total;
     return over || done_total > capacity ? MM_ERR_CAPACITY : MM_OK;
@@ -1793,17 +1942,22 @@ int mm_pack_ascii_device_async(mm_workspace_t *ws, const uint8_t *d_ascii, uint6
     return MM_OK;
 }
 
-// Which FASTA packer a call takes: 0 the two passes of mask arithmetic (mm_fasta2.hip: the default since late round 4 -
-// no look-back, no tables with limits, nothing to fall back from), 1 the one-pass kernel over lines (rounds 3-4's default;
-// MM_FASTA_KERNEL=lines or MM_FASTA_ONEPASS=1), 2 the three-pass kernels (MM_FASTA_KERNEL=three or MM_FASTA_ONEPASS=0;
-// also what the one-pass kernel falls back to).  The older two stay as cross-checks (tests/test_gpu_fasta.py).
+// Which FASTA packer a call takes.  The product has ONE: the two passes of mask arithmetic (mm_fasta2.hip - no
+// look-back, no tables with limits, nothing to fall back from).  The packers of rounds 2-4 (mm_fasta.hip: the one-pass
+// kernel over lines, 1, and the three-pass kernels, 2) are cross-checks in the EXPERIMENTS build only since round 5
+// (VERDICT r4 item 5): MM_FASTA_KERNEL=lines|three / MM_FASTA_ONEPASS=1|0 are read there and nowhere else.
 static int fasta_packer_choice(const mm_workspace_t *ws) {
+#ifdef MM_EXPERIMENTS
     const char *k = mm::mm_env("MM_FASTA_KERNEL"), *one = mm::mm_env("MM_FASTA_ONEPASS");
     int c = 0;
     if (k) c = !strcmp(k, "lines") ? 1 : (!strcmp(k, "three") ? 2 : 0);
     else if (one) c = one[0] == '0' ? 2 : 1;
     if (c == 1 && (ws->fasta_three_pass || ws->fasta_three_once)) c = 2;
     return c;
+#else
+    (void)ws;
+    return 0;
+#endif
 }
 
 int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes,
@@ -1821,7 +1975,12 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
     }
     if (!d_text || (!d_packed && packed_capacity_bytes)) return MM_ERR_NULL;
     uint8_t *sp = reinterpret_cast<uint8_t *>(ws->scratch);
-    const uint64_t need_a = mm::fasta_scratch_bytes(n_bytes), need_b = mm::fasta2_scratch_bytes(n_bytes);
+#ifdef MM_EXPERIMENTS
+    const uint64_t need_a = mm::fasta_scratch_bytes(n_bytes);
+#else
+    const uint64_t need_a = 0;
+#endif
+    const uint64_t need_b = mm::fasta2_scratch_bytes(n_bytes);
     const int r = grow(sp, ws->scratch_bytes, need_a > need_b ? need_a : need_b, 1);
     ws->scratch = sp;
     if (r) return r;
@@ -1834,8 +1993,11 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
             return hip_fail(hipGetLastError(), "fasta_pack2");
         return MM_OK;
     }
+#ifndef MM_EXPERIMENTS
+    return MM_ERR_HIP;  // (not reached: the product's choice is always 0)
+#else
     // The one-pass kernel over lines (mm_fasta.hip: the text read once, one decoupled look-back between 32 KB chunks)
-    // is the default since its third version (round 3: 0.96 ms for 1 GiB of 60-base lines against 1.66 ms for the
+    // was the default since its third version (round 3: 0.96 ms for 1 GiB of 60-base lines against 1.66 ms for the
     // three passes); MM_FASTA_ONEPASS=0 takes the three-pass kernels, which also serve texts the one-pass kernel
     // gives up on (lines shorter than 16 bytes on average - more than 2 048 line segments in a chunk; a look-back
     // time-out).
@@ -1848,12 +2010,15 @@ int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
                               reinterpret_cast<uint32_t *>(ws->total + 1)))
         return hip_fail(hipGetLastError(), "fasta_pack");
     return MM_OK;
+#endif
 }
 
 // FASTQ (round 4): four-line records, the sequence of every record packed like a FASTA record's (mm_fastq.hip).
-int mm_fastq_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
-                               uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
-                               uint64_t max_records, uint64_t *d_counts) {
+// The packer tells a byte's role from the number of newlines in front of it, so the text has to START with its first
+// record's '@': `pos_bias` is what a caller that cut blank bytes off the front adds back to the records' text positions.
+static int fastq_pack_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
+                            uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
+                            uint64_t max_records, uint64_t *d_counts, uint64_t pos_bias) {
     if (!ws || !d_counts || !d_rec_base) return MM_ERR_NULL;
     if (n_bytes >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     if (reinterpret_cast<uintptr_t>(d_packed) % 4 != 0) return MM_ERR_NULL;
@@ -1871,9 +2036,16 @@ int mm_fastq_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
     if (mm::launch_fastq_pack(d_text, n_bytes, d_packed, packed_capacity_bytes & ~3ull,
                               reinterpret_cast<unsigned long long *>(d_rec_base),
                               reinterpret_cast<unsigned long long *>(d_rec_text_pos), max_records,
-                              reinterpret_cast<unsigned long long *>(d_counts), ws->scratch, ws->stream))
+                              reinterpret_cast<unsigned long long *>(d_counts), ws->scratch, ws->stream, pos_bias))
         return hip_fail(hipGetLastError(), "fastq_pack");
     return MM_OK;
+}
+
+int mm_fastq_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
+                               uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
+                               uint64_t max_records, uint64_t *d_counts) {
+    return fastq_pack_async(ws, d_text, n_bytes, d_packed, packed_capacity_bytes, d_rec_base, d_rec_text_pos, max_records,
+                            d_counts, 0);
 }
 
 int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
@@ -1895,9 +2067,12 @@ int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_b
         size_t i = 0;
         while (i < nh && (head[i] == ' ' || head[i] == '\t' || head[i] == '\r' || head[i] == '\n')) ++i;
         if (i < nh && head[i] == '@') {
-            // FASTQ (needletail::parse_fastx tells the formats apart by this byte too): the four-line packer
-            const int r = mm_fastq_pack_device_async(ws, d_text, n_bytes, d_packed, packed_capacity_bytes, d_rec_base,
-                                                     d_rec_text_pos, max_records, d_counts);
+            // FASTQ (needletail::parse_fastx tells the formats apart by this byte too): the four-line packer, which
+            // counts lines from the start of its text - so it gets the text from the '@' on (blank lines or spaces in
+            // front of the first record used to shift every line's role by one: ADVICE r4) and adds the cut back to the
+            // records' text positions
+            const int r = fastq_pack_async(ws, d_text + i, n_bytes - i, d_packed, packed_capacity_bytes, d_rec_base,
+                                           d_rec_text_pos, max_records, d_counts, i);
             if (r) return r;
             MM_HIP(hipMemcpyAsync(out_counts, d_counts, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ws->stream));
             MM_HIP(hipStreamSynchronize(ws->stream));
@@ -1954,6 +2129,57 @@ int mm_clock_probe_end(mm_workspace_t *ws, double *ghz) {
         real += (double)h[2 * b + 1];
     }
     *ghz = real > 0 ? cyc / real * 0.1 : 0.0;  // the real-time counter ticks at 100 MHz
+    return MM_OK;
+}
+
+// Diagnostics: what the host link of this box moves - each direction alone and BOTH AT ONCE (two streams, the copy
+// engines), between caller buffers and device memory.  bench.py prints it beside `end_to_end`: the floor of mm_run_host is
+// set by the rate at which the two directions run TOGETHER, which is less than the sum of the one-way rates (97 against
+// 57.6 + 57.1 GB/s on the boxes of round 5).  out_GBps[0] = host -> device alone, [1] = device -> host alone, [2] = the sum
+// of both while they run together.  host_in / host_out: `bytes` each, page-locked for meaningful figures.
+int mm_link_probe(mm_workspace_t *ws, const void *host_in, void *host_out, uint64_t bytes, double *out_GBps) {
+    if (!ws || !host_in || !host_out || !out_GBps || bytes == 0) return MM_ERR_NULL;
+    MM_HIP(hipSetDevice(ws->device));
+    void *d_a = nullptr, *d_b = nullptr;
+    hipStream_t s1 = nullptr, s2 = nullptr;
+    int rc = MM_OK;
+    auto cleanup = [&]() {
+        if (s1) hipStreamDestroy(s1);
+        if (s2) hipStreamDestroy(s2);
+        if (d_a) hipFree(d_a);
+        if (d_b) hipFree(d_b);
+    };
+#define MM_LP(x)                                              \
+    do {                                                      \
+        const hipError_t e_ = (x);                            \
+        if (e_ != hipSuccess) {                               \
+            rc = hip_fail(e_, #x);                            \
+            cleanup();                                        \
+            return rc;                                        \
+        }                                                     \
+    } while (0)
+    MM_LP(hipMalloc(&d_a, bytes));
+    MM_LP(hipMalloc(&d_b, bytes));
+    MM_LP(hipMemset(d_b, 0, bytes));
+    MM_LP(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+    MM_LP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    for (int what = 0; what < 3; ++what) {
+        double best = 0.0;
+        for (int rep = 0; rep < 4; ++rep) {  // (the first repetition warms up)
+            MM_LP(hipDeviceSynchronize());
+            const auto t0 = std::chrono::steady_clock::now();
+            if (what != 1) MM_LP(hipMemcpyAsync(d_a, host_in, bytes, hipMemcpyHostToDevice, s1));
+            if (what != 0) MM_LP(hipMemcpyAsync(host_out, d_b, bytes, hipMemcpyDeviceToHost, s2));
+            MM_LP(hipStreamSynchronize(s1));
+            MM_LP(hipStreamSynchronize(s2));
+            const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const double rate = (what == 2 ? 2.0 : 1.0) * (double)bytes / t / 1e9;
+            if (rep && rate > best) best = rate;
+        }
+        out_GBps[what] = best;
+    }
+#undef MM_LP
+    cleanup();
     return MM_OK;
 }
 

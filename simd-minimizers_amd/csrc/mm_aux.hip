@@ -408,4 +408,59 @@ int launch_clock_probe(unsigned long long *d_out, uint32_t workgroups, uint64_t 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ---- copies between device memory and page-locked HOST memory done by a kernel instead of a copy engine (the host
+// entry point's alternative mechanisms, mm_api.hip run_host_pipelined; measured against the engines by
+// tools/ubench/link_duplex.hip).  Both keep to a few workgroups: the link moves ~55 GB/s, which 64 workgroups saturate,
+// and the fused kernel runs beside them.
+typedef uint32_t copy_v4u __attribute__((ext_vector_type(4)));
+
+// dst[lo .. hi) = src[lo .. hi) in dwords, the range read from DEVICE memory (range[0], range[1]: the running totals
+// of two consecutive chunk kernels), hi cut to cap: the device -> host leg of a chunk with no host round trip.
+// 16-byte stores aligned to dst (full PCIe write payloads), the few dwords either side of them singly.
+__global__ __launch_bounds__(kBlockThreads) void copy_range_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
+                                                                   const unsigned long long *__restrict__ range,
+                                                                   unsigned long long cap) {
+    unsigned long long lo = range[0], hi = range[1];
+    hi = hi < cap ? hi : cap;
+    if (lo >= hi) return;
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long nthreads = (unsigned long long)gridDim.x * blockDim.x;
+    // first dword index >= lo at which dst is 16-byte aligned
+    const unsigned long long mis = (reinterpret_cast<uintptr_t>(dst + lo) >> 2) & 3ull;
+    unsigned long long body = lo + ((4ull - mis) & 3ull);
+    if (body > hi) body = hi;
+    const unsigned long long n16 = (hi - body) >> 2, tail = body + (n16 << 2);
+    if (tid < body - lo) __builtin_nontemporal_store(src[lo + tid], &dst[lo + tid]);
+    if (tid < hi - tail) __builtin_nontemporal_store(src[tail + tid], &dst[tail + tid]);
+    const uint32_t *s = src + body;
+    copy_v4u *d16 = reinterpret_cast<copy_v4u *>(dst + body);
+    for (unsigned long long i = tid; i < n16; i += nthreads) {
+        copy_v4u v;  // (src is only dword aligned relative to dst: four dword loads, one 16-byte store)
+        v.x = s[4 * i], v.y = s[4 * i + 1], v.z = s[4 * i + 2], v.w = s[4 * i + 3];
+        __builtin_nontemporal_store(v, &d16[i]);
+    }
+}
+
+int launch_copy_range(const uint32_t *d_src, uint32_t *dst_host_alias, const unsigned long long *d_range, uint64_t cap,
+                      uint32_t workgroups, hipStream_t stream) {
+    hipLaunchKernelGGL(copy_range_kernel, dim3(workgroups), dim3(kBlockThreads), 0, stream, d_src, dst_host_alias, d_range,
+                       (unsigned long long)cap);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// dst[0 .. n16) = src[0 .. n16) in 16-byte units, both 16-byte aligned: the host -> device leg (src = the device's
+// address of page-locked host memory)
+__global__ __launch_bounds__(kBlockThreads) void copy16_kernel(const copy_v4u *__restrict__ src, copy_v4u *__restrict__ dst,
+                                                               unsigned long long n16) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        dst[i] = __builtin_nontemporal_load(&src[i]);
+}
+
+int launch_copy16(const void *src, void *dst, uint64_t n16, uint32_t workgroups, hipStream_t stream) {
+    hipLaunchKernelGGL(copy16_kernel, dim3(workgroups), dim3(kBlockThreads), 0, stream,
+                       reinterpret_cast<const copy_v4u *>(src), reinterpret_cast<copy_v4u *>(dst), (unsigned long long)n16);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 }  // namespace mm

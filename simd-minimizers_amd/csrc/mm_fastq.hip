@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kFqThreads) void fastq_pack_kernel(const uint8_t *_
                                                                 uint32_t *__restrict__ out32, uint64_t out_dwords,
                                                                 unsigned long long *__restrict__ rec_base,
                                                                 unsigned long long *__restrict__ rec_pos,
-                                                                uint64_t max_records) {
+                                                                uint64_t max_records, uint64_t pos_bias) {
     __shared__ uint32_t s_part[kFqPieces][kFqWaves];
     // The chunk's output is assembled in LDS (at most 16 384 bases = 1024 dwords, + 1 for its bit offset, + 2 for the
     // last thread's three-dword OR) and leaves as whole dwords; only the first and the last dword, which the chunk
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kFqThreads) void fastq_pack_kernel(const uint8_t *_
             const unsigned long long r = r0 + k++;
             if (r < max_records) {
                 rec_base[r] = o0 + (uint32_t)__popc(sm & ((1u << i) - 1u));
-                if (rec_pos) rec_pos[r] = c0 + (uint64_t)p * kFqPiece + (uint64_t)threadIdx.x * kFqBytesPerThread + i;
+                if (rec_pos) rec_pos[r] = pos_bias + c0 + (uint64_t)p * kFqPiece + (uint64_t)threadIdx.x * kFqBytesPerThread + i;
             }
         }
     }
@@ -348,7 +348,8 @@ uint64_t fastq_scratch_bytes(uint64_t n_bytes) {
 
 int launch_fastq_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed, uint64_t packed_capacity_bytes,
                       unsigned long long *d_rec_base, unsigned long long *d_rec_pos, uint64_t max_records,
-                      unsigned long long *d_counts, void *scratch, hipStream_t stream) {
+                      unsigned long long *d_counts, void *scratch, hipStream_t stream, uint64_t pos_bias) {
+    // (pos_bias: added to every record's text position - the caller passed the text from its first '@' on)
     const uint64_t chunks = fastq_chunks(n_bytes), groups = fastq_groups(chunks);
     if (chunks == 0 || chunks >= (1ull << 31)) return -1;
     unsigned long long *q = static_cast<unsigned long long *>(scratch);
@@ -370,7 +371,7 @@ int launch_fastq_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed
     hipLaunchKernelGGL(fastq_groups_kernel, dim3((uint32_t)groups), dim3(kFqGroup), 0, stream, sc, chunks);
     hipLaunchKernelGGL(fastq_resolve_kernel, dim3(1), dim3(kFqGroup), 0, stream, sc, groups);
     hipLaunchKernelGGL(fastq_pack_kernel, dim3((uint32_t)chunks), dim3(kFqThreads), 0, stream, d_text, n_bytes, sc,
-                       reinterpret_cast<uint32_t *>(d_packed), out_dwords, d_rec_base, d_rec_pos, max_records);
+                       reinterpret_cast<uint32_t *>(d_packed), out_dwords, d_rec_base, d_rec_pos, max_records, pos_bias);
     hipLaunchKernelGGL(fastq_finish_kernel, dim3(1), dim3(1), 0, stream, sc, groups, d_rec_base, max_records, d_counts);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

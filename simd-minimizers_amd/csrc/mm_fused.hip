@@ -577,14 +577,15 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         if (resident_slots(kr, gd.lds_bytes, &per_cu, &cus)) {
             const uint64_t slots = (uint64_t)per_cu * cus;
             if (nwin <= slots * (uint64_t)gd.NB && nwin * 10u >= slots * (uint64_t)gd.NB * 6u) {
+                // (the legal maximum LAST: gd.nblk carries geometry()'s bounds - 16-bit super-k-mer entries, 8-bit
+                // entries, the LDS - and is below 6 for super-k-mer runs with w >= 86; the lanes are then rebuilt
+                // by geometry() itself, so that every bound is applied again.  ADVICE r4, high)
                 uint32_t nb = (uint32_t)((nwin + slots * blk_w - 1) / (slots * blk_w));
-                nb = nb < 6u ? 6u : (nb > gd.nblk ? gd.nblk : nb);
-                g.nblk = nb;
-                g.S = a.w * nb;
-                g.list_cap = list_capacity(a.w, a.mode, g.S);
-                g.lds_bytes = g.list_cap * stride_of(a);
-                g.NB = kFusedThreads * g.S;
-                g.nblocks = (nwin + g.NB - 1) / g.NB;
+                nb = nb < 6u ? 6u : nb;
+                nb = nb > gd.nblk ? gd.nblk : nb;
+                RunArgs one = a;
+                one.nblk = nb;
+                g = geometry(one);
             }
         }
     }
@@ -678,6 +679,10 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------ split path (walk + expander)
+// EXPERIMENTS build only since round 5: measured slower than the fused kernel in round 3
+// (profiles/r03_split_ab.txt), kept as an independent cross-check of the copy-out; the shipped library carries neither
+// this launcher nor mm_split.hip / mm_walk_inst.hip and does not read MM_SPLIT*.
+#ifdef MM_EXPERIMENTS
 namespace {
 
 // prebuilt walk kernels (mm_walk_inst.hip); everything else is specialised at first use
@@ -826,6 +831,7 @@ int launch_split(const RunArgs &a, const SplitBuffers &b, hipStream_t stream) {
     if (a.timing_stop) hipEventRecord(a.timing_stop, stream);
     return 0;
 }
+#endif  // MM_EXPERIMENTS
 
 // ------------------------------------------------------------------ reads mode
 namespace {

@@ -152,7 +152,11 @@ int launch_fasta_pack2(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packe
 uint64_t fastq_scratch_bytes(uint64_t n_bytes);
 int launch_fastq_pack(const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed, uint64_t packed_capacity_bytes,
                       unsigned long long *d_rec_base, unsigned long long *d_rec_pos, uint64_t max_records,
-                      unsigned long long *d_counts, void *scratch, hipStream_t stream);
+                      unsigned long long *d_counts, void *scratch, hipStream_t stream, uint64_t pos_bias = 0);
+// copies to / from page-locked host memory by a kernel (mm_aux.hip; the host entry point's alternative mechanisms)
+int launch_copy_range(const uint32_t *d_src, uint32_t *dst_host_alias, const unsigned long long *d_range, uint64_t cap,
+                      uint32_t workgroups, hipStream_t stream);
+int launch_copy16(const void *src, void *dst, uint64_t n16, uint32_t workgroups, hipStream_t stream);
 // diagnostics: shader clock while other kernels run (out: 2 words per workgroup)
 int launch_clock_probe(unsigned long long *d_out, uint32_t workgroups, uint64_t ticks, hipStream_t stream);
 int launch_generate(uint64_t seed, uint64_t first_base, uint64_t n, uint8_t *d_packed,

@@ -162,10 +162,18 @@ def measure(name, ws, dev, warm=3, reps=5):
     import statistics
 
     import torch
+    import time
     c = component(name, ws, dev)
-    for _ in range(warm):
-        c["step"]()
-    torch.cuda.synchronize(dev)
+    # warm-up by TIME as well as by count (round 5): a component's set-up - allocation, synthetic input - leaves the chip
+    # idle long enough for its clocks to drop, and three steps of a 0.7 ms kernel do not bring them back: the driver read
+    # READS_SK at 0.884 ms in rounds 3 and 4 where a warmed-up run reads 0.74 (profiles/r05_reads_sk.txt)
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(warm):
+            c["step"]()
+        torch.cuda.synchronize(dev)
+        if time.perf_counter() - t0 > 0.06:
+            break
     ms = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -37,3 +37,14 @@ def gpu(sm):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return sm.default_workspace(0)
+
+
+@pytest.fixture(scope="session")
+def exp_build(sm):
+    """The cross-check kernels - the FASTA packers of rounds 2-4, the split path - and every MM_* switch that selects them
+    exist in the EXPERIMENTS build of the library only (round 5): tests of them skip under the product
+    and run in a child pytest that loads that build through MM_LIB_PATH
+    (tests/test_gpu_round5.py::test_cross_checks_in_the_experiments_build)."""
+    if not os.path.basename(sm.LIB_PATH).endswith("_exp.so"):
+        pytest.skip("cross-check kernels live in the experiments build (run with MM_LIB_PATH=.../libsimd_minimizers_amd_exp.so)")
+    return True

@@ -18,6 +18,9 @@ def packer_flavour(request, monkeypatch):
         monkeypatch.delenv("MM_FASTA_ONEPASS", raising=False)
         monkeypatch.delenv("MM_FASTA_KERNEL", raising=False)
     else:
+        # (round 5: the two older packers are cross-checks in the EXPERIMENTS build only - these flavours run in the
+        # child pytest of tests/test_gpu_round5.py::test_cross_checks_in_the_experiments_build)
+        request.getfixturevalue("exp_build")
         monkeypatch.setenv("MM_FASTA_ONEPASS", "1" if request.param == "one-pass" else "0")
 
 

@@ -232,7 +232,9 @@ def test_product_ignores_experiment_switches(sm, oracle, gpu, monkeypatch):
         assert len(rec) == 2
         monkeypatch.delenv(name)
     so = open(sm.LIB_PATH, "rb").read()
-    for name in (b"MM_DEBUG", b"MM_JIT_DEFS", b"MM_JIT_FORCE", b"MM_FASTA_DEBUG", b"MM_TRACE"):
+    for name in (b"MM_DEBUG", b"MM_JIT_DEFS", b"MM_JIT_FORCE", b"MM_FASTA_DEBUG", b"MM_TRACE",
+                 # round 5: the cross-check kernels and their switches left the product too
+                 b"MM_SPLIT", b"MM_FASTA_KERNEL", b"MM_FASTA_ONEPASS", b"fasta_lines_kernel", b"expand_kernel"):
         assert name not in so, name
 
 

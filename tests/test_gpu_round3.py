@@ -26,7 +26,7 @@ def _dev(out, c):
 
 # ------------------------------------------------------------------ split path
 @pytest.mark.parametrize("canon", [False, True])
-def test_split_path_matches_oracle(sm, oracle, gpu, monkeypatch, canon):
+def test_split_path_matches_oracle(sm, oracle, gpu, monkeypatch, canon, exp_build):
     """walk_kernel + expander (mm_split.hip) == oracle element by element; the fused kernel gives the same."""
     import torch
     monkeypatch.setenv("MM_SPLIT", "1")
@@ -68,7 +68,7 @@ def test_split_path_matches_oracle(sm, oracle, gpu, monkeypatch, canon):
     assert gpu.last_path() == sm.PATH_FUSED and np.array_equal(_dev(out, c), want)
 
 
-def test_split_path_redo_and_flavours(sm, oracle, gpu, monkeypatch):
+def test_split_path_redo_and_flavours(sm, oracle, gpu, monkeypatch, exp_build):
     """Low-complexity input (lists overflow: the redo pass), skip-ambiguous windows, and plans whose walk
     kernel is specialised at run time (super-k-mer indices, closed syncmers)."""
     import torch
@@ -116,7 +116,7 @@ def test_split_path_redo_and_flavours(sm, oracle, gpu, monkeypatch):
     assert c == len(want) and np.array_equal(_dev(out, c), want)
 
 
-def test_split_path_host_pipeline(sm, oracle, gpu, monkeypatch):
+def test_split_path_host_pipeline(sm, oracle, gpu, monkeypatch, exp_build):
     """mm_run_host on a sequence long enough for the pipelined path (chunks appended back to back: the
     expander takes the running total as its carry)."""
     monkeypatch.setenv("MM_SPLIT", "1")

@@ -149,7 +149,7 @@ def _random_fasta(rng, n):
     return t
 
 
-def test_fasta_packers_agree_on_random_texts(sm, oracle, gpu, monkeypatch):
+def test_fasta_packers_agree_on_random_texts(sm, oracle, gpu, monkeypatch, exp_build):
     """two-pass packer == one-pass packer == three-pass kernels (packed bytes, record tables, counts) on random texts around chunk
     multiples (tests/test_gpu_fasta.py holds both against the oracle's reader)"""
     import torch

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs ONE secondary configuration a few times (the command rocprofv3 wraps for the per-configuration
-profiles under profiles/): tools/run_config.py <C2|FWD|C4|C5|READS|C3|SHARD|READS_SK|SKIP|VALUES|PACK|FASTA|FASTQ> [steps] [warmup].
+profiles under profiles/): tools/run_config.py <C2|FWD|C4|C5|SK|READS|C3|SHARD|READS_SK|SKIP|VALUES|PACK|FASTA|FASTQ> [steps] [warmup].
 Prints kernel time by HIP events (median) as one JSON line.  Measurement aid, not part of the product."""
 import json
 import os
@@ -34,18 +34,21 @@ if cfg in workloads.COMPONENTS:  # the rows either side of the path (SURVEY.md 8
     sys.exit(0)
 
 N = 3_100_000_000
-if cfg in ("C2", "FWD", "C3", "C5"):
+if cfg in ("C2", "FWD", "C3", "C5", "SK"):
     b, n, seed, dens = {"C2": (sm.minimizers(21, 11), 268_435_456, 2, 2 / 12),
                         "FWD": (sm.minimizers(21, 11), N, 3, 2 / 12),
                         "C3": (sm.canonical_minimizers(21, 11), N, 3, 2 / 12),
-                        "C5": (sm.canonical_closed_syncmers(15, 17), N, 3, 2 / 17)}[cfg]
+                        "C5": (sm.canonical_closed_syncmers(15, 17), N, 3, 2 / 17),
+                        # canonical minimizers + super-k-mer indices at full size (bench.py's SK row)
+                        "SK": (sm.canonical_minimizers(21, 11), N, 3, 2 / 12)}[cfg]
     b = b.workspace(ws)
     d = gen(n, seed)
     out = torch.empty(int(n * dens * 1.15) + 4096, dtype=torch.int32, device=dev)
     cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    sk = torch.empty_like(out) if cfg == "SK" else None
 
     def step():
-        b.run_device(d, n, out, sync=False, d_count=cnt)
+        b.run_device(d, n, out, sync=False, d_count=cnt, out_sk=sk)
 
     def n_out():
         return int(cnt.item())
@@ -111,7 +114,7 @@ for _ in range(steps):
 ws.check()
 med = statistics.median(ms)
 no = n_out()
-alg = (n + 3) // 4 + 4 * no + (8 * 8_000_000 if cfg == "READS" else 0)
+alg = (n + 3) // 4 + 4 * no * (2 if cfg == "SK" else 1) + (8 * 8_000_000 if cfg == "READS" else 0)
 print(json.dumps({"config": cfg, "bases": n, "outputs": no, "kernel_ms_median": round(med, 4),
                   "kernel_ms_all": [round(x, 4) for x in ms], "Gbases_per_s": round(n / med / 1e6, 1),
                   "algorithmic_bytes": alg, "frac_of_8TBps": round(alg / (med * 1e-3) / 8e12, 4)}))

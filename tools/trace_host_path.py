@@ -1,0 +1,39 @@
+"""Condense `rocprofv3 --memory-copy-trace --kernel-trace --output-format csv` of tools/gpu_host_trace.py into a timeline of
+the LAST mm_run_host call: every copy (direction, agents, start, end), every fused-kernel launch, and how much of the time
+the two copy directions were in flight together.  Usage: trace_host_path.py <dir with *_memory_copy_trace.csv> [calls]"""
+import csv, glob, os, sys
+d = sys.argv[1]
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+def rows(pat):
+    out = []
+    for f in glob.glob(os.path.join(d, "**", pat), recursive=True):
+        out += list(csv.DictReader(open(f)))
+    return out
+cp = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Direction"].replace("MEMORY_COPY_", ""), r["Source_Agent_Id"], r["Destination_Agent_Id"]) for r in rows("*memory_copy_trace.csv")]
+kn = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows("*kernel_trace.csv") if "fused_kernel" in r["Kernel_Name"]]
+cp.sort(); kn.sort()
+if not kn:
+    sys.exit("no fused-kernel launches in the trace")
+per_call = len(kn) // calls
+last = kn[-per_call:]
+t0 = min(last[0][0], min((c[0] for c in cp if c[0] >= last[0][0] - 5_000_000), default=last[0][0]))
+t1 = max([k[1] for k in last] + [c[1] for c in cp if c[0] >= t0])
+print(f"last call: {per_call} chunks, {(t1 - t0) / 1e6:.2f} ms from the first copy / kernel to the last end")
+ev = [(c[0], c[1], f"copy {c[2]:<16} {c[3]} -> {c[4]}") for c in cp if c[0] >= t0] + [(k[0], k[1], "fused kernel") for k in last]
+ev.sort()
+for s, e, what in ev:
+    print(f"  {(s - t0) / 1e6:8.3f} .. {(e - t0) / 1e6:8.3f} ms  ({(e - s) / 1e6:7.3f})  {what}")
+def busy(direction):
+    iv = sorted((c[0], c[1]) for c in cp if c[0] >= t0 and c[2] == direction)
+    return iv
+def total(iv):
+    return sum(e - s for s, e in iv)
+def overlap(a, b):
+    o = 0
+    for s1, e1 in a:
+        for s2, e2 in b:
+            o += max(0, min(e1, e2) - max(s1, s2))
+    return o
+h2d, d2h = busy("HOST_TO_DEVICE"), busy("DEVICE_TO_HOST")
+print(f"copy engines busy: H2D {total(h2d) / 1e6:.2f} ms in {len(h2d)} copies, D2H {total(d2h) / 1e6:.2f} ms in {len(d2h)} copies, "
+      f"both directions in flight together {overlap(h2d, d2h) / 1e6:.2f} ms")
