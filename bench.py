@@ -447,6 +447,24 @@ def main():
         ws.enable_timing(False)
         return statistics.median(ms), ms
 
+    def link_trace(where):
+        """MM_BENCH_LINK_TRACE=1 (diagnostics): the link's both-directions rate at this point of the run, to stderr -
+        the host-to-host call took 39.5 ms in a fresh process and 71 ms at the end of this script on the same box."""
+        if not os.environ.get("MM_BENCH_LINK_TRACE") or rank != 0:
+            return
+        import ctypes as C_
+        import numpy as np_
+        nb_ = 256 << 20
+        a_, ao_ = sm.pinned_array((nb_,), np_.uint8)
+        b_, bo_ = sm.pinned_array((nb_,), np_.uint8)
+        a_[:] = 1
+        b_[:] = 2
+        r_ = (C_.c_double * 3)()
+        sm._check(L.mm_link_probe(ws.h, C_.c_void_p(a_.ctypes.data), C_.c_void_p(b_.ctypes.data), nb_, r_))
+        print(f"[link] {where}: h2d {r_[0]:.1f} d2h {r_[1]:.1f} both {r_[2]:.1f} GB/s", file=sys.stderr, flush=True)
+        del a_, b_, ao_, bo_
+
+    link_trace("start")
     extras = []
     if rank == 0 and world == 1 and not args.no_extra and args.workload == "headline" and args.bases == N_BASES and not os.environ.get("MM_BENCH_SKIP_SECONDARY"):
         # Secondary configurations of BASELINE.json (untimed region, before the headline so that they
@@ -510,6 +528,7 @@ def main():
             except Exception as e:  # a component must never take the headline down
                 extras.append({"component": comp, "error": str(e)[:200]})
 
+    link_trace("after the secondary configurations")
     # ---------------------------------------------------------------- workload set-up
     n = args.bases
     gather_ms = None
@@ -604,6 +623,7 @@ def main():
     # waves on a stream of their own read the shader cycle counter against the 100 MHz real-time counter
     # (mm_clock_probe_*).  Not inside the timed loop: a second active queue alone slows the steps by ~7 %
     # (measured: 1.96 against 1.82 ms), whatever runs on it.
+    link_trace("after the timed loop")
     live_clock = None
     if rank == 0 and world == 1 and hasattr(ws, "clock_probe_begin"):
         try:
@@ -615,6 +635,7 @@ def main():
             live_clock = ws.clock_probe_end()
         except Exception:
             live_clock = None
+    link_trace("after the clock probe")
     ws.check()  # no asynchronous run of the timed loop reported a look-back time-out / kernel error
 
     if distributed:
@@ -837,6 +858,20 @@ def main():
                         e2e.append((time.perf_counter() - te) * 1e3)
                 assert cnt.value == n_out
                 m = statistics.median(e2e)
+                host_ab = None
+                if os.environ.get("MM_BENCH_HOST_AB"):  # diagnostics: the call's mechanisms in THIS process state
+                    host_ab = {}
+                    for om, im in (("engine", "engine"), ("blit", "engine"), ("direct", "engine"), ("blit", "blit")):
+                        os.environ["MM_HOST_OUT"], os.environ["MM_HOST_IN"] = om, im
+                        tt = []
+                        for _ in range(3):
+                            te = time.perf_counter()
+                            sm._check(L.mm_run_host(plan.h, ws.h, hp.ctypes.data_as(C.POINTER(C.c_uint8)), 0, n,
+                                                    ho.ctypes.data_as(C.POINTER(C.c_uint32)), None, n_out + 1024, C.byref(cnt)))
+                            tt.append((time.perf_counter() - te) * 1e3)
+                        host_ab[f"out={om},in={im}"] = round(min(tt), 2)
+                    os.environ.pop("MM_HOST_OUT", None)
+                    os.environ.pop("MM_HOST_IN", None)
                 # the link itself, measured beside it (this figure moved 39.6 -> 71.4 ms between two driver boxes of round
                 # 4): 512 MiB each way between the same page-locked buffers and the device - each direction alone and,
                 # since round 5, BOTH AT ONCE (mm_link_probe: the copy engines on two streams).  The two directions do not
@@ -890,6 +925,8 @@ def main():
                                       "never part of `value`",
                               "ms_over_floor": (round(m / link["floor_ms_at_these_rates"], 3)
                                                 if isinstance(link.get("floor_ms_at_these_rates"), float) else None)}
+                if host_ab:
+                    end_to_end["mechanisms_ms"] = host_ab
                 del hp, ho, hp_owner, ho_owner
             except Exception as e:  # host memory limits of the box
                 end_to_end = {"error": str(e)[:200]}

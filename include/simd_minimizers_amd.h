@@ -146,6 +146,11 @@ int mm_workspace_last_path(const mm_workspace_t *ws);
  * order to `out` (may be null) and returns how many there are.  No GPU needed.  The test-suite takes its list of
  * instances to compare with the oracle from here, so that none can ship untested. */
 int mm_prebuilt_window_sizes(int canonical_windows, int reads_mode, uint32_t *out, int capacity);
+/* Bytes behind the last base of a run's last window that a launch of the fused family may still TOUCH (never use: a lane
+ * that starts inside the window range walks its whole length with the windows past the range masked, and its loads run
+ * ahead).  The launcher's own bound: mm_device_group_upload_range keeps that much resident behind every entry's share and
+ * mm_run_sharded_device's residency check allows for it.  No GPU needed. */
+uint64_t mm_fused_overread_bytes(void);
 
 /* -------------------------------------------------------------------- run */
 
@@ -447,7 +452,11 @@ int mm_device_group_result(const mm_device_group_t *group, int entry, uint32_t *
 /* The optional exchange: the shards of the last run, dense and in window order, into d_dst_pos (and d_dst_sk) on
  * the device of entry `root` - device-to-device copies (hipMemcpyPeerAsync: over xGMI between the GPUs of a node),
  * all in flight together; no RCCL dependency.  *total receives the number of positions; MM_ERR_CAPACITY when they
- * do not fit `capacity` (nothing is copied then). */
+ * do not fit `capacity` (nothing is copied then).  The copies run on the SOURCE entries' streams and the call waits for
+ * them; they are not ordered against work the caller has queued on the destination: d_dst_pos / d_dst_sk must be idle
+ * (no kernel or copy of the caller's still reading or writing them) when this is called.  MM_ERR_NULL when the group's
+ * last run was a batch run (mm_run_batch_sharded_device: see mm_device_group_gather_batch) - the two resident modes
+ * share the result buffers, each call invalidates the other mode's results. */
 int mm_device_group_gather(mm_device_group_t *group, int root, uint32_t *d_dst_pos, uint32_t *d_dst_sk /* or NULL */,
                            uint64_t capacity, uint64_t *total);
 

@@ -120,6 +120,8 @@ def lib():
         L.mm_clock_probe_begin.argtypes = [vp, C.c_uint64]
         L.mm_clock_probe_end.argtypes = [vp, C.POINTER(C.c_double)]
         L.mm_link_probe.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(C.c_double)]
+        L.mm_fused_overread_bytes.argtypes = []
+        L.mm_fused_overread_bytes.restype = C.c_uint64
         L.mm_workspace_force_generic.argtypes = [vp, C.c_int]
         L.mm_workspace_set_blocks_per_lane.argtypes = [vp, C.c_uint32]
         L.mm_workspace_enable_timing.argtypes = [vp, C.c_int]
@@ -193,7 +195,7 @@ EXPORTED_SYMBOLS = [
     "mm_run_reads_skip_ambiguous_device", "mm_pack_ascii_n_device_async", "mm_pack_ascii_device_async",
     "mm_host_alloc", "mm_host_free",
     "mm_generate_device_async", "mm_fasta_pack_device_async", "mm_fasta_pack_device", "mm_fastq_pack_device_async",
-    "mm_clock_probe_begin", "mm_clock_probe_end", "mm_link_probe",
+    "mm_clock_probe_begin", "mm_clock_probe_end", "mm_link_probe", "mm_fused_overread_bytes",
     "mm_device_group_create", "mm_device_group_destroy", "mm_device_group_size", "mm_run_sharded_host",
     "mm_run_batch_sharded_host",
     "mm_device_group_upload", "mm_device_group_upload_range", "mm_device_group_adopt", "mm_run_sharded_device", "mm_device_group_result",
@@ -392,6 +394,7 @@ class DeviceGroup:
         self.h = C.c_void_p()
         arr = (C.c_int * len(devices))(*devices)
         _check(lib().mm_device_group_create(C.byref(self.h), arr, len(devices)))
+        self._batch_n = None  # sequences of the resident batch (upload_batch), None: no batch uploaded yet
 
     def __len__(self):
         return lib().mm_device_group_size(self.h)
@@ -495,11 +498,21 @@ class DeviceGroup:
         _check(lib().mm_device_group_upload_batch(self.h, n, ptrs, nbytes))
         self._batch_n = n
 
+    def _batch_count(self) -> int:
+        if self._batch_n is None:
+            raise MinimizerError(ERR["NULL"], "no resident batch: call upload_batch() first")
+        return self._batch_n
+
     def run_batch_device(self, builder: "Builder", n_bases, base_offsets=None):
         """One batch launch per entry over its resident sequences; returns the per-sequence counts (input order)."""
-        n = self._batch_n
+        n = self._batch_count()
+        n_bases = list(n_bases)
+        base_offsets = list(base_offsets) if base_offsets is not None else [0] * n
+        if len(n_bases) != n or len(base_offsets) != n:  # (ADVICE r4: a short list used to be zero-padded silently)
+            raise MinimizerError(ERR["NULL"], f"run_batch_device: {n} sequences are resident (upload_batch), got "
+                                              f"{len(n_bases)} lengths and {len(base_offsets)} base offsets")
         lens = (C.c_uint64 * max(n, 1))(*n_bases)
-        offs = (C.c_uint64 * max(n, 1))(*(base_offsets or [0] * n))
+        offs = (C.c_uint64 * max(n, 1))(*base_offsets)
         counts = (C.c_uint64 * max(n, 1))()
         total = C.c_uint64()
         _check(lib().mm_run_batch_sharded_device(builder.plan().h, self.h, offs, lens, 1 if builder._sk is not None else 0,
@@ -508,7 +521,7 @@ class DeviceGroup:
 
     def gather_batch(self, root: int, d_dst_pos, d_dst_sk=None):
         """All sequences' positions, input order, into device tensors on the root entry's device; returns the offsets."""
-        n = self._batch_n
+        n = self._batch_count()
         offs = (C.c_uint64 * (n + 1))()
         code = lib().mm_device_group_gather_batch(self.h, root, C.c_void_p(d_dst_pos.data_ptr()),
                                                   C.c_void_p(d_dst_sk.data_ptr()) if d_dst_sk is not None else None,

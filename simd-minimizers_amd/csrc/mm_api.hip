@@ -678,6 +678,8 @@ int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n
     return tiles.size() > tile_capacity ? MM_ERR_CAPACITY : MM_OK;
 }
 
+uint64_t mm_fused_overread_bytes(void) { return mm::fused_overread_bytes(); }
+
 int mm_prebuilt_window_sizes(int canonical_windows, int reads_mode, uint32_t *out, int capacity) {
     return mm::fused_prebuilt_windows(canonical_windows != 0, reads_mode != 0, out, capacity < 0 ? 0 : capacity);
 }
@@ -2163,21 +2165,70 @@ int mm_link_probe(mm_workspace_t *ws, const void *host_in, void *host_out, uint6
     MM_LP(hipMemset(d_b, 0, bytes));
     MM_LP(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
     MM_LP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    // Copies in 32 MiB pieces, at most two per direction in the runtime's hands - the way mm_run_host moves its chunks.
+    // (One 512 MiB copy per direction, queued together, measured NO overlap at all inside a process that had loaded
+    // another build of the HIP runtime, 57 GB/s for both, where the call itself overlapped them and a stand-alone
+    // program measured 97: profiles/r05_host_path.txt.)
+    const uint64_t piece = 32ull << 20;
+    const uint64_t n_pieces = (bytes + piece - 1) / piece;
+    std::vector<hipEvent_t> ev(2 * n_pieces, nullptr);
+    auto cleanup_events = [&]() {
+        for (hipEvent_t e : ev)
+            if (e) hipEventDestroy(e);
+    };
+    for (hipEvent_t &e : ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            cleanup_events();
+            cleanup();
+            return hip_fail(hipGetLastError(), "hipEventCreate");
+        }
+#define MM_LPE(x)                                             \
+    do {                                                      \
+        const hipError_t e_ = (x);                            \
+        if (e_ != hipSuccess) {                               \
+            rc = hip_fail(e_, #x);                            \
+            cleanup_events();                                 \
+            cleanup();                                        \
+            return rc;                                        \
+        }                                                     \
+    } while (0)
     for (int what = 0; what < 3; ++what) {
         double best = 0.0;
         for (int rep = 0; rep < 4; ++rep) {  // (the first repetition warms up)
-            MM_LP(hipDeviceSynchronize());
+            MM_LPE(hipDeviceSynchronize());
             const auto t0 = std::chrono::steady_clock::now();
-            if (what != 1) MM_LP(hipMemcpyAsync(d_a, host_in, bytes, hipMemcpyHostToDevice, s1));
-            if (what != 0) MM_LP(hipMemcpyAsync(host_out, d_b, bytes, hipMemcpyDeviceToHost, s2));
-            MM_LP(hipStreamSynchronize(s1));
-            MM_LP(hipStreamSynchronize(s2));
+            uint64_t next[2] = {0, 0}, retired[2] = {0, 0};
+            const bool on[2] = {what != 1, what != 0};
+            while ((on[0] && retired[0] < n_pieces) || (on[1] && retired[1] < n_pieces)) {
+                for (int dir = 0; dir < 2; ++dir) {
+                    if (!on[dir]) continue;
+                    while (next[dir] < n_pieces && next[dir] - retired[dir] < 2) {
+                        const uint64_t o = next[dir] * piece, c = bytes - o < piece ? bytes - o : piece;
+                        if (dir == 0)
+                            MM_LPE(hipMemcpyAsync(static_cast<uint8_t *>(d_a) + o, static_cast<const uint8_t *>(host_in) + o, c,
+                                                  hipMemcpyHostToDevice, s1));
+                        else
+                            MM_LPE(hipMemcpyAsync(static_cast<uint8_t *>(host_out) + o, static_cast<uint8_t *>(d_b) + o, c,
+                                                  hipMemcpyDeviceToHost, s2));
+                        MM_LPE(hipEventRecord(ev[2 * next[dir] + dir], dir == 0 ? s1 : s2));
+                        ++next[dir];
+                    }
+                    if (retired[dir] < next[dir]) {
+                        const hipError_t q = hipEventQuery(ev[2 * retired[dir] + dir]);
+                        if (q == hipSuccess) ++retired[dir];
+                        else if (q != hipErrorNotReady) MM_LPE(q);
+                        else (void)hipGetLastError();
+                    }
+                }
+            }
             const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             const double rate = (what == 2 ? 2.0 : 1.0) * (double)bytes / t / 1e9;
             if (rep && rate > best) best = rate;
         }
         out_GBps[what] = best;
     }
+    cleanup_events();
+#undef MM_LPE
 #undef MM_LP
     cleanup();
     return MM_OK;
@@ -2350,7 +2401,7 @@ int mm_device_group_upload(mm_device_group_t *g, const uint8_t *packed, uint64_t
 // range runs its whole length: below 60 000 bases) and the look-ahead of the loads.
 static void resident_range(uint64_t base_offset, uint64_t n_bases, uint64_t N, uint64_t i, uint64_t total_bytes, uint64_t *lo,
                            uint64_t *hi) {
-    const uint64_t kMaxL = 1ull << 17, kOver = 70000ull;
+    const uint64_t kMaxL = 1ull << 17, kOver = 4ull * mm::fused_overread_bytes();  // (bases)
     const uint64_t nb_lo = n_bases > kMaxL ? n_bases - kMaxL : 0;
     uint64_t first = base_offset + nb_lo / N * i;
     first = first / 4 > 64 ? first / 4 - 64 : 0;
@@ -2523,6 +2574,7 @@ int mm_run_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, uint64_t 
     const uint64_t n_w = n_bases >= l ? n_bases - l + 1 : 0;
     if (total) *total = 0;
     g->ran = true;
+    g->batch_ran = false;  // (the result buffers are shared between the two resident modes: ADVICE r4)
     // expected positions per window (+ 15 % and a constant): a shard that needs more is run again with what it needs
     const double dens = plan->mode == MM_OPEN_SYNCMERS ? 1.0 / plan->w
                         : plan->mode == MM_CLOSED_SYNCMERS ? 2.0 / plan->w : 2.0 / (plan->w + 1.0);
@@ -2563,7 +2615,8 @@ int mm_run_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, uint64_t 
         {   // what this entry's run reads must be resident on it (mm_device_group_upload_range uploads a share + halo)
             const uint64_t lw = (uint64_t)plan->k + plan->w - 1;
             const uint64_t need_lo = (base_offset + (s.win_begin ? s.win_begin - 1 : 0)) / 4;
-            uint64_t need_hi = (base_offset + s.win_end + lw - 2) / 4 + 1 + 24576;
+            // (+ what the launch may touch behind its last window: the launcher's own bound, mm_launch.h)
+            uint64_t need_hi = (base_offset + s.win_end + lw - 2) / 4 + 1 + mm::fused_overread_bytes();
             if (need_hi > g->seq_bytes) need_hi = g->seq_bytes;
             if (need_lo < g->res_lo[i] || need_hi > g->res_hi[i]) {
                 g_last_error = "mm_run_sharded_device: entry " + std::to_string(i) + " holds bytes [" + std::to_string(g->res_lo[i]) +
@@ -2790,6 +2843,7 @@ int mm_run_batch_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, con
     }
     if (total) *total = sum;
     g->batch_ran = true;
+    g->ran = false;  // (the result buffers now hold a batch: mm_device_group_result / _gather must not read them as shards)
     return MM_OK;
 }
 

@@ -116,7 +116,7 @@ uint32_t legal_nblk(uint32_t w, uint32_t mode, uint32_t want, uint32_t cap_limit
         if (want < 12u) want = 12u;
     }
     if (want < 1u) want = 1u;
-    while (w * want > 60000u && want > 1u) --want;  // 16-bit element positions inside a lane
+    while (w * want > kFusedMaxLaneWindows && want > 1u) --want;  // 16-bit element positions inside a lane
     return want;
 }
 
@@ -288,6 +288,11 @@ uint64_t fused_status_words(const RunArgs &a) {
     return (tiles + 8) * status_stride_host();
 }
 uint32_t fused_tile_windows(const RunArgs &a) { return geometry(a).NB; }
+uint64_t fused_overread_bytes() {
+    // the longest lane + two load groups of the widest window (8 blocks each at most, kWideGroup) + the 20 bytes of a
+    // wide load, in bytes of packed sequence (4 bases per byte), rounded up to whole cache lines
+    return ((uint64_t)kFusedMaxLaneWindows + 2ull * 8ull * kJitMaxW + 3ull) / 4ull + 20ull + 127ull & ~127ull;
+}
 
 static uint32_t g_lds_pad = 0;
 
@@ -362,7 +367,7 @@ static uint32_t whole_rounds_nblk(const RunArgs &a, const KernelRef &kr, const G
     const uint32_t lo = whole_rounds_lo(g.nblk), hi = g.nblk * 115u / 100u;
     for (uint32_t nb = lo; nb <= hi; ++nb) {
         const uint64_t S = (uint64_t)a.w * nb;
-        if (S > 60000u || (sh && (S << sh) > 65536u)) continue;
+        if (S > kFusedMaxLaneWindows || (sh && (S << sh) > 65536u)) continue;
         if (list_capacity(a.w, a.mode, (uint32_t)S) * stride_of(a) > lds_limit) continue;
         if (entry8(a) && S + a.w > 255u) continue;
         const double rounds = (double)tiles_of(S) / slots;
@@ -882,7 +887,7 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     const uint32_t max_nw = a.read_len >= l ? a.read_len - l + 1 : 1;
     const uint32_t nblk = (max_nw + a.w - 1) / a.w;  // every lane must be able to walk its whole read
     const uint32_t S = nblk * a.w;
-    if (S + a.w > 60000u) return -3;
+    if (S + a.w > kFusedMaxLaneWindows) return -3;
     // A lane walks R consecutive reads, so that a tile holds about as many windows as a tile of the
     // sequence mode (fewer tiles: less look-back and copy-out overhead per window).  MM_READS_PER_LANE
     // overrides (experiments).

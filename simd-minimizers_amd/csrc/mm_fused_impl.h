@@ -671,7 +671,18 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     uint32_t pl_in = (uint32_t)pos_in + (uint32_t)((PFD - 1) * W), pl_out = (uint32_t)pos_out + (uint32_t)((PFD - 1) * W);
 #define MM_BUMP(x, c) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x) : "n"(c))
     uint32_t kn = 0;  // wide loads: index of block b + 1 within its group (wave-uniform)
-    for (uint32_t b = 1; b <= nblk; ++b) {
+    // The W-block loop.  Round 5: with wide loads the index of a block within its load group (kn) decides which dword pair
+    // its views come from - a wave-uniform switch per block, whose arms the compiler joined with register copies (7 v_mov
+    // and a chain of s_cmp / s_cbranch per block in the w = 11 kernel).  The full-tile walk now runs whole GROUPS of MG
+    // blocks with kn a compile-time constant and leaves the switch to the blocks behind the last whole group (tapered
+    // tiles, lanes whose length is no multiple of MG) and to the walks that are not the hot one (partial tiles, direct
+    // stores, skip-ambiguous).  -DMM_GROUP_UNROLL=0: the loop of rounds 3-4 (A/B).
+#ifndef MM_GROUP_UNROLL
+#define MM_GROUP_UNROLL 1
+#endif
+    constexpr bool kGroupUnroll = MM_GROUP_UNROLL && MG > 1 && !PARTIAL && !AMBI && !DIRECT;
+    auto block = [&](const uint32_t b, auto kn_tag) {
+        constexpr int KN = decltype(kn_tag)::value;  // block b + 1's index within its load group, or -1: in `kn`
         uint32_t me[NSUB], mo[NSUB];
         uint32_t tgw[NSUB];           // eager strand vote: signed 2-bit steps of the count
         uint32_t xt[NSUB], yt[NSUB];  // lazy strand vote (below): T|G bits of the block's entering / leaving bases
@@ -728,7 +739,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         if (MG != 0) {
             // wide loads: block b + 1 is block kn of its group; a new group takes the next buffer and starts the load
             // of the group after it (a harmless over-read after the last block)
-            if (kn == 0) {
+            if ((KN >= 0 ? (uint32_t)KN : kn) == 0u) {
                 // (the landing buffer [1] is shifted into the working buffer [0]; then it takes the next load)
                 sh_in = wide_normalise(Wa[0], Wa[1]);
 #ifdef MM_EXP_ONE_STREAM
@@ -743,7 +754,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 MM_BUMP(gp_out, MG * W);
 #endif
             }
-            switch (kn) {
+            switch (KN >= 0 ? (uint32_t)KN : kn) {
 #define MM_WIDE_CASE(K)                                                   \
     case K:                                                               \
         if (K < (MG ? MG : 1)) {                                          \
@@ -762,7 +773,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
 #undef MM_WIDE_CASE
                 default: break;
             }
-            kn = (kn + 1 == (uint32_t)(MG ? MG : 1)) ? 0u : kn + 1u;
+            if (KN < 0) kn = (kn + 1 == (uint32_t)(MG ? MG : 1)) ? 0u : kn + 1u;
         } else
         // views of the next block from the dwords loaded one block ago; issue the loads of the
         // block after it (a harmless over-read after the last block)
@@ -1152,6 +1163,26 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 for (int g = 0; g < NSUB; ++g) dn += (int)__builtin_popcount(xt[g]) - (int)__builtin_popcount(yt[g]);
             }
         }
+    };  // block
+    {
+        uint32_t b = 1;
+        if (kGroupUnroll) {
+            // (kn == 0 here: block 2 is the first block of load group 0, see "wide loads" in block 0)
+            for (; b + (uint32_t)(MG ? MG : 1) - 1u <= nblk; b += (uint32_t)(MG ? MG : 1)) {
+#define MM_GROUP_BLOCK(K) \
+    if (K < MG) block(b + (uint32_t)K, IntTag<(K < MG ? K : 0)>{});
+                MM_GROUP_BLOCK(0)
+                MM_GROUP_BLOCK(1)
+                MM_GROUP_BLOCK(2)
+                MM_GROUP_BLOCK(3)
+                MM_GROUP_BLOCK(4)
+                MM_GROUP_BLOCK(5)
+                MM_GROUP_BLOCK(6)
+                MM_GROUP_BLOCK(7)
+#undef MM_GROUP_BLOCK
+            }
+        }
+        for (; b <= nblk; ++b) block(b, IntTag<-1>{});
     }
 #ifdef MM_STAGE
     if (!MM_STAGE_GE(5)) {  // keep the sink alive: one list slot per lane

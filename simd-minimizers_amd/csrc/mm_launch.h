@@ -44,6 +44,15 @@ struct RunArgs {
     hipEvent_t timing_start, timing_stop;
 };
 
+// Longest lane of the fused family in windows (16-bit element positions inside a lane; legal_nblk, the reads-mode
+// launcher and the whole-rounds tuner all keep to it).
+constexpr uint32_t kFusedMaxLaneWindows = 60000u;
+// Bytes behind the last base of a run's last window that the run may still TOUCH (never use): a lane that starts inside
+// the window range walks its whole length with the windows past the range masked, and its sequence loads run two load
+// groups ahead.  The launcher's own bound - what mm_device_group_upload_range keeps resident behind an entry's share and
+// what mm_run_sharded_device's residency check allows for (round 4 carried a literal 24 576 there).
+uint64_t fused_overread_bytes();
+
 // ---- fused family (mm_fused_*.hip): one kernel, specialised per w
 bool fused_supported(uint32_t k, uint32_t w, int canonical_windows, int hasher_canonical);
 uint64_t fused_status_words(const RunArgs &a);

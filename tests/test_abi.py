@@ -174,3 +174,28 @@ def test_launch_plan_tiles_every_window(sm, monkeypatch):
             assert all(x >= y for x, y in zip(nb[k:], nb[k + 1:])), it  # lanes only shrink from there on
     assert tapered_batches > 20
     monkeypatch.delenv("MM_TAPER_SLOTS")
+
+
+def test_overread_bound_covers_every_launch_plan(sm):
+    """the bytes a launch may touch behind its last window are the launcher's own bound
+    (mm_fused_overread_bytes: longest lane + two load groups), not a literal in the residency check.  Every launch plan
+    the planner produces - small and large windows, super-k-mer indices, long and short runs - keeps its lanes within it."""
+    import ctypes as C
+    L = sm.lib()
+    bound = int(L.mm_fused_overread_bytes())
+    assert 15000 < bound < 32768
+    out7 = (C.c_uint64 * 7)()
+    n_tiles = C.c_uint64()
+    os.environ["MM_TAPER_SLOTS"] = "1024"
+    try:
+        for w in (1, 5, 11, 17, 33, 51, 100, 128):
+            for canonical in (0, 1):
+                for mode in (0, 1):
+                    for nw in (10_000, 3_000_000, 400_000_000, 3_099_999_970):
+                        nws = (C.c_uint64 * 1)(nw)
+                        sm._check(L.mm_debug_launch_plan(w, canonical, mode, 0, nws, out7, None, None, None, 0, C.byref(n_tiles)))
+                        lane_windows = int(out7[0]) * w
+                        # a lane's bases + the largest window + two load groups of 8 blocks, 4 bases per byte, + a wide load
+                        assert (lane_windows + 2 * 8 * w + 3) // 4 + 20 <= bound, (w, canonical, mode, nw, lane_windows)
+    finally:
+        del os.environ["MM_TAPER_SLOTS"]

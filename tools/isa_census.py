@@ -44,8 +44,9 @@ for ln in lines:
     if s:
         insts.append(s)
 best = None
+NWIN = W  # windows one iteration of the main loop walks: W, or W x kWideGroup<W> since round 5 (whole load groups unrolled)
 for i, s in enumerate(insts):
-    m = re.match(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", s)
+    m = re.match(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", s) or re.match(r"s_branch\s+(\.LBB\d+_\d+)", s)
     if not m or m.group(1) not in labels or labels[m.group(1)] > i:
         continue
     body = insts[labels[m.group(1)]:i + 1]
@@ -53,14 +54,16 @@ for i, s in enumerate(insts):
     # (the emit compare is v_cmpx in the fast-emit body; canonical walks carry W more v_cmp_ne_u32_sdwa since round 3:
     # the lazy strand vote's position compare)
     emit_cmp = ops["v_cmpx_ne_u32_sdwa"] if ops["v_cmpx_ne_u32_sdwa"] else ops["v_cmp_ne_u32_sdwa"]
-    if emit_cmp != W or ops["ds_write_b16"] + ops["ds_write_b8"] != W:
+    writes = ops["ds_write_b16"] + ops["ds_write_b8"]
+    if writes == 0 or writes % W or writes // W > 8 or emit_cmp != writes:
         continue
-    if sum(v for o, v in ops.items() if o.startswith("ds_read")) != W or not any(o.startswith("buffer_load") for o in ops):
-        continue  # (the block loop proper: W table look-ups, W list appends, the sequence loads of a later block)
+    if sum(v for o, v in ops.items() if o.startswith("ds_read")) != writes or not any(o.startswith("buffer_load") for o in ops):
+        continue  # (the block loop proper: one table look-up and one list append per window, the sequence loads of a later group)
     if any(o.startswith(("v_cmp_lt_i32", "buffer_store", "global_store")) for o in ops):
         continue  # range-checked or direct-store walks
-    if best is None or len(body) < len(best):
-        best = body
+    # the hot loop is the one that walks the most windows per iteration (the group-unrolled one), then the shortest
+    if best is None or writes > NWIN or (writes == NWIN and len(body) < len(best)):
+        best, NWIN = body, writes
 assert best, "main loop not found"
 
 
@@ -101,7 +104,7 @@ for piece in pieces:
     valu = [o for o in ops if o.startswith("v_")]
     group_start = any(o.startswith(("v_alignbyte", "buffer_load")) for o in ops)
     view_case = bool(valu) and all(o.startswith("v_alignbit") for o in valu) and len(valu) <= 2 * ((W + 15) // 16)
-    wgt = 1.0 / MG if (MG > 1 and (group_start or view_case)) else 1.0
+    wgt = 1.0 / MG if (MG > 1 and NWIN == W and (group_start or view_case)) else 1.0  # (unrolled groups: every piece runs)
     for b in piece:
         cls[classify(b.split()[0], b)] += wgt
 cls = collections.Counter({k: round(v, 2) for k, v in cls.items()})
@@ -127,12 +130,12 @@ full, half = cls["valu_full"], cls["valu_half"]
 # "by wall time at that clock"); the architectural figures are 2 and 4 (MI355X_MICROARCH.md)
 FULL, HALF = 2.31, 4.14
 rec = {"kernel": f"mm::fused_kernel<{W}, {c}, {c}, 0, false, false>", "kernel_source_sha": h.hexdigest()[:16],
-       "main_loop_windows": W, "main_loop_instructions": len(best), "wide_group_blocks": MG,
+       "main_loop_windows": NWIN, "main_loop_instructions": len(best), "wide_group_blocks": MG,
        "valu_full_rate": full, "valu_half_rate": half,
        "salu": cls["salu"], "lds": cls["lds"], "vmem": cls["vmem"],
-       "valu_per_window": round((full + half) / W, 2),
+       "valu_per_window": round((full + half) / NWIN, 2),
        "issue_clk_per_valu": round((FULL * full + HALF * half) / (full + half), 3),
-       "issue_clk_per_window": round((FULL * full + HALF * half) / W, 1),
+       "issue_clk_per_window": round((FULL * full + HALF * half) / NWIN, 1),
        "ideal_clk_per_valu": round((2.0 * full + 4.0 * half) / (full + half), 3),
        "rates": f"{FULL} / {HALF} shader cycles per full- / half-rate wave64 VALU instruction, measured with the shader "
                 "clock read under each loop (profiles/r03_valu_issue_rates.txt); ideal_clk_per_valu uses the "
