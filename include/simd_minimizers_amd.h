@@ -485,7 +485,9 @@ int mm_device_group_gather_batch(mm_device_group_t *group, int root, uint32_t *d
  * n_windows[0] windows, out7 = {blocks per lane, tiles, first tapered tile, tiles per taper level, last level's blocks
  * per lane, first tapered window, windows per block of a tile}.  n_seqs > 0: a batch, the tile table itself (tile t =
  * sequence, first window, blocks per lane; out7[0] = the longest lane); MM_ERR_CAPACITY when it holds more than
- * tile_capacity tiles (*n_tiles says how many). */
+ * tile_capacity tiles (*n_tiles says how many).  mode: 0 minimizers, 1 / 2 closed / open syncmers, 3 minimizers with
+ * super-k-mer indices (whose 16-bit list entries bound the lanes).  With MM_TAPER_SLOTS set the single-sequence plan also
+ * applies the one-round rule (a run of 0.6 .. 1 round of that many slots gets one tile per slot). */
 int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n_seqs, const uint64_t *n_windows,
                          uint64_t *out7, uint32_t *tile_seq, uint32_t *tile_win0, uint32_t *tile_nblk,
                          uint64_t tile_capacity, uint64_t *n_tiles);

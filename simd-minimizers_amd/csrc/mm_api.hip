@@ -639,10 +639,12 @@ int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n
     a.k = 21;
     a.w = w;
     a.canonical_windows = canonical_windows;
-    a.mode = (uint32_t)mode;
+    a.mode = mode == 3 ? 0u : (uint32_t)mode;  // (3: minimizers WITH super-k-mer indices - their 16-bit list entries bound the lanes)
     a.win_begin = 0;
     a.win_end = n_windows[0];
     memset(&a.out, 0, sizeof a.out);
+    static uint32_t sk_marker;
+    if (mode == 3) a.out.sk = &sk_marker;  // (only its being non-null matters to the planner)
     a.wamb = nullptr;
     a.wamb_dwords = 0;
     a.batch_seqs = nullptr;

@@ -542,8 +542,36 @@ bool fused_batch_tiles(const RunArgs &a0, const uint64_t *n_windows, uint64_t n_
 // The launch plan of a single-sequence run without a device (MM_TAPER_SLOTS set): what launch_fused would pass the
 // kernel.  out[0..6] = blocks per lane, tiles, taper_first, taper_per_level, taper_min_nblk, taper_start, windows per block
 // of a tile (256 x w).  Host logic only: the CPU test-suite checks that the tiles tile the window range.
+// The one-round rule of launch_fused (below): a run of 0.6 to 1 round of the chip's `slots` workgroup slots with the
+// default lanes gets exactly one round - every slot one tile, lanes as long as that takes.  Returns true and the new
+// geometry when the rule applies.
+static bool one_round_geometry(const RunArgs &a, uint64_t slots, const Geometry &gd, Geometry *g) {
+    const uint64_t nwin = a.win_end - a.win_begin, blk_w = (uint64_t)kFusedThreads * a.w;
+    if (!(nwin <= slots * (uint64_t)gd.NB && nwin * 10u >= slots * (uint64_t)gd.NB * 6u)) return false;
+    // (the legal maximum LAST: gd.nblk carries geometry()'s bounds - 16-bit super-k-mer entries, 8-bit entries, the
+    // LDS - and is below 6 for super-k-mer runs with w >= 86; the lanes are then rebuilt by geometry() itself, so that
+    // every bound is applied again.  ADVICE r4, high: the floor of 6 used to come last and overflowed the 16-bit entries.)
+    uint32_t nb = (uint32_t)((nwin + slots * blk_w - 1) / (slots * blk_w));
+    nb = nb < 6u ? 6u : nb;
+    nb = nb > gd.nblk ? gd.nblk : nb;
+    RunArgs one = a;
+    one.nblk = nb;
+    *g = geometry(one);
+    return true;
+}
+
 int fused_debug_plan(const RunArgs &a, unsigned long long *out) {
     Geometry g = geometry(a);
+    // (with MM_TAPER_SLOTS the planner pretends the chip holds that many workgroups: the one-round rule needs no device
+    // either, so the CPU suite covers it - tests/test_abi.py)
+    if (const char *e = mm_env("MM_TAPER_SLOTS")) {
+        const uint64_t slots = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : 0;
+        if (slots && g.nblocks >= 128 && a.nblk == 0 && !a.batch_tile_seq && !mm_env("MM_NO_ONE_ROUND")) {
+            RunArgs full = a;
+            full.work_windows = 0;
+            one_round_geometry(a, slots, geometry(full), &g);
+        }
+    }
     const Taper t = plan_taper(a, KernelRef(), g);
     out[0] = g.nblk;
     out[1] = t.tiles;
@@ -578,21 +606,10 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         full.work_windows = 0;  // (the default lanes of a long run)
         const Geometry gd = geometry(full);
         int per_cu = 0, cus = 0;
-        const uint64_t nwin = a.win_end - a.win_begin, blk_w = (uint64_t)kFusedThreads * a.w;
-        if (resident_slots(kr, gd.lds_bytes, &per_cu, &cus)) {
-            const uint64_t slots = (uint64_t)per_cu * cus;
-            if (nwin <= slots * (uint64_t)gd.NB && nwin * 10u >= slots * (uint64_t)gd.NB * 6u) {
-                // (the legal maximum LAST: gd.nblk carries geometry()'s bounds - 16-bit super-k-mer entries, 8-bit
-                // entries, the LDS - and is below 6 for super-k-mer runs with w >= 86; the lanes are then rebuilt
-                // by geometry() itself, so that every bound is applied again.  ADVICE r4, high)
-                uint32_t nb = (uint32_t)((nwin + slots * blk_w - 1) / (slots * blk_w));
-                nb = nb < 6u ? 6u : nb;
-                nb = nb > gd.nblk ? gd.nblk : nb;
-                RunArgs one = a;
-                one.nblk = nb;
-                g = geometry(one);
-            }
-        }
+        uint64_t slots = 0;
+        if (const char *e = mm_env("MM_TAPER_SLOTS")) slots = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : 0;  // (tests)
+        if (!slots && resident_slots(kr, gd.lds_bytes, &per_cu, &cus)) slots = (uint64_t)per_cu * cus;
+        if (slots) one_round_geometry(a, slots, gd, &g);
     }
     const bool tapers = !small_run && plan_taper(a, kr, g).first != 0xffffffffu && !mm_env("MM_TUNE_ALWAYS");
     if (!tapers && !small_run) {

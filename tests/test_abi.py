@@ -199,3 +199,48 @@ def test_overread_bound_covers_every_launch_plan(sm):
                         assert (lane_windows + 2 * 8 * w + 3) // 4 + 20 <= bound, (w, canonical, mode, nw, lane_windows)
     finally:
         del os.environ["MM_TAPER_SLOTS"]
+
+
+def test_one_round_rule_keeps_every_lane_bound(sm):
+    """ADVICE r4 (high), on the CPU: the one-round launch rule (0.6 .. 1 round of the chip's workgroup slots -> one tile
+    per slot) used to apply its floor of 6 blocks per lane AFTER the bounds geometry() had applied - with super-k-mer
+    indices and w >= 86 the 16-bit list entry (window << shift) + offset allows at most 5 blocks, and the lanes came out
+    longer than their entries can address.  Every plan - with and without the rule applying - keeps S << shift <= 65536
+    with super-k-mer indices, S + w <= 255 for the 8-bit lists of small forward windows, S <= 60 000 always."""
+    import ctypes as C
+    L = sm.lib()
+    out7 = (C.c_uint64 * 7)()
+    n_tiles = C.c_uint64()
+    checked = applied = 0
+    try:
+        for slots in (256, 512, 768, 1024, 1792):
+            os.environ["MM_TAPER_SLOTS"] = str(slots)
+            for w in (3, 11, 13, 31, 51, 64, 86, 100, 127, 128):
+                shift = max(1, w.bit_length())
+                for mode in (0, 3):
+                    for canonical in (0, 1):
+                        nws0 = (C.c_uint64 * 1)(10**10)  # (a long run: the default lanes)
+                        sm._check(L.mm_debug_launch_plan(w, canonical, mode, 0, nws0, out7, None, None, None, 0, C.byref(n_tiles)))
+                        default_nblk = int(out7[0])
+                        for frac in (0.3, 0.55, 0.61, 0.8, 0.99, 1.0, 1.01, 1.7):
+                            nw = int(frac * slots * default_nblk * w * 256)
+                            if nw < 1:
+                                continue
+                            nws = (C.c_uint64 * 1)(nw)
+                            sm._check(L.mm_debug_launch_plan(w, canonical, mode, 0, nws, out7, None, None, None, 0, C.byref(n_tiles)))
+                            nblk, tiles = int(out7[0]), int(out7[1])
+                            S = nblk * w
+                            assert nblk >= 1 and S <= 60000, (w, mode, slots, frac, nblk)
+                            if mode == 3:
+                                assert (S << shift) <= 65536, (w, slots, frac, nblk, shift)
+                            elif not canonical and w <= 13:
+                                assert S + w <= 255, (w, slots, frac, nblk)
+                            # uniform tiles cover the range (tapered plans are checked tile by tile in the test above)
+                            if int(out7[2]) == 0xffffffff:
+                                assert tiles * nblk * w * 256 >= nw > (tiles - 1) * nblk * w * 256, (w, mode, slots, frac)
+                            if 0.6 <= frac <= 1.0 and tiles == slots:
+                                applied += 1
+                            checked += 1
+    finally:
+        del os.environ["MM_TAPER_SLOTS"]
+    assert checked > 1000 and applied > 100, (checked, applied)
