@@ -468,7 +468,9 @@ int mm_device_group_gather(mm_device_group_t *group, int root, uint32_t *d_dst_p
  * n_bases[s] (and base_offsets[s], or NULL) describe sequence s of the upload; out_counts[s] (may be NULL) receives
  * its count, *total their sum.  mm_device_group_batch_result hands out where a sequence's positions lie;
  * mm_device_group_gather_batch copies all sequences, in input order, into device memory of entry `root`
- * (device-to-device) and fills the n_seqs + 1 offsets. */
+ * (device-to-device) and fills the n_seqs + 1 offsets.  Like mm_run_sharded_device the run issues one asynchronous
+ * launch per entry from the calling thread and then waits for them in turn (round 5; round 4 ran a host thread per
+ * entry); its destination rule for the gather is mm_device_group_gather's. */
 int mm_device_group_upload_batch(mm_device_group_t *group, uint64_t n_seqs, const uint8_t *const *packed,
                                  const uint64_t *packed_bytes);
 int mm_run_batch_sharded_device(const mm_plan_t *plan, mm_device_group_t *group, const uint64_t *base_offsets /* or NULL */,

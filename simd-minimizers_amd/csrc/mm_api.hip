@@ -154,6 +154,8 @@ struct mm_workspace {
     uint64_t batch_tiles_n = 0;
     unsigned long long *batch_offsets = nullptr;
     uint64_t batch_offsets_n = 0;
+    unsigned long long *h_batch = nullptr;  // page-locked landing buffer of a batch launch's offsets
+    uint64_t h_batch_n = 0;
     void *d_amb = nullptr;
     uint64_t d_amb_bytes = 0;
     unsigned long long *d_vals = nullptr;
@@ -544,6 +546,7 @@ void mm_workspace_destroy(mm_workspace_t *ws) {
     if (ws->batch_seqs) hipFree(ws->batch_seqs);
     if (ws->batch_tiles) hipFree(ws->batch_tiles);
     if (ws->batch_offsets) hipFree(ws->batch_offsets);
+    if (ws->h_batch) hipHostFree(ws->h_batch);
     if (ws->d_amb) hipFree(ws->d_amb);
     if (ws->d_vals) hipFree(ws->d_vals);
     if (ws->own_stream && ws->stream) hipStreamDestroy(ws->stream);
@@ -889,12 +892,25 @@ int mm_run_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d
 // costs one launch instead of one per sequence.  Returns MM_BATCH_FALLBACK when the plan has no
 // fused kernel (then the caller loops over the sequences).
 static const int MM_BATCH_FALLBACK = 1;
+static const int MM_BATCH_REDO = 2;
 
-static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_seqs,
-                                const void *const *d_packed, const uint64_t *packed_bytes,
-                                const uint64_t *base_offsets, const uint64_t *n_bases,
-                                uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
-                                uint64_t *out_offsets) {
+// Round 5: the launch is split into an ISSUE half (tables, uploads, the launch, the copies of the offsets and the result
+// words into page-locked memory: nothing waits) and a FINISH half (wait, judge, patch the offsets of empty sequences), so
+// that a device group issues one batch launch per entry from the calling thread and then waits for them in turn - the
+// model of mm_run_sharded_device - instead of a host thread per entry.
+struct BatchIssue {
+    std::vector<mm::BatchSeq> seqs;        // (host copies of the tables: alive until the uploads have been waited for)
+    std::vector<mm::BatchTile> tile_seq;
+    uint64_t n_seqs = 0;
+    bool launched = false;                 // false: nothing was queued (no tile at all): every offset is 0
+};
+
+static int batch_issue(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_seqs,
+                       const void *const *d_packed, const uint64_t *packed_bytes,
+                       const uint64_t *base_offsets, const uint64_t *n_bases,
+                       uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity, BatchIssue *bi) {
+    bi->n_seqs = n_seqs;
+    bi->launched = false;
     if (ws->force_generic || n_seqs == 0 || n_seqs >= (1ull << 32) ||
         !mm::fused_supported(plan->k, plan->w, plan->canonical_windows, (int)plan->ht.canonical))
         return MM_BATCH_FALLBACK;
@@ -937,8 +953,10 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
         const uint64_t per_seq = a.work_windows / nonempty * 1024ull;
         if (per_seq < a.work_windows) a.work_windows = per_seq ? per_seq : 1;
     }
-    std::vector<mm::BatchSeq> seqs(n_seqs);
-    std::vector<mm::BatchTile> tile_seq;
+    std::vector<mm::BatchSeq> &seqs = bi->seqs;
+    std::vector<mm::BatchTile> &tile_seq = bi->tile_seq;
+    seqs.assign(n_seqs, mm::BatchSeq{nullptr, 0, 0, 0, 0, {0, 0}});
+    tile_seq.clear();
     std::vector<uint64_t> nws(n_seqs);
     for (uint64_t s = 0; s < n_seqs; ++s) {
         if (n_bases[s] >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
@@ -954,7 +972,6 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
     for (uint64_t s = 0; s < n_seqs; ++s) {
         const uint64_t nw = nws[s];
         mm::BatchSeq &b = seqs[s];
-        b = mm::BatchSeq{nullptr, 0, 0, 0, 0, {0, 0}};
         if (nw == 0) continue;
         if (!d_packed[s]) return MM_ERR_NULL;
         mm::SeqView v;
@@ -966,16 +983,21 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
         b.n_windows = (uint32_t)nw;
     }
     const uint64_t n_tiles = tile_seq.size();
-    if (n_tiles == 0) {
-        for (uint64_t s = 0; s <= n_seqs; ++s) out_offsets[s] = 0;
-        return MM_OK;
-    }
+    if (n_tiles == 0) return MM_OK;  // (launched stays false: every offset is 0)
     int r = grow(ws->batch_seqs, ws->batch_seqs_n, n_seqs, sizeof(mm::BatchSeq));
     if (r) return r;
     r = grow(ws->batch_tiles, ws->batch_tiles_n, n_tiles, sizeof(mm::BatchTile));
     if (r) return r;
     r = grow(ws->batch_offsets, ws->batch_offsets_n, n_seqs + 1, sizeof(unsigned long long));
     if (r) return r;
+    if (ws->h_batch_n < n_seqs + 1) {  // page-locked landing buffer of the offsets (a pageable one would make the copy block)
+        if (ws->h_batch) hipHostFree(ws->h_batch);
+        ws->h_batch = nullptr;
+        ws->h_batch_n = 0;
+        const uint64_t want = (n_seqs + 1) * 2;
+        MM_HIP(hipHostMalloc(reinterpret_cast<void **>(&ws->h_batch), want * sizeof(unsigned long long), hipHostMallocDefault));
+        ws->h_batch_n = want;
+    }
     MM_HIP(hipMemcpyAsync(ws->batch_seqs, seqs.data(), n_seqs * sizeof(mm::BatchSeq), hipMemcpyHostToDevice,
                           ws->stream));
     MM_HIP(hipMemcpyAsync(ws->batch_tiles, tile_seq.data(), n_tiles * sizeof(mm::BatchTile), hipMemcpyHostToDevice,
@@ -988,48 +1010,74 @@ static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint6
     if (r) return r;
     a.out.status = ws->status;
     a.status_avail = ws->status_words;
-
-    std::vector<unsigned long long> offs(n_seqs + 1);
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        a.use_ticket = (ws->force_ticket || mm::mm_env("MM_FORCE_TICKET")) ? 1 : 0;
-        a.timing_start = a.timing_stop = nullptr;
-        r = next_status_epoch(ws, &a.status_epoch);
-        if (r) return r;
-        MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
-        MM_HIP(hipMemsetAsync(ws->batch_offsets, 0xFF, (n_seqs + 1) * sizeof(unsigned long long), ws->stream));
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (ws->timing) {
-            MM_HIP(hipEventCreate(&e0));
-            MM_HIP(hipEventCreate(&e1));
-            a.timing_start = e0;
-            a.timing_stop = e1;
-        }
-        const int lr = mm::launch_fused(a, ws->stream);
-        if (lr != 0) {
-            if (e0) hipEventDestroy(e0);
-            if (e1) hipEventDestroy(e1);
-            if (lr == -2) return MM_BATCH_FALLBACK;
-            g_last_error = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
-            return MM_ERR_HIP;
-        }
-        if (ws->timing) ws->events.emplace_back(e0, e1);
-        ws->last_path = MM_PATH_FUSED;
-        MM_HIP(hipMemcpyAsync(offs.data(), ws->batch_offsets, (n_seqs + 1) * sizeof(unsigned long long),
-                              hipMemcpyDeviceToHost, ws->stream));
-        MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                              ws->stream));
-        MM_HIP(hipStreamSynchronize(ws->stream));
-        const int je = judge_run_error(ws);
-        if (je < 0) return je;
-        if (je == 0) break;  // (1: redo the batch in ticket mode)
+    a.use_ticket = (ws->force_ticket || mm::mm_env("MM_FORCE_TICKET")) ? 1 : 0;
+    a.timing_start = a.timing_stop = nullptr;
+    r = next_status_epoch(ws, &a.status_epoch);
+    if (r) return r;
+    MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
+    MM_HIP(hipMemsetAsync(ws->batch_offsets, 0xFF, (n_seqs + 1) * sizeof(unsigned long long), ws->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ws->timing) {
+        MM_HIP(hipEventCreate(&e0));
+        MM_HIP(hipEventCreate(&e1));
+        a.timing_start = e0;
+        a.timing_stop = e1;
     }
+    const int lr = mm::launch_fused(a, ws->stream);
+    if (lr != 0) {
+        if (e0) hipEventDestroy(e0);
+        if (e1) hipEventDestroy(e1);
+        if (lr == -2) return MM_BATCH_FALLBACK;
+        g_last_error = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
+        return MM_ERR_HIP;
+    }
+    if (ws->timing) ws->events.emplace_back(e0, e1);
+    ws->last_path = MM_PATH_FUSED;
+    MM_HIP(hipMemcpyAsync(ws->h_batch, ws->batch_offsets, (n_seqs + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                          ws->stream));
+    MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ws->stream));
+    bi->launched = true;
+    return MM_OK;
+}
+
+// The other half: wait for an issued batch launch.  Returns MM_OK, MM_BATCH_REDO (a look-back spin ran out: the workspace
+// is in ticket mode now, issue the batch again), MM_ERR_CAPACITY (the true total is in out_offsets[n_seqs]) or another error.
+static int batch_finish(mm_workspace_t *ws, BatchIssue *bi, bool has_pos, uint64_t capacity, uint64_t *out_offsets) {
+    const uint64_t n_seqs = bi->n_seqs;
+    if (!bi->launched) {
+        for (uint64_t s = 0; s <= n_seqs; ++s) out_offsets[s] = 0;
+        return MM_OK;
+    }
+    MM_HIP(hipStreamSynchronize(ws->stream));
+    bi->seqs.clear();
+    bi->tile_seq.clear();
+    const int je = judge_run_error(ws);
+    if (je < 0) return je;
+    if (je == 1) return MM_BATCH_REDO;  // (the workspace is in ticket mode now)
     // sequences without a window own no tile: their slice is empty and starts where the next one does
+    unsigned long long *offs = ws->h_batch;
     offs[n_seqs] = ws->h_total[0];
     for (uint64_t s = n_seqs; s-- > 0;)
         if (offs[s] == ~0ull) offs[s] = offs[s + 1];
     for (uint64_t s = 0; s <= n_seqs; ++s) out_offsets[s] = offs[s];
-    if (d_out_pos && out_offsets[n_seqs] > capacity) return MM_ERR_CAPACITY;
+    if (has_pos && out_offsets[n_seqs] > capacity) return MM_ERR_CAPACITY;
     return MM_OK;
+}
+
+static int run_batch_one_launch(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_seqs,
+                                const void *const *d_packed, const uint64_t *packed_bytes,
+                                const uint64_t *base_offsets, const uint64_t *n_bases,
+                                uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
+                                uint64_t *out_offsets) {
+    BatchIssue bi;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int r = batch_issue(plan, ws, n_seqs, d_packed, packed_bytes, base_offsets, n_bases, d_out_pos, d_out_sk, capacity, &bi);
+        if (r) return r;
+        r = batch_finish(ws, &bi, d_out_pos != nullptr, capacity, out_offsets);
+        if (r != MM_BATCH_REDO) return r;
+    }
+    g_last_error = "look-back scan timed out in ticket mode";
+    return MM_ERR_HIP;
 }
 
 int mm_run_batch_device(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_seqs,
@@ -2778,64 +2826,95 @@ int mm_run_batch_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, con
     const uint64_t l = (uint64_t)plan->k + plan->w - 1;
     const double dens = plan->mode == MM_OPEN_SYNCMERS ? 1.0 / plan->w
                         : plan->mode == MM_CLOSED_SYNCMERS ? 2.0 / plan->w : 2.0 / (plan->w + 1.0);
-    std::vector<ShardResult> res(N);
-    // one host thread per entry: a batch launch reads its offsets back, so the entries would run one after the other
-    // from one thread
-    auto run_entry = [&](uint64_t i) {
-        ShardResult &r = res[i];
+    // One batch launch per entry, ISSUED from this thread one after the other (nothing waits), then waited for in
+    // turn - the model of mm_run_sharded_device (round 4 ran a host thread per entry here because a batch launch read
+    // its offsets back synchronously; round 5 split it into batch_issue / batch_finish).  An entry whose plan has no
+    // fused kernel, whose lists time out or whose results need more room than the expected density is run again,
+    // alone and synchronously, when its turn to be waited for comes.
+    struct Entry {
+        std::vector<const void *> dptr;
+        std::vector<uint64_t> dbytes, offs, lens;
+        BatchIssue bi;
+        uint64_t want = 0;
+        bool issued = false, sync_path = false;
+    };
+    std::vector<Entry> ent(N);
+    g->ran = false;  // (the result buffers now hold a batch: mm_device_group_result / _gather must not read them as shards)
+    g->batch_ran = false;
+    auto grow_entry = [&](uint64_t i, uint64_t want) -> int {
+        mm_device_group::Shard &sh = g->shard[i];
+        int rc = grow(sh.d_pos, sh.cap_pos, want ? want : 1, sizeof(uint32_t));
+        if (rc == MM_OK && want_superkmers) rc = grow(sh.d_sk, sh.cap_sk, want ? want : 1, sizeof(uint32_t));
+        return rc;
+    };
+    auto cap_of = [&](uint64_t i) -> uint64_t {
+        const mm_device_group::Shard &sh = g->shard[i];
+        return want_superkmers ? (sh.cap_pos < sh.cap_sk ? sh.cap_pos : sh.cap_sk) : sh.cap_pos;
+    };
+    for (uint64_t i = 0; i < N; ++i) {
         mm_device_group::BatchEntry &b = g->batch[i];
         mm_device_group::Shard &sh = g->shard[i];
-        mm_workspace *ws = g->ws[i];
+        Entry &e = ent[i];
         sh.count = 0;
         sh.has_sk = want_superkmers != 0;
         b.offs.assign(b.seqs.size() + 1, 0);
-        if (b.seqs.empty()) return;
-        auto fail = [&](int rc) {
-            r.rc = rc;
-            r.err = g_last_error;
-        };
-        if (hipSetDevice(ws->device) != hipSuccess) return fail(MM_ERR_HIP);
-        std::vector<const void *> dptr(b.seqs.size());
-        std::vector<uint64_t> dbytes(b.seqs.size()), offs(b.seqs.size()), lens(b.seqs.size());
+        if (b.seqs.empty()) continue;
+        MM_HIP(hipSetDevice(g->ws[i]->device));
+        const size_t m = b.seqs.size();
+        e.dptr.resize(m);
+        e.dbytes.resize(m);
+        e.offs.resize(m);
+        e.lens.resize(m);
         uint64_t windows = 0;
-        for (size_t j = 0; j < b.seqs.size(); ++j) {
+        for (size_t j = 0; j < m; ++j) {
             const uint64_t s = b.seqs[j];
-            offs[j] = base_offsets ? base_offsets[s] : 0;
-            lens[j] = n_bases[s];
-            if ((offs[j] + lens[j] + 3) / 4 > b.nbytes[j]) return fail(MM_ERR_CAPACITY);  // more bases than were uploaded
-            dptr[j] = b.d_buf + b.at[j];
-            dbytes[j] = b.nbytes[j] + 64;
-            windows += lens[j] >= l ? lens[j] - l + 1 : 0;
+            e.offs[j] = base_offsets ? base_offsets[s] : 0;
+            e.lens[j] = n_bases[s];
+            if ((e.offs[j] + e.lens[j] + 3) / 4 > b.nbytes[j]) return MM_ERR_CAPACITY;  // more bases than were uploaded
+            e.dptr[j] = b.d_buf + b.at[j];
+            e.dbytes[j] = b.nbytes[j] + 64;
+            windows += e.lens[j] >= l ? e.lens[j] - l + 1 : 0;
         }
-        uint64_t want = (uint64_t)(dens * 1.15 * (double)windows) + 4096;
-        if (want > windows) want = windows;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            int rc = grow(sh.d_pos, sh.cap_pos, want ? want : 1, sizeof(uint32_t));
-            if (rc == MM_OK && want_superkmers) rc = grow(sh.d_sk, sh.cap_sk, want ? want : 1, sizeof(uint32_t));
-            if (rc) return fail(rc);
-            const uint64_t cap = want_superkmers ? (sh.cap_pos < sh.cap_sk ? sh.cap_pos : sh.cap_sk) : sh.cap_pos;
-            rc = mm_run_batch_device(plan, ws, b.seqs.size(), dptr.data(), dbytes.data(), offs.data(), lens.data(), sh.d_pos,
-                                     want_superkmers ? sh.d_sk : nullptr, cap, b.offs.data());
-            if (rc == MM_ERR_CAPACITY && attempt == 0) {  // denser than expected: again with what it needs
-                want = b.offs[b.seqs.size()];
+        e.want = (uint64_t)(dens * 1.15 * (double)windows) + 4096;
+        if (e.want > windows) e.want = windows;
+        int rc = grow_entry(i, e.want);
+        if (rc) return rc;
+        rc = batch_issue(plan, g->ws[i], m, e.dptr.data(), e.dbytes.data(), e.offs.data(), e.lens.data(), sh.d_pos,
+                         want_superkmers ? sh.d_sk : nullptr, cap_of(i), &e.bi);
+        if (rc == MM_BATCH_FALLBACK) e.sync_path = true;  // (no fused kernel for this plan: the per-sequence loop, below)
+        else if (rc) return rc;
+        else e.issued = true;
+    }
+    for (uint64_t i = 0; i < N; ++i) {
+        mm_device_group::BatchEntry &b = g->batch[i];
+        mm_device_group::Shard &sh = g->shard[i];
+        Entry &e = ent[i];
+        if (b.seqs.empty()) continue;
+        MM_HIP(hipSetDevice(g->ws[i]->device));
+        const size_t m = b.seqs.size();
+        int rc = MM_OK;
+        if (e.issued) {
+            rc = batch_finish(g->ws[i], &e.bi, true, cap_of(i), b.offs.data());
+            if (rc == MM_BATCH_REDO) e.sync_path = true;
+            else if (rc == MM_ERR_CAPACITY) {  // denser than expected: again with what it needs
+                e.want = b.offs[m];
+                e.sync_path = true;
+            } else if (rc) return rc;
+        }
+        for (int attempt = 0; e.sync_path && attempt < 2; ++attempt) {
+            rc = grow_entry(i, e.want);
+            if (rc) return rc;
+            rc = mm_run_batch_device(plan, g->ws[i], m, e.dptr.data(), e.dbytes.data(), e.offs.data(), e.lens.data(), sh.d_pos,
+                                     want_superkmers ? sh.d_sk : nullptr, cap_of(i), b.offs.data());
+            if (rc == MM_ERR_CAPACITY && attempt == 0) {
+                e.want = b.offs[m];
                 continue;
             }
-            if (rc) return fail(rc);
+            if (rc) return rc;
             break;
         }
-        sh.count = b.offs[b.seqs.size()];
-    };
-    {
-        std::vector<std::thread> th;
-        for (uint64_t i = 1; i < N; ++i) th.emplace_back(run_entry, i);
-        run_entry(0);
-        for (std::thread &t : th) t.join();
+        sh.count = b.offs[m];
     }
-    for (uint64_t i = 0; i < N; ++i)
-        if (res[i].rc) {
-            g_last_error = res[i].err;
-            return res[i].rc;
-        }
     uint64_t sum = 0;
     for (uint64_t s = 0; s < n_seqs; ++s) {
         const mm_device_group::BatchEntry &b = g->batch[(size_t)g->seq_entry[s]];
@@ -2845,7 +2924,6 @@ int mm_run_batch_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, con
     }
     if (total) *total = sum;
     g->batch_ran = true;
-    g->ran = false;  // (the result buffers now hold a batch: mm_device_group_result / _gather must not read them as shards)
     return MM_OK;
 }
 
