@@ -595,11 +595,12 @@ def main():
             return int(offs[-1])
     torch.cuda.synchronize(dev)
 
-    # Clock ramp (round 5; untimed, BEFORE the W warm-up steps, disclosed as config.clock_ramp_ms).  The set-up above
-    # (allocation, synthetic input) leaves the chip idle and its shader clock low; W = 5 steps of a 1.5 ms kernel do
-    # not bring it back - the same kernel read 1.56 ms per step behind five warm-up steps and 1.46 ms a second later on
-    # one box (profiles/r05_clock_ramp.txt).  `value` is a sustained rate, so the chip runs this step back to back for
-    # MM_BENCH_RAMP_MS (default 200) milliseconds first; the W warm-up steps and the K timed steps follow as before.
+    # Ramp (round 5; untimed, BEFORE the W warm-up steps, disclosed as config.clock_ramp_ms).  The set-up above
+    # (allocation, synthetic input) leaves the chip idle; W = 5 steps of a 1.5 ms kernel do not bring it back to its
+    # sustained state - the same kernel read 1.56 ms per step behind five warm-up steps and 1.49 ms behind 200 ms of
+    # steps on one box, 4.4 %, with the shader clock reading no lower in the slow case (profiles/r05_clock_ramp.txt: it is
+    # not only the shader clock that comes up under load).  `value` is a sustained rate, so the chip runs this step back
+    # to back for MM_BENCH_RAMP_MS (default 200) milliseconds first; the W warm-up steps and the K timed steps follow.
     ramp_ms = float(os.environ.get("MM_BENCH_RAMP_MS", "200"))
     t_ramp = time.perf_counter()
     while (time.perf_counter() - t_ramp) * 1e3 < ramp_ms:
@@ -861,17 +862,26 @@ def main():
                 ho[:] = 0
                 cnt = C.c_uint64()
                 plan = b.plan()
+                # Ten calls back to back; `ms` = the median of the last five.  The first calls of a process whose link has
+                # been idle run far below the link's rate - 71-72 ms for calls 2-4 of this script in rounds 4 and 5, 41 ms
+                # from the fifth on, in the same process, on the same buffers (profiles/r05_host_path.txt) - so every call's
+                # time is printed (`calls_ms`) and the steady state is what is compared with the link's floor.
                 e2e = []
-                for i in range(4):
+                for i in range(10):
+                    if i == 1 and os.environ.get("MM_ENV_DYNAMIC"):
+                        os.environ["MM_PIPE_TRACE"] = "1"  # (diagnostics: the chunk milestones of an early call, to stderr)
                     te = time.perf_counter()
                     sm._check(L.mm_run_host(plan.h, ws.h, hp.ctypes.data_as(C.POINTER(C.c_uint8)), 0, n,
                                             ho.ctypes.data_as(C.POINTER(C.c_uint32)), None, n_out + 1024, C.byref(cnt)))
-                    if i:
-                        e2e.append((time.perf_counter() - te) * 1e3)
+                    e2e.append((time.perf_counter() - te) * 1e3)
+                    os.environ.pop("MM_PIPE_TRACE", None)
                 assert cnt.value == n_out
-                m = statistics.median(e2e)
+                calls_ms = [round(x, 2) for x in e2e]
+                m = statistics.median(e2e[5:])
                 host_ab = None
-                if os.environ.get("MM_BENCH_HOST_AB"):  # diagnostics: the call's mechanisms in THIS process state
+                # (diagnostics: the call's mechanisms in THIS process state - on request, or when the call took far longer
+                # than it does in a fresh process: 39.5 ms on every box of round 5, 71-72 ms in one run of this script in three)
+                if os.environ.get("MM_BENCH_HOST_AB") or (m > 55.0 and os.environ.get("MM_ENV_DYNAMIC")):
                     host_ab = {}
                     for om, im in (("engine", "engine"), ("blit", "engine"), ("direct", "engine"), ("blit", "blit")):
                         os.environ["MM_HOST_OUT"], os.environ["MM_HOST_IN"] = om, im
@@ -884,6 +894,17 @@ def main():
                         host_ab[f"out={om},in={im}"] = round(min(tt), 2)
                     os.environ.pop("MM_HOST_OUT", None)
                     os.environ.pop("MM_HOST_IN", None)
+                    os.environ["MM_PIPE_TRACE"] = "1"  # (the chunks' milestones of one more call, to stderr)
+                    sm._check(L.mm_run_host(plan.h, ws.h, hp.ctypes.data_as(C.POINTER(C.c_uint8)), 0, n,
+                                            ho.ctypes.data_as(C.POINTER(C.c_uint32)), None, n_out + 1024, C.byref(cnt)))
+                    os.environ.pop("MM_PIPE_TRACE", None)
+                    try:
+                        want = {f"{hp.ctypes.data:x}", f"{ho.ctypes.data:x}"}
+                        for ln in open("/proc/self/numa_maps"):
+                            if ln.split(" ", 1)[0] in want:
+                                print("[numa_maps] " + ln.strip(), file=sys.stderr, flush=True)
+                    except Exception:
+                        pass
                 # the link itself, measured beside it (this figure moved 39.6 -> 71.4 ms between two driver boxes of round
                 # 4): 512 MiB each way between the same page-locked buffers and the device - each direction alone and,
                 # since round 5, BOTH AT ONCE (mm_link_probe: the copy engines on two streams).  The two directions do not
@@ -933,10 +954,11 @@ def main():
                               "what": "mm_run_host: H2D of the packed bytes + kernel + D2H of the positions, "
                                       "page-locked caller buffers (mm_host_alloc), pipelined in 16 chunks (at most two "
                                       "uploads and two downloads in the runtime's hands at a time, counts polled from "
-                                      "page-locked words the kernels store); median of 3 after 1 warm-up; PCIe-bound, "
-                                      "never part of `value`",
+                                      "page-locked words the kernels store); ten calls back to back, `ms` = median of the "
+                                      "last five, every call in `calls_ms`; PCIe-bound, never part of `value`",
                               "ms_over_floor": (round(m / link["floor_ms_at_these_rates"], 3)
                                                 if isinstance(link.get("floor_ms_at_these_rates"), float) else None)}
+                end_to_end["calls_ms"] = calls_ms
                 if host_ab:
                     end_to_end["mechanisms_ms"] = host_ab
                 del hp, ho, hp_owner, ho_owner

@@ -708,11 +708,13 @@ static int prepare_window_ambiguity(mm_workspace_t *ws, const AmbArgs &amb, uint
     const uint64_t n_dwords = (byte_shift + amb.bytes + 3) / 4;
     if (n_dwords == 0 || n_dwords >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     if ((bit0 + span_bases + 31) / 32 > n_dwords) return MM_ERR_CAPACITY;
-    const uint64_t need = (win_end + 31) / 32 + 2;
+    // (pad dwords: read by the one-block-ahead prefetch of the last lanes - two for the 8-byte views, four for the
+    // 16-byte loads of the large windows' walk, which must lie INSIDE the buffer descriptor's range as a whole)
+    const uint64_t kPad = 8;
+    const uint64_t need = (win_end + 31) / 32 + kPad;
     int r = grow(ws->wamb, ws->wamb_dwords, need, sizeof(uint32_t));
     if (r) return r;
-    // the two pad dwords are read by the one-block-ahead prefetch of the last lanes
-    MM_HIP(hipMemsetAsync(ws->wamb + (need - 2), 0, 2 * sizeof(uint32_t), ws->stream));
+    MM_HIP(hipMemsetAsync(ws->wamb + (need - kPad), 0, kPad * sizeof(uint32_t), ws->stream));
     if (mm::launch_window_ambiguity(reinterpret_cast<const uint32_t *>(a - byte_shift), (uint32_t)n_dwords,
                                     bit0, l, win_begin, win_end, ws->wamb, ws->stream))
         return hip_fail(hipGetLastError(), "window_ambiguity");
@@ -1494,9 +1496,10 @@ static int run_host_common(const mm_plan_t *plan, mm_workspace_t *ws, const void
 // total into a page-locked word of its own: no copies on the kernels' stream), and the host only polls those words to
 // size each chunk's device -> host copy, which waits for its kernel through an event on the device side.
 // The mechanisms of the two legs can be switched (results identical; A/B per box, tools/host_link_diag.sh):
-//   MM_HOST_OUT=engine (default: hipMemcpyAsync, a copy engine) | blit (a copy kernel that reads its range from device
-//   memory and stores into the caller's page-locked buffer: no host involvement at all) | direct (the fused kernel's own
-//   copy-out stores go straight into the caller's page-locked buffer);  MM_HOST_IN=engine | blit;  MM_PIPE_CHUNKS=n.
+//   MM_HOST_OUT=blit (default: a copy kernel that reads its range from device memory and stores into the caller's
+//   page-locked buffer - no host involvement, and no dependence on the state of the copy engines, see below) | engine
+//   (hipMemcpyAsync) | direct (the fused kernel's own copy-out stores go straight into the caller's page-locked buffer);
+//   MM_HOST_IN=engine (default) | blit;  MM_PIPE_CHUNKS=n.
 // blit / direct need buffers the device can address (mm_host_alloc, hipHostMalloc, hipHostRegister); other buffers
 // keep the engines.  Returns MM_PIPE_FALLBACK if the caller should take the one-shot path instead.
 static const int MM_PIPE_FALLBACK = 1;
@@ -1545,7 +1548,13 @@ static int run_host_pipelined(const mm_plan_t *plan, mm_workspace_t *ws, const u
     }
     if (!ws->h_pipe_dev) return MM_PIPE_FALLBACK;
     // mechanisms of the two legs
-    int out_mode = 0, in_mode = 0;  // 0 engine, 1 blit kernel, 2 (out only) the fused kernel's own stores
+    // Default since late round 5: uploads by a copy engine, downloads by the copy KERNEL.  The engines are 6 % faster once
+    // they run at their rate (41.0 against 43.5 ms per call) - but a process whose link has been idle gets there only
+    // after two to five calls: 68 / 48 / 39.5 ms in a fresh process, 91 / 78 / 71 / 71 / 71 / 44 / 41 ms at the end of
+    // bench.py, with a 20 ms stall of the first copies in the trace - and a caller that makes one call now and then
+    // lives in that state.  The copy kernel reads 43.5 ms from the second call on, every time
+    // (profiles/r05_host_path.txt, tools/gpu_host_cold.py).  MM_HOST_OUT=engine selects the engines for downloads.
+    int out_mode = 1, in_mode = 0;  // 0 engine, 1 blit kernel, 2 (out only) the fused kernel's own stores
     if (const char *e = mm::mm_env("MM_HOST_OUT")) out_mode = !strcmp(e, "blit") ? 1 : (!strcmp(e, "direct") ? 2 : 0);
     if (const char *e = mm::mm_env("MM_HOST_IN")) in_mode = !strcmp(e, "blit") ? 1 : 0;
     uint32_t *pos_alias = nullptr, *sk_alias = nullptr;
@@ -1642,6 +1651,14 @@ static int run_host_pipelined(const mm_plan_t *plan, mm_workspace_t *ws, const u
         if (q != hipSuccess) (void)hipGetLastError();
         return MM_OK;
     };
+    // MM_PIPE_TRACE=1 (diagnostics): host time stamps of every chunk's milestones, printed to stderr when the call ends
+    struct ChunkTrace {
+        double submit = 0, in_done = 0, count = 0, out_queued = 0, out_done = 0;
+    };
+    const bool tracing = mm::mm_env("MM_PIPE_TRACE") != nullptr;
+    std::vector<ChunkTrace> tr(tracing ? n_chunks : 0);
+    const auto t_call = std::chrono::steady_clock::now();
+    auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
     uint64_t next_in = 0, in_retired = 0;    // chunks submitted / whose upload is known to be complete
     uint64_t next_out = 0, out_retired = 0;  // chunks whose count was taken / whose download is known to be complete
     uint64_t done_total = 0;
@@ -1650,6 +1667,7 @@ static int run_host_pipelined(const mm_plan_t *plan, mm_workspace_t *ws, const u
     while (next_out < n_chunks && !broken) {
         bool progress = false;
         while (next_in < n_chunks && (lim_in == 0 || next_in - in_retired < lim_in)) {
+            if (tracing) tr[next_in].submit = now_ms();
             r = submit_chunk(next_in++);
             if (r) return r;
             progress = true;
@@ -1658,12 +1676,18 @@ static int run_host_pipelined(const mm_plan_t *plan, mm_workspace_t *ws, const u
         if (lim_in && in_retired < next_in) {
             r = done(ws->ev_in[in_retired], &yes);
             if (r) return r;
-            if (yes) ++in_retired, progress = true;
+            if (yes) {
+                if (tracing) tr[in_retired].in_done = now_ms();
+                ++in_retired, progress = true;
+            }
         }
         if (lim_out && out_retired < next_out) {
             r = done(ws->ev_out[out_retired], &yes);
             if (r) return r;
-            if (yes) ++out_retired, progress = true;
+            if (yes) {
+                if (tracing) tr[out_retired].out_done = now_ms();
+                ++out_retired, progress = true;
+            }
         }
         if (next_out < next_in && (lim_out == 0 || next_out - out_retired < lim_out)) {
             const uint64_t c = next_out;
@@ -1683,6 +1707,7 @@ static int run_host_pipelined(const mm_plan_t *plan, mm_workspace_t *ws, const u
                 } else {
                     if (tot > cap) over = true;
                     const uint64_t upto = tot < cap ? tot : cap;
+                    if (tracing) tr[c].count = now_ms();
                     if (out_mode == 0 && upto > done_total) {
                         MM_HIP(hipStreamWaitEvent(ws->copy_out, ws->ev_k[c], 0));
                         MM_HIP(hipMemcpyAsync(out_pos + done_total, ws->d_out + done_total,
@@ -1692,6 +1717,7 @@ static int run_host_pipelined(const mm_plan_t *plan, mm_workspace_t *ws, const u
                                                   (upto - done_total) * sizeof(uint32_t), hipMemcpyDeviceToHost, ws->copy_out));
                     }
                     if (lim_out) MM_HIP(hipEventRecord(ws->ev_out[c], ws->copy_out));
+                    if (tracing) tr[c].out_queued = now_ms();
                     done_total = tot;
                     ++next_out;
                     progress = true;
@@ -1702,6 +1728,13 @@ static int run_host_pipelined(const mm_plan_t *plan, mm_workspace_t *ws, const u
     }
     MM_HIP(hipStreamSynchronize(ws->stream));
     MM_HIP(hipStreamSynchronize(ws->copy_out));
+    if (tracing) {
+        fprintf(stderr, "[mm pipe] %llu chunks, out=%d in=%d, in flight %llu / %llu, call %.2f ms\n", (unsigned long long)n_chunks,
+                out_mode, in_mode, (unsigned long long)lim_in, (unsigned long long)lim_out, now_ms());
+        for (uint64_t c = 0; c < n_chunks; ++c)
+            fprintf(stderr, "[mm pipe]  chunk %2llu: queued %7.2f  upload done %7.2f  count known %7.2f  download queued %7.2f  done %7.2f\n",
+                    (unsigned long long)c, tr[c].submit, tr[c].in_done, tr[c].count, tr[c].out_queued, tr[c].out_done);
+    }
     const int je = judge_run_error(ws);
     if (je < 0) return je;
     if (je == 1) return MM_PIPE_FALLBACK;  // a look-back spin ran out in some chunk: the whole call again, one shot, ticket mode

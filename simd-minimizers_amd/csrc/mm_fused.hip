@@ -120,6 +120,12 @@ uint32_t legal_nblk(uint32_t w, uint32_t mode, uint32_t want, uint32_t cap_limit
     return want;
 }
 
+// Landing area of the skip-ambiguous walk's look-ahead loads (kAmbiLand, mm_fused_impl.h): behind the lists, for runs with
+// ambiguity bits whose kernel uses it.  Returns its bytes (0: none) and the offset the kernel is told.
+static uint32_t ambi_landing(uint32_t w, const void *wamb) {
+    return (wamb && ambi_land_rule((int)w)) ? kLandBytes : 0u;  // (in FRONT of the lists; a multiple of 16 bytes)
+}
+
 struct Geometry {
     uint32_t nblk, S, NB, list_cap, lds_bytes;
     uint64_t nblocks;
@@ -648,6 +654,9 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.read_offsets = nullptr;
     p.wamb = a.wamb;
     p.wamb_dwords = a.wamb_dwords;
+    const uint32_t land_bytes = ambi_landing(a.w, a.wamb);
+    p.land_bytes = land_bytes;
+    if (g.lds_bytes + land_bytes > kMaxLdsBytes) return -2;  // (cannot happen with the default lanes: 39 KB of lists above w = 32)
     p.batch_seqs = a.batch_seqs;
     p.batch_tile_seq = a.batch_tile_seq;
     p.batch_offsets = a.batch_offsets;
@@ -672,10 +681,10 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         return -1;
     // (the ticket is only read in ticket mode: one stream operation less per run otherwise)
     if (a.use_ticket && hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
-    uint32_t lds_bytes = g.lds_bytes;
+    uint32_t lds_bytes = g.lds_bytes + land_bytes;
     if (p.debug & 16u) {  // timing experiment (wrong results): lists of half the capacity, overflow ignored
         p.list_cap = g.list_cap / 2 > a.w + 2 ? g.list_cap / 2 : a.w + 2;
-        lds_bytes = p.list_cap * stride_of(a);
+        lds_bytes = p.list_cap * stride_of(a) + land_bytes;
     }
     if (const char *pad = mm_env("MM_LDS_PAD")) g_lds_pad = (uint32_t)atoi(pad);  // occupancy experiments
     p.trace = nullptr;
@@ -757,6 +766,7 @@ int launch_split(const RunArgs &a, const SplitBuffers &b, hipStream_t stream) {
     const Geometry g = geometry(a);
     if (g.nblocks == 0) return 0;
     if (g.lds_bytes > kMaxLdsBytes || a.batch_tile_seq) return -2;
+    if (a.wamb && ambi_land_rule((int)a.w)) return -2;  // (the walk kernel has no landing area: the fused kernel takes these)
     const bool sk = a.out.sk != nullptr && a.mode == 0;
     const KernelRef kr = resolve_walk_kernel(a.w, a.canonical_windows, (int)a.ht.canonical, a.mode, sk);
     if (!kr) return -2;
@@ -779,6 +789,7 @@ int launch_split(const RunArgs &a, const SplitBuffers &b, hipStream_t stream) {
     p.read_lens = nullptr;
     p.read_starts = nullptr;
     p.read_offsets = nullptr;
+    p.land_bytes = 0;  // (plans that need the landing area were refused above)
     p.wamb = a.wamb;
     p.wamb_dwords = a.wamb_dwords;
     p.batch_seqs = a.batch_seqs;
@@ -968,6 +979,9 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.read_offsets = a.read_offsets;
     p.wamb = a.wamb;
     p.wamb_dwords = a.wamb_dwords;
+    const uint32_t land_bytes = ambi_landing(a.w, a.wamb);
+    p.land_bytes = land_bytes;
+    if (lds_bytes + land_bytes > 159u * 1024u) return -3;
     p.batch_seqs = nullptr;
     p.batch_tile_seq = nullptr;
     p.batch_offsets = nullptr;
@@ -984,7 +998,7 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
         return -1;
     // (the ticket is only read in ticket mode: one stream operation less per run otherwise)
     if (a.use_ticket && hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
-    return launch_kernel(kr, (uint32_t)nblocks, lds_bytes, stream, p, a.timing_start, a.timing_stop);
+    return launch_kernel(kr, (uint32_t)nblocks, lds_bytes + land_bytes, stream, p, a.timing_start, a.timing_stop);
 }
 
 }  // namespace mm

@@ -128,6 +128,10 @@ struct FusedParams {
     uint32_t taper_min_nblk;
     unsigned long long taper_start;
     uint32_t append;     // 1: *out.total holds the outputs before this launch (carry-in of tile 0), 0: starts at 0
+    // Round 5, skip-ambiguous walks over large windows: bytes of the landing area of the walk's look-ahead loads
+    // (kAmbiLand in lane_walk; 4 waves x kLandWaveBytes) at the FRONT of the dynamic LDS - the lists start behind it, so
+    // that list entries past a list's capacity still fall beyond the workgroup's allocation and never into it; 0 = none.
+    uint32_t land_bytes;
     // reads mode (READS kernels): one lane per read, reads at a fixed stride in the buffer
     uint32_t n_reads;
     uint32_t reads_per_lane;            // READS: consecutive reads one lane walks one after the other (1..4)
@@ -352,7 +356,28 @@ struct LaneCtx {
     uint32_t nblk;           // W-blocks this lane walks
     const uint32_t *seq_d;   // the sequence the tile reads (p.seq, or the batch entry)
     uint32_t seq_dwords;
+    uint32_t land;           // LDS byte address of this WAVE's landing area (kAmbiLand walks), 0 = none (wave-uniform)
 };
+
+// Skip-ambiguous walks over large windows (round 5).  The walk that knows skipped windows carries its
+// ambiguity words and their look-ahead on top of a register budget that is already full above w = 32 (168 registers, three
+// waves per SIMD), and the compiler made room by spilling exactly the LANDING registers of the look-ahead loads - the fifth
+// dword of both sequence streams and the ambiguity dwords - which puts an s_waitcnt vmcnt(0) behind each load: every block
+// waited for the memory latency it was meant to hide, and a dirty wave walked at half speed (k=31 w=51: 1.03 ms per Gbp
+// against 0.55 plain).  Those loads now land in LDS (buffer_load ... lds: no register until the data is used): per wave and
+// parity 64 x 16 bytes of ambiguity bits and 2 x 64 x 4 bytes of fifth dwords, two parities.  The launcher allocates the
+// area in FRONT of the lists (FusedParams::land_bytes) for runs with ambiguity bits whose kernel uses it - in front: the
+// lists rely on entries past their capacity falling beyond the workgroup's allocation (see "redo"); behind them the area
+// took those entries, a dense tile's walk read its own overflow as ambiguity bits and counted two windows too few
+// (k = 1, w = 55: every base its own k-mer, 106 emits into a list of 23).
+constexpr uint32_t kLandAmbBytes = 64u * 16u, kLandQ4Bytes = 64u * 4u;
+constexpr uint32_t kLandParityBytes = kLandAmbBytes + 2u * kLandQ4Bytes;   // 1536
+constexpr uint32_t kLandWaveBytes = 2u * kLandParityBytes;                 // 3072
+constexpr uint32_t kLandBytes = kFusedWaves * kLandWaveBytes;              // 12288 per workgroup
+#ifndef MM_AMBI_LAND
+#define MM_AMBI_LAND 1  // (0: A/B, the register look-ahead of rounds 2-4)
+#endif
+constexpr bool ambi_land_rule(int W) { return MM_AMBI_LAND && W >= 32 && W <= 96 && wide_group_blocks(W) != 0; }
 
 // One lane walks its S windows.  List mode: appends emitted 16-bit values to the lane's LDS
 // list (entries past the capacity are dropped but counted).  DIRECT mode: stores final values
@@ -474,6 +499,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
 #else
     WideBuf Wa[2], Wr[2];  // [0] working buffer of the current group, [1] landing buffer of the next one
 #endif
+    constexpr bool kAmbiLand = AMBI && ambi_land_rule(W);  // (the look-ahead loads that land in LDS: see below)
     uint32_t gp_in = 0, gp_out = 0;  // first base (tile-relative) of the next group to load
     auto wide_load = [&](uint32_t gpos, WideBuf &w) {
         const uint32_t off = (gpos >> 4) << 2;
@@ -484,7 +510,35 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         w.q[1] = v.y;
         w.q[2] = v.z;
         w.q[3] = v.w;
-        w.q[4] = ND == 5 ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 16, 0) : 0u;
+        w.q[4] = (ND == 5 && !kAmbiLand) ? __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 16, 0) : 0u;
+    };
+    // kAmbiLand (see ambi_land_rule): the look-ahead loads whose landing registers the compiler used to spill - the fifth
+    // dword of either stream, the ambiguity dwords - land in LDS instead.  `lpar` / `apar`: parity of the landing
+    // buffer the NEXT group's fifth dwords / the NEXT block's ambiguity bits go to (wave-uniform).
+    const uint32_t land = ctx.land;
+    // (the lane's index is made again at every use - two instructions - instead of living in a register across the walk:
+    // a register the allocator spills is reloaded with a scratch load, and a scratch load in the loop waits for every
+    // look-ahead load in front of it)
+    // (volatile: the compiler would otherwise hoist the loop-invariant address out of the block loop - and spill it)
+    auto lane_id_now = [&]() -> uint32_t {
+        uint32_t x;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+        return x;
+    };
+    uint32_t lpar = 0, apar = 0;
+    typedef __attribute__((address_space(3))) void *LdsPtr;
+    auto lds_u32 = [&](uint32_t addr) -> uint32_t {
+        return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)addr);
+    };
+    // which == 0: stream entering the hash, 1: leaving it
+    auto land_q4_load = [&](uint32_t gpos, uint32_t par, uint32_t which) {
+        const uint32_t off = (gpos >> 4) << 2;
+        const uint32_t base = __builtin_amdgcn_readfirstlane(land + par * kLandParityBytes + kLandAmbBytes + which * kLandQ4Bytes);
+        // (the 16 bytes go into the SCALAR offset: an instruction offset of a load to LDS moves the LDS address as well)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(uintptr_t)base, 4, off, 16, 0, 0);
+    };
+    auto land_q4_read = [&](uint32_t par, uint32_t which) -> uint32_t {
+        return lds_u32(land + par * kLandParityBytes + kLandAmbBytes + which * kLandQ4Bytes + 4u * lane_id_now());
     };
     // the buffer that becomes current: shifted down by the byte part of the lane's position; returns the bit part
     auto wide_normalise = [&](WideBuf &dst, const WideBuf &w) -> uint32_t {
@@ -554,6 +608,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
 #ifndef MM_EXP_ONE_STREAM
             wide_load(gp_out, Wr[1]);
 #endif
+            if (kAmbiLand && ND == 5) {
+                land_q4_load(gp_in, lpar, 0u);
+                land_q4_load(gp_out, lpar, 1u);
+            }
             gp_in += (uint32_t)(MG * W);
             gp_out += (uint32_t)(MG * W);
         }
@@ -640,11 +698,29 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         return __builtin_amdgcn_alignbit(d[1], d[0], bit & 31u);
     };
     uint32_t aw[NSUBA], aw_next[NSUBA];
-    if (AMBI) {
+    // kAmbiLand: the 128 bits from the dword that holds the block's first window bit on (31 + W <= 127) land in LDS
+    auto land_amb_load = [&](uint32_t bit, uint32_t par) {
+        const uint32_t base = __builtin_amdgcn_readfirstlane(land + par * kLandParityBytes);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (LdsPtr)(uintptr_t)base, 16, (bit >> 5) << 2, 0, 0, 0);
+    };
+    auto land_amb_read = [&](uint32_t bit, uint32_t par, uint32_t (&out)[NSUBA]) {
+        typedef uint32_t u32x4a __attribute__((ext_vector_type(4)));
+        const u32x4a d = *reinterpret_cast<const __attribute__((address_space(3))) u32x4a *>(
+            (uintptr_t)(land + par * kLandParityBytes + 16u * lane_id_now()));
+        const uint32_t dd[5] = {d.x, d.y, d.z, d.w, 0u};
+#pragma unroll
+        for (int g = 0; g < NSUBA; ++g) out[g] = __builtin_amdgcn_alignbit(dd[g + 1 < 5 ? g + 1 : 4], dd[g < 4 ? g : 3], bit & 31u);
+    };
+    if (AMBI && kAmbiLand) {
+        land_amb_load(ctx.abase, apar);
+#pragma unroll
+        for (int g = 0; g < NSUBA; ++g) aw_next[g] = 0u;
+    } else if (AMBI) {
 #pragma unroll
         for (int g = 0; g < NSUBA; ++g) aw_next[g] = aview(ctx.abase + 32u * (uint32_t)g);
-        if (MODE == 0 && !ctx.no_prev && (aview(ctx.abase - 1u) & 1u)) prev = 0xffffffffu;
     }
+    // (a lane whose predecessor window is skipped starts without a predecessor: its first clean window emits)
+    if (AMBI && MODE == 0 && !ctx.no_prev && (aview(ctx.abase - 1u) & 1u)) prev = 0xffffffffu;
 
     // ---- blocks 1..nblk: one window per step
     // next free list slot as a 32-bit LDS address (the low half of the flat address of LDS memory)
@@ -736,11 +812,27 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 asm volatile("" : "+v"(v2[g]));
             }
         }
+        if (AMBI && kAmbiLand) {
+            // This block's window bits come out of LDS (every load of the wave has to be back for that: the wait stands
+            // BEFORE this block's look-ahead loads are issued, so that it only waits for loads a block old), the next
+            // block's are sent there.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            land_amb_read(ctx.abase + (b - 1u) * (uint32_t)W, apar, aw);
+            if (ND == 5 && (KN >= 0 ? (uint32_t)KN : kn) == 0u) {
+                // (a new load group starts with this block: the fifth dwords of its two streams, under the same wait)
+                Wa[1].q[4] = land_q4_read(lpar, 0u);
+                Wr[1].q[4] = land_q4_read(lpar, 1u);
+                lpar ^= 1u;
+            }
+            apar ^= 1u;
+            land_amb_load(ctx.abase + b * (uint32_t)W, apar);
+        }
         if (MG != 0) {
             // wide loads: block b + 1 is block kn of its group; a new group takes the next buffer and starts the load
             // of the group after it (a harmless over-read after the last block)
             if ((KN >= 0 ? (uint32_t)KN : kn) == 0u) {
                 // (the landing buffer [1] is shifted into the working buffer [0]; then it takes the next load)
+                // (kAmbiLand: the fifth dwords were taken out of LDS at the top of the block)
                 sh_in = wide_normalise(Wa[0], Wa[1]);
 #ifdef MM_EXP_ONE_STREAM
                 sh_out = sh_in;
@@ -750,6 +842,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 sh_out = wide_normalise(Wr[0], Wr[1]);
                 wide_load(gp_in, Wa[1]);
                 wide_load(gp_out, Wr[1]);
+                if (kAmbiLand && ND == 5) {
+                    land_q4_load(gp_in, lpar, 0u);
+                    land_q4_load(gp_out, lpar, 1u);
+                }
                 MM_BUMP(gp_in, MG * W);
                 MM_BUMP(gp_out, MG * W);
 #endif
@@ -792,7 +888,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             qr[PFD - 2][g] = raw((int32_t)pl_out + 16 * g);
             if (kV2Load) q2[PFD - 2][g] = raw(pos_r2 + (PFD - 1) * W + 16 * g);
         }
-        if (AMBI) {
+        if (AMBI && !kAmbiLand) {
 #pragma unroll
             for (int g = 0; g < NSUBA; ++g) {
                 aw[g] = aw_next[g];
@@ -864,9 +960,15 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                     // collector's lanes (src/intrinsics/dedup.rs:147-155) - and its lane's slot pointer stands still, so
                     // what the append writes for it is overwritten by the lane's next entry (or falls behind the list's
                     // end).  `valid`: the lane's range check of partial walks (all ones otherwise).
-                    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)aw[AMBI ? (jj >> 5) : 0], jj & 31, 1);
-                    const uint32_t selx = sel | m;
-                    const uint32_t st = stride_v & ~m;
+                    // (round 5: in inline assembly - the compiler turned `stride & ~sext(bit)` into a shift to the sign bit, a
+                    // compare and a v_cndmask on VCC, 19 issue cycles per window where the three instructions below take 8;
+                    // the dirty walk of k=31 w=33 ran 2.0 x the plain one's time, profiles/r05_skip_dirty_walk.txt)
+                    // (the bit-field extract stays a builtin - its offset is a constant only after unrolling, which an "n"
+                    // constraint does not see under hiprtc - but its result is consumed by assembly, so it is made as such)
+                    uint32_t selx, st;
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)aw[AMBI ? (jj >> 5) : 0], jj & 31, 1);  // all ones: skipped
+                    asm("v_or_b32 %0, %1, %2" : "=v"(selx) : "v"(sel), "v"(m));
+                    asm("v_bitop3_b32 %0, %1, %2, %2 bitop3:0x30" : "=v"(st) : "v"(stride_v), "v"(m));      // stride & ~m
 #define MM_EMIT_SKIP(WR, SELB)                                                                        \
     asm volatile("v_cmp_ne_u32_sdwa vcc, %[sel], %[prev] src0_sel:" SELB " src1_sel:" SELB "\n\t"    \
                  "s_and_b64 vcc, vcc, %[ok]\n\t"                                                     \
@@ -1714,14 +1816,25 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         : (uint32_t)(((uint64_t)win_end - bw0) < NB ? ((uint64_t)win_end - bw0) : NB);
     const bool partial = READS || nvalid < NB;
 
+    // the lane lists: the dynamic LDS behind the landing area of the skip-ambiguous walk (none: land_bytes = 0)
+    uint8_t *const lists = smem + p.land_bytes;
     LaneCtx ctx;
     ctx.tab = s_tab;
-    ctx.list = smem + kEB * (uint32_t)tid;
+    ctx.list = lists + kEB * (uint32_t)tid;
     ctx.list_bytes = p.list_cap * kStride;
     ctx.dst = 0;
     ctx.nblk = nblk_t;
     ctx.seq_d = seq_d;
     ctx.seq_dwords = seq_dwords;
+    // landing area of the skip-ambiguous walk's look-ahead loads (behind the lists, one slice per wave; see kAmbiLand)
+    ctx.land = 0;
+    if (kAmbi && ambi_land_rule(W) && p.wamb) {
+        if (p.land_bytes < kLandBytes) {  // (a launcher that did not allocate it: never walk with a null landing area)
+            if (tid == 0) flag_error(p.out.error, 2u);
+            return;
+        }
+        ctx.land = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(smem) + (uint32_t)wave * kLandWaveBytes);
+    }
     bool lane_active = false;
     // READS: a lane walks reads_per_lane consecutive reads; read j of lane t is read
     // (bid * 256 + t) * R + j of the batch
@@ -1867,7 +1980,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     if (batch && tid == 0 && local_tile == 0 && !redo) p.batch_offsets[batch_s] = s_excl;
 
     if (!overflow) {
-        copy_out_wave<kE8, SK, READS>(smem, p.out, MM_DBG(p), wave, lane,
+        copy_out_wave<kE8, SK, READS>(lists, p.out, MM_DBG(p), wave, lane,
                                       (READS ? 0u : (uint32_t)bw0) - (MODE == 0 ? 1u : 0u), S, (uint32_t)kSkShift<W>,
                                       run0, wave_total, my_count, excl);
     } else if (READS) {

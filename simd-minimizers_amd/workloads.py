@@ -44,7 +44,11 @@ def component(name, ws, dev):
                 "what": f"reads mode: {n_reads} reads x {rl} bp, canonical minimizers k={k} w={w}"
                         + (" with super-k-mer indices" if sk is not None else "") + ", one launch (src/lib.rs:378 per read)",
                 "kernels": ["fused_kernel"]}
-    if name == "SKIP":
+    if name in ("SKIP", "SKIP_W33", "SKIP_W51", "PLAIN_W33", "PLAIN_W51"):
+        # (SKIP: the bench row, k=21 w=11.  SKIP_W33 / _W51 and their PLAIN_ twins: tools/prof_head.py stalls:<name> - the dirty
+        # walk of the large windows beside the plain walk on the same sequence, profiles/r05_skip_dirty_walk.txt)
+        if name != "SKIP":
+            k, w = 31, int(name[-2:])
         n = 1_000_000_000
         d = _generate(ws, dev, n, 2)
         amb = torch.zeros((n + 7) // 8 + 64, dtype=torch.uint8, device=dev)
@@ -58,10 +62,13 @@ def component(name, ws, dev):
         b = canonical_minimizers(k, w).workspace(ws)
 
         def step():
-            b.run_skip_ambiguous_device(d, amb, n, out, sync=False, d_count=cnt)
+            if name.startswith("PLAIN"):
+                b.run_device(d, n, out, sync=False, d_count=cnt)
+            else:
+                b.run_skip_ambiguous_device(d, amb, n, out, sync=False, d_count=cnt)
 
         def alg():
-            return (n + 3) // 4 + (n + 7) // 8 + 4 * int(cnt.item())
+            return (n + 3) // 4 + (0 if name.startswith("PLAIN") else (n + 7) // 8) + 4 * int(cnt.item())
         return {"step": step, "units": n, "unit": "bases", "alg_bytes": alg, "keep": (d, amb, out, cnt),
                 "what": f"skip-ambiguous windows (PackedNSeq, src/lib.rs:451-496): canonical k={k} w={w} on {n} bp with "
                         "0.1 % isolated Ns and 200 gaps of 50 kbp; window-ambiguity prepass + walk",

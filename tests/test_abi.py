@@ -244,3 +244,22 @@ def test_one_round_rule_keeps_every_lane_bound(sm):
     finally:
         del os.environ["MM_TAPER_SLOTS"]
     assert checked > 1000 and applied > 100, (checked, applied)
+
+
+def test_kernel_source_compiles_with_hiprtc(tmp_path):
+    """Window sizes without a prebuilt kernel are compiled at first use by hiprtc from the kernel's source (mm_jit.hip).
+    hiprtc cross-compiles without a device, so the CPU suite can catch what only it rejects - round 5: an inline-assembly
+    "n" constraint whose operand is a constant only after unrolling compiled under hipcc and failed under hiprtc, and the
+    run quietly took the generic family.  Two instances that exercise every walk: w = 100 (no prebuilt kernel, beyond the
+    LDS landing's range) and w = 40 (inside it)."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++") or not os.path.exists("/opt/rocm/lib/libhiprtc.so"):
+        pytest.skip("no g++ / libhiprtc")
+    probe_dir = os.path.join(ROOT, "tools", "jit_probe")
+    exe = str(tmp_path / "probe.bin")
+    subprocess.run(["g++", "-O1", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", exe, os.path.join(probe_dir, "probe.cpp"),
+                    "-L/opt/rocm/lib", "-lhiprtc", "-Wl,-rpath,/opt/rocm/lib"], check=True, capture_output=True)
+    for name in ("mm::fused_kernel<100, true, true, 0, false, false>", "mm::fused_kernel<40, true, true, 0, false, true>"):
+        r = subprocess.run([exe, name], cwd=probe_dir, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "HIPRTC_SUCCESS" in r.stdout, (name, (r.stdout + r.stderr)[-1500:])

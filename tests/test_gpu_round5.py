@@ -239,3 +239,30 @@ def test_cross_checks_in_the_experiments_build(sm):
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail
+
+
+def test_skip_ambiguous_large_windows_landing(sm, oracle, gpu):
+    """Round 5: the skip-ambiguous walk over windows of 32 .. 96 keeps its look-ahead loads' landing data in LDS (in front
+    of the lane lists).  Random sequences with isolated Ns and N runs over several tiles, windows with and without a fifth
+    load dword, and DENSE tiles whose lists overflow (k = 1 .. 3: every base nearly its own k-mer - the redo pass walks
+    with the same landing area, and list entries past a list's capacity must not reach it) against the oracle."""
+    import torch
+    rng = np.random.default_rng(55)
+    checked = 0
+    for (k, w) in ((1, 55), (1, 33), (3, 51), (3, 41), (19, 33), (21, 35), (31, 51), (21, 63), (19, 65), (21, 81), (31, 33)):
+        assert (k + w - 1) % 2 == 1
+        for n in (333, 5_003, 120_007, 1_500_013):
+            a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n + 8)].copy()
+            if k <= 3 and n > 1000:
+                a[n // 3: n // 3 + 900] = ord("A")          # a homopolymer stretch: every window ties
+            a[rng.integers(0, n, size=max(1, n // 250))] = ord("N")
+            s0 = int(rng.integers(0, n))
+            a[s0:s0 + int(rng.integers(1, 200))] = ord("N")
+            packed, amb = oracle.pack_ascii_n(a.tobytes())
+            d_p, d_m = torch.from_numpy(packed).cuda(), torch.from_numpy(amb).cuda()
+            out = torch.zeros(n + 8, dtype=torch.int32, device="cuda")
+            c = sm.canonical_minimizers(k, w).run_skip_ambiguous_device(d_p, d_m, n, out)
+            want = oracle.run_skip_ambiguous(packed, amb, n, k, w)
+            assert c == len(want) and np.array_equal(_dev(out, c), want), (k, w, n, c, len(want))
+            checked += 1
+    assert checked == 44

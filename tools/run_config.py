@@ -29,7 +29,7 @@ def gen(n, seed):
 
 from simd_minimizers_amd import workloads  # noqa: E402
 
-if cfg in workloads.COMPONENTS:  # the rows either side of the path
+if cfg in workloads.COMPONENTS or cfg.startswith(("SKIP_W", "PLAIN_W")):  # the rows either side of the path
     print(json.dumps(workloads.measure(cfg, ws, dev, warm=warm, reps=steps)))
     sys.exit(0)
 
