@@ -155,6 +155,15 @@ Geometry geometry(const RunArgs &a) {
         const uint64_t fit = a.work_windows / (1024ull * kFusedThreads * a.w);
         if (fit < g.nblk) g.nblk = fit < 6u ? 6u : (uint32_t)fit;
     }
+    // Skip-ambiguous runs (round 5): the walk streams a third array beside the two sequence streams - one bit per window
+    // - and with the default lanes of the middle window sizes the resident lanes' spans no longer fit the L2: the dirty walk
+    // of k=31 w=33 missed the L2 3.2 x as often as the plain walk and took 1.07 ms per Gbp with the default 26 blocks per
+    // lane, 0.70 with 13; w = 25: 0.73 -> 0.63 with 14; w <= 20 and w >= 41 are flat (tools/gpu_skip_nblk.py,
+    // profiles/r05_skip_dirty_walk.txt).  Lanes of at most 400 windows there.
+    if (a.nblk == 0 && a.wamb && a.w >= 21u && a.w <= 40u) {
+        const uint32_t lim = 400u / a.w;
+        if (g.nblk > lim) g.nblk = lim < 6u ? 6u : lim;
+    }
     // super-k-mer runs pack (window << shift) + offset-in-window into the 16-bit list entry
     // (kSkShift in mm_fused_impl.h): the lane length is bounded by S << shift <= 65536
     if (a.out.sk && a.mode == 0) {

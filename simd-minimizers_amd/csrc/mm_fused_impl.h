@@ -311,7 +311,12 @@ constexpr int wide_group_blocks_nd(int W, int nd) {
         bool ok = true;
         for (int g = 0; g < nsub; ++g) {
             const int off = 2 * W * m + 32 * g, low = off % 32;
-            const int bases = W - 16 * g < 16 ? W - 16 * g : 16;  // bases this view has to hold
+            // bases this view has to hold; the LAST view one more: the strand window's leaving base of the block's last step
+            // is the hash-out view moved on by one base (next_base_view), i.e. base W of the block.  (Round 5: without it
+            // w = 49 and w = 65 - one base in their last view, right at the edge of the valid bits - read a zero there for
+            // lanes at the worst alignment, and a tie whose strand count was off by one took the wrong side:
+            // tests/test_gpu_round5.py::test_skip_ambiguous_large_windows_landing found it, on the plain walk too.)
+            const int bases = (W - 16 * g < 16 ? W - 16 * g : 16) + (g == nsub - 1 ? 1 : 0);
             if (low > 24 || off + 6 + 2 * bases > valid) ok = false;
         }
         if (!ok) break;

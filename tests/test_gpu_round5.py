@@ -266,3 +266,42 @@ def test_skip_ambiguous_large_windows_landing(sm, oracle, gpu):
             assert c == len(want) and np.array_equal(_dev(out, c), want), (k, w, n, c, len(want))
             checked += 1
     assert checked == 44
+
+
+def test_strand_vote_at_every_lane_alignment(sm, oracle, gpu):
+    """The strand window's leaving base of a block's last step is base W of the block's hash-out view (one base beyond the
+    block).  For w = 49 and w = 65 that base sits right at the edge of the bits a wide load keeps valid for every lane
+    alignment; round 5 found lanes at the worst alignment reading a zero there, a strand count off by one, and a tie
+    resolved to the wrong side (two emits missing in 1.5 Mbp).  Tie-heavy sequences (long two-letter stretches: most
+    windows tie at their minimum and the vote decides), every base offset, several lane lengths so that lane starts take
+    every residue mod 16, window sizes around the wide loads' group boundaries - plain canonical runs against the oracle."""
+    import torch
+    rng = np.random.default_rng(65)
+    n = 400_009
+    codes = rng.integers(0, 4, size=n + 8).astype(np.uint8)
+    for s in range(0, n, 40_000):
+        m = min(15_000, n - s)
+        codes[s:s + m] = rng.integers(0, 2, size=m) * 3            # A / G only: ties everywhere, the vote near its threshold
+        m2 = max(0, min(8_000, n - s - 20_000))
+        codes[s + 20_000:s + 20_000 + m2] = rng.integers(0, 2, size=m2) + 1   # C / T only
+    ws = gpu
+    checked = 0
+    try:
+        for off in (0, 1, 2, 3):
+            packed = np.zeros((n + off + 3) // 4 + 64, dtype=np.uint8)
+            shifted = np.concatenate([np.zeros(off, dtype=np.uint8), codes[:n]])
+            for j in range(4):
+                c = shifted[j::4]
+                packed[: len(c)] |= (c << (2 * j)).astype(np.uint8)
+            d = torch.from_numpy(packed).cuda()
+            out = torch.zeros(n, dtype=torch.int32, device="cuda")
+            for (k, w) in ((19, 49), (19, 65), (21, 47), (19, 51), (21, 63), (19, 33), (17, 17)):
+                want = oracle.run(packed, n, k, w, canonical=True, base_offset=off)
+                for nb in (0, 7, 9):
+                    ws.set_blocks_per_lane(nb)
+                    c = sm.canonical_minimizers(k, w).run_device(d, n, out, base_offset=off)
+                    assert c == len(want) and np.array_equal(_dev(out, c), want), (k, w, off, nb, c, len(want))
+                    checked += 1
+    finally:
+        ws.set_blocks_per_lane(0)
+    assert checked == 4 * 7 * 3

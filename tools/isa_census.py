@@ -74,7 +74,7 @@ def wide_group(w):
             return 0
         nsub, valid, m = (w + 15) // 16, 32 * nd - 24, 0
         while m < 8:
-            if any((2 * w * m + 32 * g) % 32 > 24 or 2 * w * m + 32 * g + 6 + 2 * min(16, w - 16 * g) > valid
+            if any((2 * w * m + 32 * g) % 32 > 24 or 2 * w * m + 32 * g + 6 + 2 * (min(16, w - 16 * g) + (1 if g == nsub - 1 else 0)) > valid
                    for g in range(nsub)):
                 break
             m += 1
