@@ -123,7 +123,7 @@ uint32_t legal_nblk(uint32_t w, uint32_t mode, uint32_t want, uint32_t cap_limit
 // Landing area of the skip-ambiguous walk's look-ahead loads (kAmbiLand, mm_fused_impl.h): behind the lists, for runs with
 // ambiguity bits whose kernel uses it.  Returns its bytes (0: none) and the offset the kernel is told.
 static uint32_t ambi_landing(uint32_t w, const void *wamb) {
-    return (wamb && ambi_land_rule((int)w)) ? kLandBytes : 0u;  // (in FRONT of the lists; a multiple of 16 bytes)
+    return wamb ? ambi_land_bytes((int)w) : 0u;  // (in FRONT of the lists; a multiple of 16 bytes; 0 for window sizes without it)
 }
 
 struct Geometry {
@@ -160,9 +160,17 @@ Geometry geometry(const RunArgs &a) {
     // of k=31 w=33 missed the L2 3.2 x as often as the plain walk and took 1.07 ms per Gbp with the default 26 blocks per
     // lane, 0.70 with 13; w = 25: 0.73 -> 0.63 with 14; w <= 20 and w >= 41 are flat (tools/gpu_skip_nblk.py,
     // profiles/r05_skip_dirty_walk.txt).  Lanes of at most 400 windows there.
-    if (a.nblk == 0 && a.wamb && a.w >= 21u && a.w <= 40u) {
+    // (w = 38, 40 took part until the chunked window bits, ambi_rows_rule: with them 18 - 22 blocks read 0.71 ms against 0.81 with 10)
+    if (a.nblk == 0 && a.wamb && a.w >= 21u && a.w <= 40u && !ambi_rows_rule((int)a.w)) {
         const uint32_t lim = 400u / a.w;
         if (g.nblk > lim) g.nblk = lim < 6u ? 6u : lim;
+    }
+    // ... and in the three-workgroup classes (38 <= w <= 54, 168 registers) the landing area of the window bits' chunks
+    // (20 KB, ambi_rows_rule) has to fit beside the lists three times per CU: lanes whose lists stay below 33 KB
+    // (k=31 w=51: 22 blocks instead of 27; the lane length is flat there, same file).
+    if (a.nblk == 0 && a.wamb && ambi_rows_rule((int)a.w) && a.w <= 54u) {
+        const uint32_t room = (kMaxLdsBytes / 3u - 1024u) - ambi_land_bytes((int)a.w);
+        while (g.nblk > 6u && list_capacity(a.w, a.mode, a.w * g.nblk) * stride_of(a) > room) --g.nblk;
     }
     // super-k-mer runs pack (window << shift) + offset-in-window into the 16-bit list entry
     // (kSkShift in mm_fused_impl.h): the lane length is bounded by S << shift <= 65536

@@ -375,14 +375,30 @@ struct LaneCtx {
 // lists rely on entries past their capacity falling beyond the workgroup's allocation (see "redo"); behind them the area
 // took those entries, a dense tile's walk read its own overflow as ambiguity bits and counted two windows too few
 // (k = 1, w = 55: every base its own k-mer, 106 emits into a list of 23).
-constexpr uint32_t kLandAmbBytes = 64u * 16u, kLandQ4Bytes = 64u * 4u;
-constexpr uint32_t kLandParityBytes = kLandAmbBytes + 2u * kLandQ4Bytes;   // 1536
-constexpr uint32_t kLandWaveBytes = 2u * kLandParityBytes;                 // 3072
-constexpr uint32_t kLandBytes = kFusedWaves * kLandWaveBytes;              // 12288 per workgroup
+//
+// Late round 5, the 3-workgroup classes (w >= 38): one 16-byte load of window bits per lane and BLOCK touched every bit line
+// (128 bytes = 1024 windows = 20 blocks of w = 51) twenty times, and with the lines of 24 576 resident lanes per XCD - two
+// sequence streams and the bits - far beyond its 4 MB of L2 none of those touches hit: the dirty walk of k=31 w=51 fetched
+// 5.1 GB per Gbp (plain: 1.05 GB; the bits themselves are 0.125 GB) and ran at the fabric's speed, 0.82 ms
+// (profiles/r05_skip_dirty_walk.txt, section 7).  There the bits now arrive in CHUNKS of kAmbRowDwords dwords per lane -
+// sixteen dword loads to LDS, row r of the chunk at r x 256 bytes + 4 x lane, so that a lane reads dword d of its chunk at
+// d x 256 + 4 x lane whatever its alignment (conflict-free; two rows per ds_read2st64) - and a chunk serves
+// (512 - 31) / W blocks: nine at w = 51.  One buffer: the next chunk is asked for when the last block of the current one
+// has read its bits, and used a block later.
+constexpr uint32_t kLandQ4Bytes = 64u * 4u;
+constexpr uint32_t kAmbRowDwords = 16u;
 #ifndef MM_AMBI_LAND
 #define MM_AMBI_LAND 1  // (0: A/B, the register look-ahead of rounds 2-4)
 #endif
+#ifndef MM_AMBI_ROWS_MINW
+#define MM_AMBI_ROWS_MINW 38  // (97: A/B, one 16-byte load per block for every landing window size)
+#endif
 constexpr bool ambi_land_rule(int W) { return MM_AMBI_LAND && W >= 32 && W <= 96 && wide_group_blocks(W) != 0; }
+constexpr bool ambi_rows_rule(int W) { return ambi_land_rule(W) && W >= MM_AMBI_ROWS_MINW; }
+// a wave's slice: the window bits (two parities of 64 x 16 bytes, or ONE chunk of kAmbRowDwords rows), then two parities of fifth dwords
+constexpr uint32_t land_amb_bytes(int W) { return ambi_rows_rule(W) ? kAmbRowDwords * 256u : 2u * 64u * 16u; }  // 2048 / 4096
+constexpr uint32_t land_wave_bytes(int W) { return land_amb_bytes(W) + 4u * kLandQ4Bytes; }                    // 3072 / 5120
+constexpr uint32_t ambi_land_bytes(int W) { return ambi_land_rule(W) ? kFusedWaves * land_wave_bytes(W) : 0u; }  // 12288 / 20480 per workgroup
 
 // One lane walks its S windows.  List mode: appends emitted 16-bit values to the lane's LDS
 // list (entries past the capacity are dropped but counted).  DIRECT mode: stores final values
@@ -531,6 +547,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         return x;
     };
     uint32_t lpar = 0, apar = 0;
+    constexpr uint32_t kLandAmbBytes = land_amb_bytes(W);
+    auto q4_off = [](uint32_t par, uint32_t which) -> uint32_t { return kLandAmbBytes + (2u * par + which) * kLandQ4Bytes; };
     typedef __attribute__((address_space(3))) void *LdsPtr;
     auto lds_u32 = [&](uint32_t addr) -> uint32_t {
         return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)addr);
@@ -538,12 +556,12 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     // which == 0: stream entering the hash, 1: leaving it
     auto land_q4_load = [&](uint32_t gpos, uint32_t par, uint32_t which) {
         const uint32_t off = (gpos >> 4) << 2;
-        const uint32_t base = __builtin_amdgcn_readfirstlane(land + par * kLandParityBytes + kLandAmbBytes + which * kLandQ4Bytes);
+        const uint32_t base = __builtin_amdgcn_readfirstlane(land + q4_off(par, which));
         // (the 16 bytes go into the SCALAR offset: an instruction offset of a load to LDS moves the LDS address as well)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsPtr)(uintptr_t)base, 4, off, 16, 0, 0);
     };
     auto land_q4_read = [&](uint32_t par, uint32_t which) -> uint32_t {
-        return lds_u32(land + par * kLandParityBytes + kLandAmbBytes + which * kLandQ4Bytes + 4u * lane_id_now());
+        return lds_u32(land + q4_off(par, which) + 4u * lane_id_now());
     };
     // the buffer that becomes current: shifted down by the byte part of the lane's position; returns the bit part
     auto wide_normalise = [&](WideBuf &dst, const WideBuf &w) -> uint32_t {
@@ -705,18 +723,43 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     uint32_t aw[NSUBA], aw_next[NSUBA];
     // kAmbiLand: the 128 bits from the dword that holds the block's first window bit on (31 + W <= 127) land in LDS
     auto land_amb_load = [&](uint32_t bit, uint32_t par) {
-        const uint32_t base = __builtin_amdgcn_readfirstlane(land + par * kLandParityBytes);
+        const uint32_t base = __builtin_amdgcn_readfirstlane(land + par * 1024u);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (LdsPtr)(uintptr_t)base, 16, (bit >> 5) << 2, 0, 0, 0);
     };
     auto land_amb_read = [&](uint32_t bit, uint32_t par, uint32_t (&out)[NSUBA]) {
         typedef uint32_t u32x4a __attribute__((ext_vector_type(4)));
         const u32x4a d = *reinterpret_cast<const __attribute__((address_space(3))) u32x4a *>(
-            (uintptr_t)(land + par * kLandParityBytes + 16u * lane_id_now()));
+            (uintptr_t)(land + par * 1024u + 16u * lane_id_now()));
         const uint32_t dd[5] = {d.x, d.y, d.z, d.w, 0u};
 #pragma unroll
         for (int g = 0; g < NSUBA; ++g) out[g] = __builtin_amdgcn_alignbit(dd[g + 1 < 5 ? g + 1 : 4], dd[g < 4 ? g : 3], bit & 31u);
     };
-    if (AMBI && kAmbiLand) {
+    // kAmbRows (ambi_rows_rule): chunks of kAmbRowDwords dwords per lane, row r of a chunk at r x 256 bytes + 4 x lane
+    constexpr bool kAmbRows = kAmbiLand && ambi_rows_rule(W);
+    constexpr uint32_t kAmbChunkBlocks = kAmbRows ? (32u * kAmbRowDwords - 31u) / (uint32_t)W : 1u;  // blocks a chunk serves
+    static_assert(!kAmbRows || kAmbChunkBlocks >= 1u, "a chunk holds at least one block's bits at any alignment");
+    uint32_t ka = 0;    // index of the coming block within its chunk (wave-uniform)
+    uint32_t arel = 0;  // bit of the coming block's first window relative to the first dword of its chunk (per lane)
+    auto land_rows_load = [&](uint32_t bit) {
+        const uint32_t base = __builtin_amdgcn_readfirstlane(land);
+        const uint32_t voff = (bit >> 5) << 2;
+#pragma unroll
+        for (uint32_t r = 0; r < kAmbRowDwords; ++r)  // (the row's 4 r bytes in the SCALAR offset, as in land_q4_load)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (LdsPtr)(uintptr_t)(base + r * 256u), 4, voff, r * 4u, 0, 0);
+    };
+    auto land_rows_read = [&](uint32_t rel, uint32_t (&out)[NSUBA]) {
+        const uint32_t a = land + ((rel >> 5) << 8) + 4u * lane_id_now();
+        uint32_t dd[NSUBA + 1];
+#pragma unroll
+        for (int g = 0; g <= NSUBA; ++g) dd[g] = lds_u32(a + 256u * (uint32_t)g);
+#pragma unroll
+        for (int g = 0; g < NSUBA; ++g) out[g] = __builtin_amdgcn_alignbit(dd[g + 1], dd[g], rel);  // (its low five bits)
+    };
+    if (AMBI && kAmbRows) {
+        land_rows_load(ctx.abase);  // block 1's chunk
+#pragma unroll
+        for (int g = 0; g < NSUBA; ++g) aw_next[g] = 0u;
+    } else if (AMBI && kAmbiLand) {
         land_amb_load(ctx.abase, apar);
 #pragma unroll
         for (int g = 0; g < NSUBA; ++g) aw_next[g] = 0u;
@@ -822,15 +865,35 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             // BEFORE this block's look-ahead loads are issued, so that it only waits for loads a block old), the next
             // block's are sent there.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            land_amb_read(ctx.abase + (b - 1u) * (uint32_t)W, apar, aw);
+            if (kAmbRows) {
+                // (wave-uniform) a new chunk starts with this block: asked for at the end of the block before it
+                if (ka == 0u) arel = (ctx.abase + (b - 1u) * (uint32_t)W) & 31u;
+                land_rows_read(arel, aw);
+                arel += (uint32_t)W;
+            } else {
+                land_amb_read(ctx.abase + (b - 1u) * (uint32_t)W, apar, aw);
+            }
             if (ND == 5 && (KN >= 0 ? (uint32_t)KN : kn) == 0u) {
                 // (a new load group starts with this block: the fifth dwords of its two streams, under the same wait)
                 Wa[1].q[4] = land_q4_read(lpar, 0u);
                 Wr[1].q[4] = land_q4_read(lpar, 1u);
                 lpar ^= 1u;
             }
-            apar ^= 1u;
-            land_amb_load(ctx.abase + b * (uint32_t)W, apar);
+            if (kAmbRows) {
+                // (the chunk's last block has taken its bits: the next chunk goes to the SAME rows - once those reads are
+                // back, the hardware does not order an LDS read against a later load to LDS - and is waited for at the top
+                // of the next block, a block's time later, like every look-ahead load of this walk)
+                if (ka + 1u == kAmbChunkBlocks) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    land_rows_load(ctx.abase + b * (uint32_t)W);
+                    ka = 0u;
+                } else {
+                    ka += 1u;
+                }
+            } else {
+                apar ^= 1u;
+                land_amb_load(ctx.abase + b * (uint32_t)W, apar);
+            }
         }
         if (MG != 0) {
             // wide loads: block b + 1 is block kn of its group; a new group takes the next buffer and starts the load
@@ -1834,11 +1897,11 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     // landing area of the skip-ambiguous walk's look-ahead loads (behind the lists, one slice per wave; see kAmbiLand)
     ctx.land = 0;
     if (kAmbi && ambi_land_rule(W) && p.wamb) {
-        if (p.land_bytes < kLandBytes) {  // (a launcher that did not allocate it: never walk with a null landing area)
+        if (p.land_bytes < ambi_land_bytes(W)) {  // (a launcher that did not allocate it: never walk with a null landing area)
             if (tid == 0) flag_error(p.out.error, 2u);
             return;
         }
-        ctx.land = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(smem) + (uint32_t)wave * kLandWaveBytes);
+        ctx.land = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(smem) + (uint32_t)wave * land_wave_bytes(W));
     }
     bool lane_active = false;
     // READS: a lane walks reads_per_lane consecutive reads; read j of lane t is read

@@ -305,3 +305,74 @@ def test_strand_vote_at_every_lane_alignment(sm, oracle, gpu):
     finally:
         ws.set_blocks_per_lane(0)
     assert checked == 4 * 7 * 3
+
+
+def test_skip_ambiguous_chunked_window_bits(sm, oracle, gpu):
+    """Late round 5: for w >= 38 the dirty walk takes its window bits in CHUNKS of sixteen dwords per lane (rows in LDS, one
+    buffer, (512 - 31) / w blocks per chunk).  Every edge of that scheme against the oracle: the smallest and largest window
+    sizes it serves, lanes shorter than / equal to / one block longer than a chunk and several chunks long, base and bit
+    offsets (the lanes' alignments inside their first dword), window-range shards (lanes starting anywhere), Ns every few
+    dozen bases so that nearly every dword of the bits matters, and reads mode (one fresh chunk per read)."""
+    import torch
+    rng = np.random.default_rng(512)
+    ws = gpu
+    checked = 0
+    try:
+        for (k, w) in ((20, 38), (31, 41), (31, 51), (22, 64), (21, 95), (20, 96)):
+            assert (k + w - 1) % 2 == 1
+            per_chunk = (512 - 31) // w
+            for off in (0, 3):
+                n = 700_001 + 13 * off
+                a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n + off + 8)].copy()
+                a[rng.integers(0, n, size=n // 90)] = ord("N")                 # windows of l = 57 .. 114: most are skipped ...
+                for s in rng.integers(0, n - 5000, size=30):                   # ... except in clean stretches
+                    a[s:s + int(rng.integers(300, 4000))] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=1)]
+                for s in rng.integers(0, n - 5000, size=30):
+                    m = int(rng.integers(300, 4000))
+                    a[s:s + m] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=m)]
+                packed, amb = oracle.pack_ascii_n(a.tobytes())
+                d_p, d_m = torch.from_numpy(packed).cuda(), torch.from_numpy(amb).cuda()
+                out = torch.zeros(n + 8, dtype=torch.int32, device="cuda")
+                b = sm.canonical_minimizers(k, w)
+                want = oracle.run_skip_ambiguous(packed, amb, n, k, w, base_offset=off, amb_offset=off)
+                assert len(want) > 1000, (k, w, len(want))
+                for nb in (0, 1, per_chunk - 1, per_chunk, per_chunk + 1, 2 * per_chunk, 2 * per_chunk + 1):
+                    if nb < 0 or (nb == 0 and off):
+                        continue
+                    ws.set_blocks_per_lane(max(nb, 1) if nb else 0)
+                    c = b.run_skip_ambiguous_device(d_p, d_m, n, out, base_offset=off, amb_offset=off)
+                    assert ws.last_path() == sm.PATH_FUSED
+                    assert c == len(want) and np.array_equal(_dev(out, c), want), (k, w, off, nb, c, len(want))
+                    checked += 1
+                ws.set_blocks_per_lane(0)
+                # window-range shards concatenate to the whole (a shard dedups against the window before it)
+                nw = n - (k + w - 1) + 1
+                cuts = [0, nw // 3 + 5, 2 * nw // 3 - 7, nw]
+                parts = []
+                for s, e in zip(cuts[:-1], cuts[1:]):
+                    cc = b.run_skip_ambiguous_device(d_p, d_m, n, out, base_offset=off, amb_offset=off, win_begin=s, win_end=e)
+                    parts.append(_dev(out, cc).copy())
+                assert np.array_equal(np.concatenate(parts), want), (k, w, off)
+                checked += 1
+        # reads mode: one fresh chunk per read, reads of a few blocks
+        for (k, w, n_reads, stride, read_len, off) in ((31, 51, 700, 401, 400, 1), (20, 38, 500, 300, 250, 0)):
+            span = n_reads * stride + 64 + off
+            a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=span)].copy()
+            a[rng.integers(0, span, size=span // 150)] = ord("N")
+            packed, amb = oracle.pack_ascii_n(a.tobytes())
+            d_p, d_m = torch.from_numpy(packed).cuda(), torch.from_numpy(amb).cuda()
+            out = torch.zeros(n_reads * read_len, dtype=torch.int32, device="cuda")
+            offs = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
+            total = sm.run_reads_device(sm.Builder(k, w, True, 0), d_p, n_reads, stride, read_len, out, offs,
+                                        base_offset=off, d_amb=d_m, amb_offset=off)
+            assert ws.last_path() == sm.PATH_FUSED
+            ho, hp = offs.cpu().numpy(), _dev(out, total)
+            assert ho[-1] == total and total > 0
+            for r in range(n_reads):
+                want = oracle.run_skip_ambiguous(packed, amb, read_len, k, w, base_offset=off + r * stride,
+                                                 amb_offset=off + r * stride)
+                assert np.array_equal(hp[ho[r]:ho[r + 1]], want), (k, w, r)
+            checked += 1
+    finally:
+        ws.set_blocks_per_lane(0)
+    assert checked == 6 * (7 + 6 + 2) + 2

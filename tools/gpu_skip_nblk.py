@@ -13,13 +13,19 @@ g = torch.Generator(device="cuda"); g.manual_seed(1)
 amb[torch.randint(0, n // 8, (n // 8000,), device="cuda", generator=g)] = 1 << 3
 out = torch.zeros(int(n * 0.2), dtype=torch.int32, device="cuda")
 cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
-def kt(step, warm=6, reps=6):
-    for _ in range(warm): step()
+def kt(step, reps=6):
+    import time
+    t0 = time.perf_counter()  # (warm up by time: a few steps after an idle second read up to 10 % slow)
+    while time.perf_counter() - t0 < 0.1:
+        step(); ws.sync()
     ws.sync(); ws.enable_timing(True); ws.kernel_time(True)
     for _ in range(reps): step()
     ws.sync(); ms, l = ws.kernel_time(True); ws.enable_timing(False)
     return ms / max(1, l)
-for (k, w, sweep) in ((31, 33, (0, 13, 11, 9, 8, 7, 6, 5)), (31, 51, (0, 27, 20, 16, 12, 10, 8, 6)), (21, 25, (0, 14, 11, 9, 7)), (21, 19, (0, 20, 16, 12, 9)), (15, 17, (0, 28, 20, 14, 10))):
+CASES = ((31, 33, (0, 13, 11, 9, 8, 7, 6, 5)), (31, 51, (0, 27, 20, 16, 12, 10, 8, 6)), (21, 25, (0, 14, 11, 9, 7)), (21, 19, (0, 20, 16, 12, 9)), (15, 17, (0, 28, 20, 14, 10)))
+if len(sys.argv) > 1:  # k,w,nb,nb,... per argument (0 = the library's default lanes)
+    CASES = tuple((int(a.split(",")[0]), int(a.split(",")[1]), tuple(int(x) for x in a.split(",")[2:])) for a in sys.argv[1:])
+for (k, w, sweep) in CASES:
     b = sm.canonical_minimizers(k, w)
     row = []
     for nb in sweep:
