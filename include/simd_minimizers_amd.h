@@ -488,11 +488,16 @@ int mm_device_group_gather_batch(mm_device_group_t *group, int root, uint32_t *d
  * per lane, first tapered window, windows per block of a tile}.  n_seqs > 0: a batch, the tile table itself (tile t =
  * sequence, first window, blocks per lane; out7[0] = the longest lane); MM_ERR_CAPACITY when it holds more than
  * tile_capacity tiles (*n_tiles says how many).  mode: 0 minimizers, 1 / 2 closed / open syncmers, 3 minimizers with
- * super-k-mer indices (whose 16-bit list entries bound the lanes).  With MM_TAPER_SLOTS set the single-sequence plan also
- * applies the one-round rule (a run of 0.6 .. 1 round of that many slots gets one tile per slot). */
+ * super-k-mer indices (whose 16-bit list entries bound the lanes), 4 minimizers over a PackedNSeq (the skip-ambiguous walk's
+ * lane rules).  With MM_TAPER_SLOTS set the single-sequence plan also applies the one-round rule (a run of 0.6 .. 1 round of
+ * that many slots gets one tile per slot).
+ * mm_debug_launch_lds: the dynamic LDS of the same single-sequence launch, out2 = {bytes of the lane lists, bytes of the
+ * skip-ambiguous walk's landing area in front of them (0 without ambiguity bits)} - the CPU suite checks that the two fit
+ * the CU as often as the kernel's register bound lets workgroups share it. */
 int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n_seqs, const uint64_t *n_windows,
                          uint64_t *out7, uint32_t *tile_seq, uint32_t *tile_win0, uint32_t *tile_nblk,
                          uint64_t tile_capacity, uint64_t *n_tiles);
+int mm_debug_launch_lds(uint32_t w, int canonical_windows, int mode, uint64_t n_windows, uint64_t *out2);
 /* Diagnostics: the shader clock while other work runs on the device.  _begin starts a handful of sleeping
  * single-wave workgroups on a stream of the workspace's own that sample the shader cycle counter against the
  * 100 MHz real-time counter for duration_us; _end waits for them and returns the mean clock in GHz (bench.py

@@ -631,10 +631,8 @@ int mm_workspace_last_path(const mm_workspace_t *ws) { return ws ? ws->last_path
 // n_windows windows - single sequence: out7 = {blocks per lane, tiles, taper_first, taper_per_level, taper_min_nblk,
 // taper_start, windows per block of a tile}; batch (n_seqs > 0): the tile table itself, tile t = {seq, first window,
 // blocks per lane}.  The CPU test-suite checks that the tiles tile every sequence exactly.
-int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n_seqs, const uint64_t *n_windows,
-                         uint64_t *out7, uint32_t *tile_seq, uint32_t *tile_win0, uint32_t *tile_nblk, uint64_t tile_capacity,
-                         uint64_t *n_tiles) {
-    if (!n_windows || w == 0) return MM_ERR_NULL;
+// the planner's view of a run: everything but the sizes is a placeholder (no device is touched)
+static mm::RunArgs debug_plan_args(uint32_t w, int canonical_windows, int mode, uint64_t n_seqs, uint64_t n_windows0) {
     mm::RunArgs a;
     memset(&a.seq, 0, sizeof a.seq);
     memset(&a.ht, 0, sizeof a.ht);
@@ -642,13 +640,15 @@ int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n
     a.k = 21;
     a.w = w;
     a.canonical_windows = canonical_windows;
-    a.mode = mode == 3 ? 0u : (uint32_t)mode;  // (3: minimizers WITH super-k-mer indices - their 16-bit list entries bound the lanes)
+    // (3: minimizers WITH super-k-mer indices - their 16-bit list entries bound the lanes; 4: minimizers over a PackedNSeq -
+    // the skip-ambiguous walk's landing area and lane rules)
+    a.mode = (mode == 3 || mode == 4) ? 0u : (uint32_t)mode;
     a.win_begin = 0;
-    a.win_end = n_windows[0];
+    a.win_end = n_windows0;
     memset(&a.out, 0, sizeof a.out);
-    static uint32_t sk_marker;
+    static uint32_t sk_marker, amb_marker;
     if (mode == 3) a.out.sk = &sk_marker;  // (only its being non-null matters to the planner)
-    a.wamb = nullptr;
+    a.wamb = mode == 4 ? &amb_marker : nullptr;
     a.wamb_dwords = 0;
     a.batch_seqs = nullptr;
     a.batch_tile_seq = nullptr;
@@ -656,11 +656,29 @@ int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n
     a.batch_n = (uint32_t)n_seqs;
     a.batch_tiles = 0;
     a.nblk = 0;
-    a.work_windows = n_windows[0];
+    a.work_windows = n_windows0;
     a.use_ticket = 0;
     a.scratch = nullptr;
     a.generic_round_windows = 0;
     a.timing_start = a.timing_stop = nullptr;
+    return a;
+}
+
+int mm_debug_launch_lds(uint32_t w, int canonical_windows, int mode, uint64_t n_windows, uint64_t *out2) {
+    if (!out2 || w == 0) return MM_ERR_NULL;
+    const mm::RunArgs a = debug_plan_args(w, canonical_windows, mode, 0, n_windows);
+    unsigned long long o[2];
+    mm::fused_debug_lds(a, o);
+    out2[0] = o[0];
+    out2[1] = o[1];
+    return MM_OK;
+}
+
+int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n_seqs, const uint64_t *n_windows,
+                         uint64_t *out7, uint32_t *tile_seq, uint32_t *tile_win0, uint32_t *tile_nblk, uint64_t tile_capacity,
+                         uint64_t *n_tiles) {
+    if (!n_windows || w == 0) return MM_ERR_NULL;
+    mm::RunArgs a = debug_plan_args(w, canonical_windows, mode, n_seqs, n_windows[0]);
     if (n_seqs == 0) {
         if (!out7) return MM_ERR_NULL;
         unsigned long long o[7];

@@ -166,10 +166,11 @@ Geometry geometry(const RunArgs &a) {
         if (g.nblk > lim) g.nblk = lim < 6u ? 6u : lim;
     }
     // ... and in the three-workgroup classes (38 <= w <= 54, 168 registers) the landing area of the window bits' chunks
-    // (20 KB, ambi_rows_rule) has to fit beside the lists three times per CU: lanes whose lists stay below 33 KB
-    // (k=31 w=51: 22 blocks instead of 27; the lane length is flat there, same file).
+    // (ambi_rows_rule) has to fit beside the lists three times per CU - 160 KB in units of 1280 bytes: 53 760 per workgroup,
+    // 512 of them for the static tables.  The chunks are sized so that the default lanes pass (amb_row_dwords); this is the
+    // guard for whatever changes either side (two workgroups per CU instead of three: k=31 w=51 0.74 -> 1.06 ms per Gbp).
     if (a.nblk == 0 && a.wamb && ambi_rows_rule((int)a.w) && a.w <= 54u) {
-        const uint32_t room = (kMaxLdsBytes / 3u - 1024u) - ambi_land_bytes((int)a.w);
+        const uint32_t room = (160u * 1024u / 3u / 1280u) * 1280u - 512u - ambi_land_bytes((int)a.w);
         while (g.nblk > 6u && list_capacity(a.w, a.mode, a.w * g.nblk) * stride_of(a) > room) --g.nblk;
     }
     // super-k-mer runs pack (window << shift) + offset-in-window into the 16-bit list entry
@@ -604,6 +605,13 @@ int fused_debug_plan(const RunArgs &a, unsigned long long *out) {
     out[5] = t.start;
     out[6] = (unsigned long long)kFusedThreads * a.w;
     return 0;
+}
+
+// dynamic LDS of a launch with the default lanes: the lane lists and the skip-ambiguous walk's landing area (CPU tests)
+void fused_debug_lds(const RunArgs &a, unsigned long long *out2) {
+    const Geometry g = geometry(a);
+    out2[0] = g.lds_bytes;
+    out2[1] = ambi_landing(a.w, a.wamb);
 }
 
 int launch_fused(const RunArgs &a, hipStream_t stream) {

@@ -380,13 +380,16 @@ struct LaneCtx {
 // (128 bytes = 1024 windows = 20 blocks of w = 51) twenty times, and with the lines of 24 576 resident lanes per XCD - two
 // sequence streams and the bits - far beyond its 4 MB of L2 none of those touches hit: the dirty walk of k=31 w=51 fetched
 // 5.1 GB per Gbp (plain: 1.05 GB; the bits themselves are 0.125 GB) and ran at the fabric's speed, 0.82 ms
-// (profiles/r05_skip_dirty_walk.txt, section 7).  There the bits now arrive in CHUNKS of kAmbRowDwords dwords per lane -
-// sixteen dword loads to LDS, row r of the chunk at r x 256 bytes + 4 x lane, so that a lane reads dword d of its chunk at
+// (profiles/r05_skip_dirty_walk.txt, section 7).  There the bits now arrive in CHUNKS of amb_row_dwords(W) dwords per lane -
+// one dword load to LDS per row, row r of the chunk at r x 256 bytes + 4 x lane, so that a lane reads dword d of its chunk at
 // d x 256 + 4 x lane whatever its alignment (conflict-free; two rows per ds_read2st64) - and a chunk serves
-// (512 - 31) / W blocks: nine at w = 51.  One buffer: the next chunk is asked for when the last block of the current one
+// (32 x rows - 31) / W blocks: six at w = 51 (11 rows), seven at w = 64 (16 rows).  One buffer: the next chunk is asked for when the last block of the current one
 // has read its bits, and used a block later.
 constexpr uint32_t kLandQ4Bytes = 64u * 4u;
-constexpr uint32_t kAmbRowDwords = 16u;
+// rows of a chunk: as many as fit beside the DEFAULT lanes' lists three times per CU (w <= 54: the CU's 160 KB are handed out in
+// units of 1280 bytes, so a workgroup may take 53 760; 39 520 of lists + 336 of tables leave 13 904: eleven rows and the fifth
+// dwords are 13 312), more where two workgroups share a CU
+constexpr uint32_t amb_row_dwords(int W) { return W <= 54 ? 11u : 16u; }
 #ifndef MM_AMBI_LAND
 #define MM_AMBI_LAND 1  // (0: A/B, the register look-ahead of rounds 2-4)
 #endif
@@ -395,9 +398,10 @@ constexpr uint32_t kAmbRowDwords = 16u;
 #endif
 constexpr bool ambi_land_rule(int W) { return MM_AMBI_LAND && W >= 32 && W <= 96 && wide_group_blocks(W) != 0; }
 constexpr bool ambi_rows_rule(int W) { return ambi_land_rule(W) && W >= MM_AMBI_ROWS_MINW; }
-// a wave's slice: the window bits (two parities of 64 x 16 bytes, or ONE chunk of kAmbRowDwords rows), then two parities of fifth dwords
-constexpr uint32_t land_amb_bytes(int W) { return ambi_rows_rule(W) ? kAmbRowDwords * 256u : 2u * 64u * 16u; }  // 2048 / 4096
-constexpr uint32_t land_wave_bytes(int W) { return land_amb_bytes(W) + 4u * kLandQ4Bytes; }                    // 3072 / 5120
+// a wave's slice: the window bits (two parities of 64 x 16 bytes, or ONE chunk of amb_row_dwords rows), then the fifth dwords (two parities, or one buffer)
+constexpr uint32_t land_amb_bytes(int W) { return ambi_rows_rule(W) ? amb_row_dwords(W) * 256u : 2u * 64u * 16u; }  // 2048 / 2816 / 4096
+constexpr uint32_t land_q4_bytes(int W) { return (ambi_rows_rule(W) ? 2u : 4u) * kLandQ4Bytes; }  // (one buffer beside the chunks)
+constexpr uint32_t land_wave_bytes(int W) { return land_amb_bytes(W) + land_q4_bytes(W); }                         // 3072 / 3328 / 4608
 constexpr uint32_t ambi_land_bytes(int W) { return ambi_land_rule(W) ? kFusedWaves * land_wave_bytes(W) : 0u; }  // 12288 / 20480 per workgroup
 
 // One lane walks its S windows.  List mode: appends emitted 16-bit values to the lane's LDS
@@ -548,7 +552,10 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     };
     uint32_t lpar = 0, apar = 0;
     constexpr uint32_t kLandAmbBytes = land_amb_bytes(W);
-    auto q4_off = [](uint32_t par, uint32_t which) -> uint32_t { return kLandAmbBytes + (2u * par + which) * kLandQ4Bytes; };
+    // (beside the chunked window bits the fifth dwords keep ONE buffer: a group's two values are read at the top of its first
+    // block, the next group's loads are issued further down the same block behind a wait for those reads)
+    constexpr bool kQ4One = AMBI && ambi_rows_rule(W);
+    auto q4_off = [](uint32_t par, uint32_t which) -> uint32_t { return kLandAmbBytes + (2u * (kQ4One ? 0u : par) + which) * kLandQ4Bytes; };
     typedef __attribute__((address_space(3))) void *LdsPtr;
     auto lds_u32 = [&](uint32_t addr) -> uint32_t {
         return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>((uintptr_t)addr);
@@ -736,6 +743,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
     };
     // kAmbRows (ambi_rows_rule): chunks of kAmbRowDwords dwords per lane, row r of a chunk at r x 256 bytes + 4 x lane
     constexpr bool kAmbRows = kAmbiLand && ambi_rows_rule(W);
+    constexpr uint32_t kAmbRowDwords = amb_row_dwords(W);
     constexpr uint32_t kAmbChunkBlocks = kAmbRows ? (32u * kAmbRowDwords - 31u) / (uint32_t)W : 1u;  // blocks a chunk serves
     static_assert(!kAmbRows || kAmbChunkBlocks >= 1u, "a chunk holds at least one block's bits at any alignment");
     uint32_t ka = 0;    // index of the coming block within its chunk (wave-uniform)
@@ -911,6 +919,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 wide_load(gp_in, Wa[1]);
                 wide_load(gp_out, Wr[1]);
                 if (kAmbiLand && ND == 5) {
+                    if (kQ4One) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the reads at the top of this block)
                     land_q4_load(gp_in, lpar, 0u);
                     land_q4_load(gp_out, lpar, 1u);
                 }

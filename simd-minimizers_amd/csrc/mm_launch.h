@@ -67,6 +67,7 @@ uint32_t fused_batch_nblk(const RunArgs &a, const uint64_t *n_windows, uint64_t 
 // the last round of the launch tapered.  Appends to `tiles`; returns false if the table would pass 2^31 tiles.
 // launch plan of a single-sequence run as the kernel would get it (MM_TAPER_SLOTS set: no device needed); see mm_fused.hip
 int fused_debug_plan(const RunArgs &a, unsigned long long *out /* [7] */);
+void fused_debug_lds(const RunArgs &a, unsigned long long *out2);  // {bytes of the lane lists, bytes of the skip-ambiguous landing area}
 // *nblk_out receives the longest lane of the table (RunArgs::nblk of the launch: it sizes the lists).
 bool fused_batch_tiles(const RunArgs &a, const uint64_t *n_windows, uint64_t n_seqs, std::vector<BatchTile> &tiles,
                        uint32_t *nblk_out);

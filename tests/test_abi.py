@@ -263,3 +263,37 @@ def test_kernel_source_compiles_with_hiprtc(tmp_path):
     for name in ("mm::fused_kernel<100, true, true, 0, false, false>", "mm::fused_kernel<40, true, true, 0, false, true>"):
         r = subprocess.run([exe, name], cwd=probe_dir, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "HIPRTC_SUCCESS" in r.stdout, (name, (r.stdout + r.stderr)[-1500:])
+
+
+def test_skip_ambiguous_launches_fit_the_cu(sm):
+    """Round 5, no GPU: a skip-ambiguous launch carries the landing area of its look-ahead loads in front of the lane lists
+    (12 KB for 32 <= w <= 37, 13 KB for 38 <= w <= 54, 18 KB above, 0 elsewhere).  Lists + landing + the static tables have to
+    fit the CU's 160 KB as many times as the kernel's register bound lets workgroups share it (4 up to w = 37, 3 up to
+    w = 54, 2 up to w = 64) - one workgroup fewer is a quarter to a third of the walk's speed - and the window sizes with
+    chunked window bits keep the default lanes of the plain walk (a genome's clean waves walk those lanes)."""
+    import ctypes as C
+    L = sm.lib()
+    out2, out7, out7p = (C.c_uint64 * 2)(), (C.c_uint64 * 7)(), (C.c_uint64 * 7)()
+    nw = (C.c_uint64 * 1)(3 * 10**9)
+    checked = 0
+    for w in list(range(13, 66)) + [81, 96, 100, 128]:
+        sm._check(L.mm_debug_launch_lds(w, 1, 4, nw[0], out2))
+        lists, landing = int(out2[0]), int(out2[1])
+        sm._check(L.mm_debug_launch_lds(w, 1, 0, nw[0], out2))
+        assert int(out2[1]) == 0                                     # (no ambiguity bits: no landing area)
+        sm._check(L.mm_debug_launch_plan(w, 1, 4, 0, nw, out7, None, None, None, 0, None))
+        sm._check(L.mm_debug_launch_plan(w, 1, 0, 0, nw, out7p, None, None, None, 0, None))
+        nblk, nblk_plain = int(out7[0]), int(out7p[0])
+        want_landing = 0 if (w < 32 or w > 96) else (4 * 3072 if w < 38 else (4 * 3328 if w <= 54 else 4 * 4608))
+        if 32 <= w <= 96 and landing == 0:
+            continue                                                 # (a window size whose loads are not grouped: no landing)
+        assert landing == want_landing, (w, landing)
+        per_cu = 4 if w <= 37 else (3 if w <= 54 else (2 if w <= 64 else 1))
+        granule = 1280                                               # (the CU's 160 KB are handed out in units of 1280 bytes)
+        assert -(-(lists + landing + 512) // granule) * granule * per_cu <= 160 * 1024, (w, lists, landing, per_cu)
+        if 21 <= w <= 37:
+            assert nblk * w <= 400 or nblk == 6, (w, nblk)          # (the short lanes of the middle window sizes)
+        else:
+            assert nblk == nblk_plain, (w, nblk, nblk_plain)
+        checked += 1
+    assert checked >= 50
