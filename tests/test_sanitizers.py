@@ -126,6 +126,44 @@ arr = (C.c_uint64 * 3)(900_000, 0, 5_000_000)
 seq_, w0_, nb_ = (C.c_uint32 * 4096)(), (C.c_uint32 * 4096)(), (C.c_uint32 * 4096)()
 o7, nt = (C.c_uint64 * 7)(), C.c_uint64()
 assert sm.lib().mm_debug_launch_plan(11, 1, 0, 3, arr, o7, seq_, w0_, nb_, 4096, C.byref(nt)) == 0 and nt.value > 3
+o2 = (C.c_uint64 * 2)()
+assert sm.lib().mm_debug_launch_lds(51, 1, 4, 10**9, o2) == 0 and o2[1] == 13312
+# round 5: the host-to-host call's mechanisms (page-locked and pageable caller buffers, a capacity that is too small),
+# the link probe, the skip-ambiguous run over a large window (prepass + landing area + chunked window bits) from host memory
+n = 70_000_000
+data = oracle.gen_packed(23, n + 64)
+d = torch.from_numpy(data).cuda()
+cap = int(n * 0.19)
+dev_out = torch.zeros(cap, dtype=torch.int32, device="cuda")
+c_dev = b.run_device(d, n, dev_out)
+want = dev_out[:c_dev].cpu().numpy().view(np.uint32)
+hp, _k1 = sm.pinned_array((len(data),), np.uint8)
+hp[:] = data
+ppos, _k2 = sm.pinned_array((cap + 3,), np.uint32)
+u8p, u32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)
+ws = sm.default_workspace(0)
+for out_m, in_m, chunks, pinned in (("engine", "engine", None, True), ("blit", "engine", "5", True), ("direct", "blit", None, True),
+                                    ("blit", "blit", "64", False)):
+    os.environ["MM_HOST_OUT"], os.environ["MM_HOST_IN"] = out_m, in_m
+    if chunks: os.environ["MM_PIPE_CHUNKS"] = chunks
+    else: os.environ.pop("MM_PIPE_CHUNKS", None)
+    src = hp if pinned else data
+    pos = ppos[1: cap + 1] if pinned else np.zeros(cap, dtype=np.uint32)
+    cnt = C.c_uint64()
+    sm._check(sm.lib().mm_run_host(b.plan().h, ws.h, src.ctypes.data_as(u8p), 0, n, pos.ctypes.data_as(u32p), None, cap, C.byref(cnt)))
+    assert cnt.value == c_dev and np.array_equal(pos[:c_dev], want), (out_m, in_m)
+    code = sm.lib().mm_run_host(b.plan().h, ws.h, src.ctypes.data_as(u8p), 0, n, pos.ctypes.data_as(u32p), None, 1000, C.byref(cnt))
+    assert code == sm.ERR["CAPACITY"] and cnt.value == c_dev
+for k_ in ("MM_HOST_OUT", "MM_HOST_IN", "MM_PIPE_CHUNKS"): os.environ.pop(k_, None)
+rates = (C.c_double * 3)()
+sm._check(sm.lib().mm_link_probe(ws.h, hp.ctypes.data_as(C.c_void_p), ppos.ctypes.data_as(C.c_void_p), 40 << 20, rates))
+assert min(rates) > 0.5
+a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=900_001)].copy()
+a[rng.integers(0, len(a), size=len(a) // 120)] = ord("N")
+b51 = sm.canonical_minimizers(31, 51)
+got = b51.run_skip_ambiguous_windows_once(sm.PackedNSeqVec.from_ascii(a.tobytes()))
+packed, amb = oracle.pack_ascii_n(a.tobytes())
+assert np.array_equal(np.asarray(got, dtype=np.uint32), oracle.run_skip_ambiguous(packed, amb, len(a), 31, 51))
 print("host paths ok")
 """
 

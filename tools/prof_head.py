@@ -203,11 +203,17 @@ def component(tag, cfg):
         cur = sqlite3.connect(db).cursor()
         acc = collections.defaultdict(float)
         n = collections.defaultdict(int)
+        per_kernel = collections.defaultdict(int)
         for k, c, v in cur.execute("select kernel_name,counter_name,value from counters_collection"):
             if any(l in k for l in likes):
                 acc[c] += v
                 n[c] += 1
+                per_kernel[(c, k)] += 1
         for c in acc:
+            # steps of this pass: the row warms up by TIME since round 5, so the step count is what was dispatched - every
+            # kernel of the row runs once per step (set-up kernels that ran once or twice are not counted)
+            counts = [m for (cc, _k), m in per_kernel.items() if cc == c and m >= 3]
+            steps = min(counts) if counts else steps
             tot[c] = acc[c] / steps
             lines.append(f"{c:14s} {n[c]} dispatches of {likes} over {steps} steps: {tot[c]:.1f} KB per step\n")
     if len(tot) == 2:
