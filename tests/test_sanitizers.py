@@ -156,7 +156,7 @@ for out_m, in_m, chunks, pinned in (("engine", "engine", None, True), ("blit", "
     assert code == sm.ERR["CAPACITY"] and cnt.value == c_dev
 for k_ in ("MM_HOST_OUT", "MM_HOST_IN", "MM_PIPE_CHUNKS"): os.environ.pop(k_, None)
 rates = (C.c_double * 3)()
-sm._check(sm.lib().mm_link_probe(ws.h, hp.ctypes.data_as(C.c_void_p), ppos.ctypes.data_as(C.c_void_p), 40 << 20, rates))
+sm._check(sm.lib().mm_link_probe(ws.h, hp.ctypes.data_as(C.c_void_p), ppos.ctypes.data_as(C.c_void_p), 16 << 20, rates))
 assert min(rates) > 0.5
 a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=900_001)].copy()
 a[rng.integers(0, len(a), size=len(a) // 120)] = ord("N")
