@@ -1801,7 +1801,9 @@ static int run_host_small(const mm_plan_t *plan, mm_workspace_t *ws, const uint8
     const uint64_t in_room = (kSmallInBytes + 255) & ~255ull;
     if (!ws->h_small) {
         void *hp = nullptr, *dp = nullptr;
-        if (hipHostMalloc(&hp, in_room + 2 * kSmallOutElems * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+        // (coherent: the CPU rewrites the bytes between calls and reads the positions right behind the wait - the device must
+        // not keep either in its L2, whatever HIP_HOST_COHERENT says)
+        if (hipHostMalloc(&hp, in_room + 2 * kSmallOutElems * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
             (void)hipGetLastError();
             if (hp) hipHostFree(hp);
