@@ -129,7 +129,7 @@ struct FusedParams {
     unsigned long long taper_start;
     uint32_t append;     // 1: *out.total holds the outputs before this launch (carry-in of tile 0), 0: starts at 0
     // Round 5, skip-ambiguous walks over large windows: bytes of the landing area of the walk's look-ahead loads
-    // (kAmbiLand in lane_walk; 4 waves x kLandWaveBytes) at the FRONT of the dynamic LDS - the lists start behind it, so
+    // (kAmbiLand in lane_walk; 4 waves x land_wave_bytes(W)) at the FRONT of the dynamic LDS - the lists start behind it, so
     // that list entries past a list's capacity still fall beyond the workgroup's allocation and never into it; 0 = none.
     uint32_t land_bytes;
     // reads mode (READS kernels): one lane per read, reads at a fixed stride in the buffer
@@ -402,7 +402,7 @@ constexpr bool ambi_rows_rule(int W) { return ambi_land_rule(W) && W >= MM_AMBI_
 constexpr uint32_t land_amb_bytes(int W) { return ambi_rows_rule(W) ? amb_row_dwords(W) * 256u : 2u * 64u * 16u; }  // 2048 / 2816 / 4096
 constexpr uint32_t land_q4_bytes(int W) { return (ambi_rows_rule(W) ? 2u : 4u) * kLandQ4Bytes; }  // (one buffer beside the chunks)
 constexpr uint32_t land_wave_bytes(int W) { return land_amb_bytes(W) + land_q4_bytes(W); }                         // 3072 / 3328 / 4608
-constexpr uint32_t ambi_land_bytes(int W) { return ambi_land_rule(W) ? kFusedWaves * land_wave_bytes(W) : 0u; }  // 12288 / 20480 per workgroup
+constexpr uint32_t ambi_land_bytes(int W) { return ambi_land_rule(W) ? kFusedWaves * land_wave_bytes(W) : 0u; }  // 12288 / 13312 / 18432 per workgroup
 
 // One lane walks its S windows.  List mode: appends emitted 16-bit values to the lane's LDS
 // list (entries past the capacity are dropped but counted).  DIRECT mode: stores final values

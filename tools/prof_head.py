@@ -63,9 +63,12 @@ def counters(db, like="fused_kernel"):
 
 
 def src_sha():
+    csrc = os.path.join(ROOT, "simd-minimizers_amd", "csrc")
+    sys.path.insert(0, csrc)
+    from strip_comments import strip  # (the hash is of the source without its comments, as in bench.py)
     h = hashlib.sha256()
     for f in ("mm_fused_impl.h", "mm_common.h"):
-        h.update(open(os.path.join(ROOT, "simd-minimizers_amd", "csrc", f), "rb").read())
+        h.update(strip(open(os.path.join(csrc, f)).read()).encode())
     return h.hexdigest()[:16]
 
 
