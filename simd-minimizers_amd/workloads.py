@@ -44,11 +44,12 @@ def component(name, ws, dev):
                 "what": f"reads mode: {n_reads} reads x {rl} bp, canonical minimizers k={k} w={w}"
                         + (" with super-k-mer indices" if sk is not None else "") + ", one launch (src/lib.rs:378 per read)",
                 "kernels": ["fused_kernel"]}
-    if name in ("SKIP", "SKIP_W33", "SKIP_W51", "PLAIN_W33", "PLAIN_W51"):
+    if name == "SKIP" or name.startswith(("SKIP_W", "PLAIN_W")):
         # (SKIP: the bench row, k=21 w=11.  SKIP_W33 / _W51 and their PLAIN_ twins: tools/prof_head.py stalls:<name> - the dirty
         # walk of the large windows beside the plain walk on the same sequence, profiles/r05_skip_dirty_walk.txt)
         if name != "SKIP":
-            k, w = 31, int(name[-2:])
+            w = int(name.split("_W")[1])
+            k = 31 if w % 2 else 30  # (canonical windows need odd k + w - 1)
         n = 1_000_000_000
         d = _generate(ws, dev, n, 2)
         amb = torch.zeros((n + 7) // 8 + 64, dtype=torch.uint8, device=dev)
