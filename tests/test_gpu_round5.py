@@ -376,3 +376,24 @@ def test_skip_ambiguous_chunked_window_bits(sm, oracle, gpu):
     finally:
         ws.set_blocks_per_lane(0)
     assert checked == 6 * (7 + 6 + 2) + 2
+
+
+def test_bench_single_process_device_group_line(sm, gpu):
+    """`bench.py --gpus 2 --single-process`: the several-device C ABI (mm_device_group_*) driven from ONE process - here two
+    entries that share this GPU, a functional check of the line: the strong split of one sequence, the entries' outputs
+    summing to the whole run's, and the gather timed beside it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    n = 200_000_000
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-process", "--steps", "3",
+                        "--warmup", "2", "--bases", str(n)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    cfg = line["config"]
+    assert cfg["devices"] == [0, 0] and cfg["distinct_devices"] == 1
+    assert sum(cfg["outputs_per_entry"]) == cfg["outputs"] and abs(cfg["outputs"] / n - 1 / 6) < 0.01
+    assert cfg["gather_ms"] > 0
