@@ -145,7 +145,9 @@ Geometry geometry(const RunArgs &a) {
     g.nblk = legal_nblk(a.w, a.mode, a.nblk, default_cap_limit(a.w, a.canonical_windows != 0, entry8(a)));
     if (entry8(a)) {
         const uint32_t max_nblk = (255u - a.w) / a.w;
-        if (g.nblk > max_nblk) g.nblk = max_nblk;
+        // (MM_E8_NOLIMIT, experiments build: a TIMING run with longer lanes - the entries wrap, the outputs are wrong, the
+        // instructions and the LDS are what a walk with two 8-bit list segments per lane would have)
+        if (g.nblk > max_nblk && !mm_exp_env("MM_E8_NOLIMIT")) g.nblk = max_nblk;
     }
     // Default lanes are as long as the lists (and the cache, see default_cap_limit) allow; a run too
     // short to fill the chip once with such tiles (1024 resident workgroups) gets shorter lanes, down
