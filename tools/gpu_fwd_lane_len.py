@@ -6,7 +6,8 @@ n = 3_100_000_000
 d = sm.generate_device(n, 3); ws = sm.default_workspace(0)
 out = torch.zeros(int(n * 0.19), dtype=torch.int32, device="cuda")
 cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
-b = sm.Builder(21, 11, False, 0)
+canon = os.environ.get("MM_CANON", "0") == "1"
+b = sm.Builder(21, 11, canon, 0)
 def kt(reps=8):
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.2:
@@ -17,4 +18,4 @@ def kt(reps=8):
     return ms / l
 for nb in [int(x) for x in (sys.argv[1:] or "0 22 20 17 14 11 8 0".split())]:
     ws.set_blocks_per_lane(nb)
-    print(f"forward k=21 w=11 3.1 Gbp, blocks per lane {nb or 'default'}: {kt():.4f} ms", flush=True)
+    print(f"{'canonical' if canon else 'forward'} k=21 w=11 3.1 Gbp, blocks per lane {nb or 'default'}: {kt():.4f} ms", flush=True)
