@@ -162,7 +162,8 @@ Geometry geometry(const RunArgs &a) {
     // of k=31 w=33 missed the L2 3.2 x as often as the plain walk and took 1.07 ms per Gbp with the default 26 blocks per
     // lane, 0.70 with 13; w = 25: 0.73 -> 0.63 with 14; w <= 20 and w >= 41 are flat (tools/gpu_skip_nblk.py,
     // profiles/r05_skip_dirty_walk.txt).  Lanes of at most 400 windows there.
-    // (w = 38, 40 took part until the chunked window bits, ambi_rows_rule: with them 18 - 22 blocks read 0.71 ms against 0.81 with 10)
+    // (w = 36 .. 40 took part until the chunked window bits, ambi_rows_rule: with them 18 - 22 blocks read 0.71 ms against 0.81 with 10
+    // at w = 38; w = 36 0.74 -> 0.68, w = 37 0.81 -> 0.68)
     if (a.nblk == 0 && a.wamb && a.w >= 21u && a.w <= 40u && !ambi_rows_rule((int)a.w)) {
         const uint32_t lim = 400u / a.w;
         if (g.nblk > lim) g.nblk = lim < 6u ? 6u : lim;
@@ -172,7 +173,8 @@ Geometry geometry(const RunArgs &a) {
     // 512 of them for the static tables.  The chunks are sized so that the default lanes pass (amb_row_dwords); this is the
     // guard for whatever changes either side (two workgroups per CU instead of three: k=31 w=51 0.74 -> 1.06 ms per Gbp).
     if (a.nblk == 0 && a.wamb && ambi_rows_rule((int)a.w) && a.w <= 54u) {
-        const uint32_t room = (160u * 1024u / 3u / 1280u) * 1280u - 512u - ambi_land_bytes((int)a.w);
+        const uint32_t per_cu = a.w <= 37u ? 4u : 3u;  // (the register bounds of the canonical walks, MM_MIN_BLOCKS)
+        const uint32_t room = (160u * 1024u / per_cu / 1280u) * 1280u - 512u - ambi_land_bytes((int)a.w);
         while (g.nblk > 6u && list_capacity(a.w, a.mode, a.w * g.nblk) * stride_of(a) > room) --g.nblk;
     }
     // super-k-mer runs pack (window << shift) + offset-in-window into the 16-bit list entry

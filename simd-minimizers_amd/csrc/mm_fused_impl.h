@@ -389,12 +389,13 @@ constexpr uint32_t kLandQ4Bytes = 64u * 4u;
 // rows of a chunk: as many as fit beside the DEFAULT lanes' lists three times per CU (w <= 54: the CU's 160 KB are handed out in
 // units of 1280 bytes, so a workgroup may take 53 760; 39 520 of lists + 336 of tables leave 13 904: eleven rows and the fifth
 // dwords are 13 312), more where two workgroups share a CU
-constexpr uint32_t amb_row_dwords(int W) { return W <= 54 ? 11u : 16u; }
+// (w <= 37, four workgroups per CU - 40 960 bytes each - and lanes bounded by geometry(): eight rows)
+constexpr uint32_t amb_row_dwords(int W) { return W <= 37 ? 8u : (W <= 54 ? 11u : 16u); }
 #ifndef MM_AMBI_LAND
 #define MM_AMBI_LAND 1  // (0: A/B, the register look-ahead of rounds 2-4)
 #endif
 #ifndef MM_AMBI_ROWS_MINW
-#define MM_AMBI_ROWS_MINW 38  // (97: A/B, one 16-byte load per block for every landing window size)
+#define MM_AMBI_ROWS_MINW 36  // (w = 33 .. 35 measured slower with the chunks: 0.69 -> 0.73, 0.81 -> 0.99 ms per Gbp at the 128-register bound; 36, 37 faster: 0.74 -> 0.68, 0.81 -> 0.68.  97: A/B, one 16-byte load per block everywhere)
 #endif
 constexpr bool ambi_land_rule(int W) { return MM_AMBI_LAND && W >= 32 && W <= 96 && wide_group_blocks(W) != 0; }
 constexpr bool ambi_rows_rule(int W) { return ambi_land_rule(W) && W >= MM_AMBI_ROWS_MINW; }

@@ -267,7 +267,7 @@ def test_kernel_source_compiles_with_hiprtc(tmp_path):
 
 def test_skip_ambiguous_launches_fit_the_cu(sm):
     """Round 5, no GPU: a skip-ambiguous launch carries the landing area of its look-ahead loads in front of the lane lists
-    (12 KB for 32 <= w <= 37, 13 KB for 38 <= w <= 54, 18 KB above, 0 elsewhere).  Lists + landing + the static tables have to
+    (12 KB for 32 <= w <= 35, 10 KB for w = 36, 37, 13 KB for 38 <= w <= 54, 18 KB above, 0 elsewhere).  Lists + landing + the static tables have to
     fit the CU's 160 KB as many times as the kernel's register bound lets workgroups share it (4 up to w = 37, 3 up to
     w = 54, 2 up to w = 64) - one workgroup fewer is a quarter to a third of the walk's speed - and the window sizes with
     chunked window bits keep the default lanes of the plain walk (a genome's clean waves walk those lanes)."""
@@ -284,15 +284,17 @@ def test_skip_ambiguous_launches_fit_the_cu(sm):
         sm._check(L.mm_debug_launch_plan(w, 1, 4, 0, nw, out7, None, None, None, 0, None))
         sm._check(L.mm_debug_launch_plan(w, 1, 0, 0, nw, out7p, None, None, None, 0, None))
         nblk, nblk_plain = int(out7[0]), int(out7p[0])
-        want_landing = 0 if (w < 32 or w > 96) else (4 * 3072 if w < 38 else (4 * 3328 if w <= 54 else 4 * 4608))
+        want_landing = 0 if (w < 32 or w > 96) else (4 * 3072 if w < 36 else (4 * 2560 if w < 38 else (4 * 3328 if w <= 54 else 4 * 4608)))
         if 32 <= w <= 96 and landing == 0:
             continue                                                 # (a window size whose loads are not grouped: no landing)
         assert landing == want_landing, (w, landing)
         per_cu = 4 if w <= 37 else (3 if w <= 54 else (2 if w <= 64 else 1))
         granule = 1280                                               # (the CU's 160 KB are handed out in units of 1280 bytes)
         assert -(-(lists + landing + 512) // granule) * granule * per_cu <= 160 * 1024, (w, lists, landing, per_cu)
-        if 21 <= w <= 37:
+        if 21 <= w <= 35:
             assert nblk * w <= 400 or nblk == 6, (w, nblk)          # (the short lanes of the middle window sizes)
+        elif w in (36, 37):
+            assert 12 <= nblk <= nblk_plain, (w, nblk, nblk_plain)   # (chunked window bits beside lists that fit four times per CU)
         else:
             assert nblk == nblk_plain, (w, nblk, nblk_plain)
         checked += 1
