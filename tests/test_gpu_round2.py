@@ -351,7 +351,7 @@ def _sharded_worker(rank, world, port, backend, q):
 
     dev_id = rank if backend == "nccl" else 0
     torch.cuda.set_device(dev_id)
-    if world > 1:
+    if world > 1 or backend == "nccl":
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{dev_id}"))
         else:
@@ -375,6 +375,16 @@ def _sharded_worker(rank, world, port, backend, q):
             return out[:c].clone()
 
         local, counts, gathered = sharding.run_sharded(compute, n - (k + w - 1) + 1, gather_to=0)
+        if backend == "nccl" and world == 1:
+            # (one rank: run_sharded returns before its collectives - run them here, through RCCL, on device tensors)
+            cnt = torch.tensor([int(local.numel())], dtype=torch.int64, device="cuda")
+            counts_t = [torch.zeros(1, dtype=torch.int64, device="cuda")]
+            dist.all_gather(counts_t, cnt)
+            cat, parts = sharding.gather_positions_cat(local, [int(counts_t[0].item())], 0)
+            ok = ok and int(counts_t[0].item()) == counts[0] and torch.equal(cat, local) and len(parts) == 1
+            s_ = local[:1024].to(torch.int64).clone()
+            dist.all_reduce(s_)
+            ok = ok and torch.equal(s_, local[:1024].to(torch.int64))
         if rank == 0:
             want = o.run(data, n, k, w, canonical=canonical, mode=mode)
             got = gathered.cpu().numpy().view(np.uint32)
@@ -396,7 +406,7 @@ def _sharded_worker(rank, world, port, backend, q):
             g = gathered[i].cpu().numpy().view(np.uint32)
             ok = ok and counts[i] == len(want) and np.array_equal(g, want)
         q.put(bool(ok))
-    if world > 1:
+    if world > 1 or backend == "nccl":
         dist.barrier()
         dist.destroy_process_group()
 
@@ -427,6 +437,13 @@ def _run_world(world, backend):
 def test_sharded_path_real_kernel_world1(gpu):
     """sharding.run_sharded / run_contig_batch_sharded wired to Builder.run_device / run_batch_device."""
     _run_world(1, "gloo")
+
+
+def test_sharded_path_real_kernel_world1_rccl(gpu):
+    """Round 5: the same helpers with an RCCL process group of ONE rank - what a one-GPU box can execute of the N > 1
+    path's communication: the communicator comes up on the device, the count exchange and the gather run through RCCL
+    on device tensors (degenerate: one rank), the barrier and the teardown.  Two ranks over RCCL need two GPUs (below)."""
+    _run_world(1, "nccl")
 
 
 def test_sharded_path_real_kernel_world2_shared_gpu(gpu):
