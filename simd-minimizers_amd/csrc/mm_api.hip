@@ -1791,13 +1791,14 @@ void mm_host_free(void *p) {
 // (hipHostMallocMapped), the kernel reads them from there and stores its positions (and indices) there, the one wait of the
 // synchronous run covers everything, and the CPU copies the results out.  A 150-base read moves 38 bytes in and about 100
 // out over the link; what the call costs is the launch and the wait.  (Many reads per call: mm_run_packed_reads_host.)
+static const int MM_SMALL_NOT_TAKEN = 1;  // (run_host_small's answer to a call that is not its to serve; errors are negative)
 static const uint64_t kSmallBases = 64ull << 10;
 static const uint64_t kSmallInBytes = (kSmallBases + 3) / 4 + 64;                 // bytes in, with room for a base offset
 static const uint64_t kSmallOutElems = kSmallBases;                               // at most one position per window
 static int run_host_small(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed, uint64_t base_offset,
                           uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk, uint64_t capacity, uint64_t *out_count) {
     const uint64_t bytes = (base_offset + n_bases + 3) / 4;
-    if (!ws->h_total_dev || n_bases > kSmallBases || bytes + 16 > kSmallInBytes || mm::mm_env("MM_NO_SMALL_HOST")) return 1;  // not this path
+    if (!ws->h_total_dev || n_bases > kSmallBases || bytes + 16 > kSmallInBytes || mm::mm_env("MM_NO_SMALL_HOST")) return MM_SMALL_NOT_TAKEN;
     const uint64_t in_room = (kSmallInBytes + 255) & ~255ull;
     if (!ws->h_small) {
         void *hp = nullptr, *dp = nullptr;
@@ -1807,7 +1808,7 @@ static int run_host_small(const mm_plan_t *plan, mm_workspace_t *ws, const uint8
             hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
             (void)hipGetLastError();
             if (hp) hipHostFree(hp);
-            return 1;  // (no mapped host memory on this runtime: the copies below stay)
+            return MM_SMALL_NOT_TAKEN;  // (no mapped host memory on this runtime: the copies below stay)
         }
         ws->h_small = static_cast<uint8_t *>(hp);
         ws->h_small_dev = static_cast<uint8_t *>(dp);
@@ -1842,7 +1843,7 @@ int mm_run_host(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed
     if (bytes && !packed) return MM_ERR_NULL;
     {
         const int rs = run_host_small(plan, ws, packed, base_offset, n_bases, out_pos, out_sk, capacity, out_count);
-        if (rs != 1) return rs;  // (1: not a call for that path)
+        if (rs != MM_SMALL_NOT_TAKEN) return rs;
     }
     uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
     int r = grow(din, ws->d_in_bytes, bytes + 16, 1);

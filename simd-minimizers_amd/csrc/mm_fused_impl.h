@@ -756,6 +756,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         for (uint32_t r = 0; r < kAmbRowDwords; ++r)  // (the row's 4 r bytes in the SCALAR offset, as in land_q4_load)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (LdsPtr)(uintptr_t)(base + r * 256u), 4, voff, r * 4u, 0, 0);
     };
+    // (the last dword read, row (rel >> 5) + NSUBA, only contributes when rel & 31 != 0; at the chunk's last block and rel & 31 == 0
+    // it lies one row behind the chunk - inside the wave's slice, the fifth dwords' buffer - and none of its bits is used)
     auto land_rows_read = [&](uint32_t rel, uint32_t (&out)[NSUBA]) {
         const uint32_t a = land + ((rel >> 5) << 8) + 4u * lane_id_now();
         uint32_t dd[NSUBA + 1];
