@@ -186,14 +186,14 @@ def cpu_baseline():
 
 # --------------------------------------------------------------------------- recorded counters
 def kernel_source_sha():
-    """Hash of the kernel source WITHOUT its comments (csrc/strip_comments.py, the text the run-time specialisation embeds):
+    """Hash of the kernel source WITHOUT its comments and blank lines (csrc/strip_comments.py):
     a reworded comment does not make the recorded counters stale, a changed instruction does."""
     csrc = os.path.join(ROOT, "simd-minimizers_amd", "csrc")
     sys.path.insert(0, csrc)
     from strip_comments import strip
     h = hashlib.sha256()
     for f in ("mm_fused_impl.h", "mm_common.h"):
-        h.update(strip(open(os.path.join(csrc, f)).read()).encode())
+        h.update("\n".join(ln for ln in strip(open(os.path.join(csrc, f)).read()).split("\n") if ln.strip()).encode())  # (blank lines - stripped comment lines - do not count)
     return h.hexdigest()[:16]
 
 

@@ -126,7 +126,7 @@ sys.path.insert(0, csrc)
 from strip_comments import strip  # noqa: E402  (the hash is of the source without its comments, as in bench.py)
 h = hashlib.sha256()
 for f in ("mm_fused_impl.h", "mm_common.h"):
-    h.update(strip(open(os.path.join(csrc, f)).read()).encode())
+    h.update("\n".join(ln for ln in strip(open(os.path.join(csrc, f)).read()).split("\n") if ln.strip()).encode())  # (blank lines - stripped comment lines - do not count)
 full, half = cls["valu_full"], cls["valu_half"]
 # shader cycles per wave64 instruction (means over the instructions of each class in profiles/r03_valu_issue_rates.txt,
 # "by wall time at that clock"); the architectural figures are 2 and 4 (MI355X_MICROARCH.md)

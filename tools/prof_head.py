@@ -68,7 +68,7 @@ def src_sha():
     from strip_comments import strip  # (the hash is of the source without its comments, as in bench.py)
     h = hashlib.sha256()
     for f in ("mm_fused_impl.h", "mm_common.h"):
-        h.update(strip(open(os.path.join(csrc, f)).read()).encode())
+        h.update("\n".join(ln for ln in strip(open(os.path.join(csrc, f)).read()).split("\n") if ln.strip()).encode())  # (blank lines - stripped comment lines - do not count)
     return h.hexdigest()[:16]
 
 
