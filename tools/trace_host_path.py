@@ -10,7 +10,10 @@ def rows(pat):
         out += list(csv.DictReader(open(f)))
     return out
 cp = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Direction"].replace("MEMORY_COPY_", ""), r["Source_Agent_Id"], r["Destination_Agent_Id"]) for r in rows("*memory_copy_trace.csv")]
-kn = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows("*kernel_trace.csv") if "fused_kernel" in r["Kernel_Name"]]
+krows = rows("*kernel_trace.csv")
+kn = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in krows if "fused_kernel" in r["Kernel_Name"]]
+# (round 5: the default download is a copy KERNEL that stores into the caller's page-locked buffer - it shows among the kernels)
+ck = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in krows if "copy_range_kernel" in r["Kernel_Name"]]
 cp.sort(); kn.sort()
 if not kn:
     sys.exit("no fused-kernel launches in the trace")
@@ -18,9 +21,12 @@ per_call = len(kn) // calls
 last = kn[-per_call:]
 t0 = min(last[0][0], min((c[0] for c in cp if c[0] >= last[0][0] - 5_000_000), default=last[0][0]))
 t1 = max([k[1] for k in last] + [c[1] for c in cp if c[0] >= t0])
-print(f"last call: {per_call} chunks, {(t1 - t0) / 1e6:.2f} ms from the first copy / kernel to the last end")
-ev = [(c[0], c[1], f"copy {c[2]:<16} {c[3]} -> {c[4]}") for c in cp if c[0] >= t0] + [(k[0], k[1], "fused kernel") for k in last]
+
+t1 = max([t1] + [c[1] for c in ck if c[0] >= t0])
+ev = [(c[0], c[1], f"copy {c[2]:<16} {c[3]} -> {c[4]}") for c in cp if c[0] >= t0] + [(k[0], k[1], "fused kernel") for k in last] + \
+     [(c[0], c[1], "copy kernel: positions -> the caller's page-locked buffer") for c in ck if c[0] >= t0]
 ev.sort()
+print(f"last call: {per_call} chunks, {(t1 - t0) / 1e6:.2f} ms from the first copy / kernel to the last end")
 for s, e, what in ev:
     print(f"  {(s - t0) / 1e6:8.3f} .. {(e - t0) / 1e6:8.3f} ms  ({(e - s) / 1e6:7.3f})  {what}")
 def busy(direction):
@@ -35,5 +41,9 @@ def overlap(a, b):
             o += max(0, min(e1, e2) - max(s1, s2))
     return o
 h2d, d2h = busy("HOST_TO_DEVICE"), busy("DEVICE_TO_HOST")
+ckb = sorted((c[0], c[1]) for c in ck if c[0] >= t0)
+if ckb:
+    print(f"copy kernels (device -> host): {total(ckb) / 1e6:.2f} ms in {len(ckb)} launches, in flight together with the uploads "
+          f"{overlap(h2d, ckb) / 1e6:.2f} ms; first download starts at {(ckb[0][0] - t0) / 1e6:.2f} ms, last ends at {(ckb[-1][1] - t0) / 1e6:.2f} ms")
 print(f"copy engines busy: H2D {total(h2d) / 1e6:.2f} ms in {len(h2d)} copies, D2H {total(d2h) / 1e6:.2f} ms in {len(d2h)} copies, "
       f"both directions in flight together {overlap(h2d, d2h) / 1e6:.2f} ms")
