@@ -140,6 +140,13 @@ int mm_workspace_kernel_time(mm_workspace_t *ws, double *total_ms, uint64_t *lau
                              int reset);
 /* Family used by the last run (mm_path_t). */
 int mm_workspace_last_path(const mm_workspace_t *ws);
+/* 1 when the last reads / batch run on this workspace was a LANE-TABLE launch (round 6): one launch of the reads-mode
+ * kernel whose lanes are segments of the reads - a read longer than a lane takes consecutive lanes - so reads and
+ * sequences of any lengths (Builder::run per read / contig, src/lib.rs:378; the reference's `short` experiment spans
+ * lengths 16 .. 16 384, bench/src/bin/paper.rs:62-115) fill every tile.  mm_run_reads_device*, mm_run_packed_reads_*
+ * take it when the longest read exceeds a default lane, mm_run_batch_device for batches of short sequences that lie
+ * within 2^32 bases of one another; diagnostics only, results are the same on every path. */
+int mm_workspace_last_lane_table(const mm_workspace_t *ws);
 /* Window sizes w for which the library carries a PREBUILT fused kernel (every other w <= 128 is specialised at
  * first use, larger ones take the generic family): canonical_windows 0 / 1 selects the forward / canonical
  * instances, reads_mode 0 / 1 the sequence-mode / reads-mode ones.  Writes up to `capacity` sizes in ascending

@@ -128,6 +128,7 @@ def lib():
         L.mm_workspace_enable_timing.argtypes = [vp, C.c_int]
         L.mm_workspace_kernel_time.argtypes = [vp, C.POINTER(C.c_double), u64p, C.c_int]
         L.mm_workspace_last_path.argtypes = [vp]
+        L.mm_workspace_last_lane_table.argtypes = [vp]
         if hasattr(L, "mm_prebuilt_window_sizes"):  # (absent from the round-3 library kept for A/B runs under tools/ab/)
             L.mm_prebuilt_window_sizes.argtypes = [C.c_int, C.c_int, u32p, C.c_int]
             L.mm_prebuilt_window_sizes.restype = C.c_int
@@ -186,7 +187,7 @@ EXPORTED_SYMBOLS = [
     "mm_plan_create",
     "mm_plan_destroy", "mm_plan_value_len", "mm_workspace_create", "mm_workspace_destroy",
     "mm_workspace_sync", "mm_workspace_check", "mm_workspace_force_generic", "mm_workspace_set_blocks_per_lane",
-    "mm_workspace_enable_timing", "mm_workspace_kernel_time", "mm_workspace_last_path", "mm_prebuilt_window_sizes",
+    "mm_workspace_enable_timing", "mm_workspace_kernel_time", "mm_workspace_last_path", "mm_workspace_last_lane_table", "mm_prebuilt_window_sizes",
     "mm_run_device_async", "mm_run_device", "mm_run_host", "mm_run_host_ascii",
     "mm_values_u64_device_async", "mm_values_u64_host", "mm_values_u128_device_async",
     "mm_values_u128_host", "mm_run_batch_device", "mm_run_reads_device_async", "mm_run_reads_device",
@@ -384,6 +385,10 @@ class Workspace:
 
     def last_path(self) -> int:
         return lib().mm_workspace_last_path(self.h)
+
+    def last_lane_table(self) -> bool:
+        """The last reads / batch run was ONE lane-table launch (``mm_workspace_last_lane_table``)."""
+        return bool(lib().mm_workspace_last_lane_table(self.h))
 
 
 class DeviceGroup:

@@ -155,6 +155,21 @@ struct mm_workspace {
     unsigned long long *batch_offsets = nullptr;
     uint64_t batch_offsets_n = 0;
     unsigned long long *h_batch = nullptr;  // page-locked landing buffer of a batch launch's offsets
+    // lane-table launches (round 6; mm_lanes.hip): the table, the tiles' origins, first lane per read, block sums, and -
+    // batches of sequences - the uploaded starts and lengths
+    mm::LaneSeg *seg_table = nullptr;
+    uint64_t seg_table_n = 0;
+    uint32_t *seg_origin = nullptr;
+    uint64_t seg_origin_n = 0;
+    uint32_t *seg_first = nullptr;
+    uint64_t seg_first_n = 0;
+    uint32_t *seg_blk = nullptr;
+    uint64_t seg_blk_n = 0;
+    unsigned long long *seg_starts = nullptr;
+    uint64_t seg_starts_n = 0;
+    uint32_t *seg_lens = nullptr;
+    uint64_t seg_lens_n = 0;
+    bool last_lane_table = false;  // the last reads / batch run was a lane-table launch (diagnostics)
     uint8_t *h_small = nullptr;             // page-locked staging of short host calls (run_host_small): bytes in, positions, indices
     uint8_t *h_small_dev = nullptr;         // ... as the device addresses it
     uint64_t h_batch_n = 0;
@@ -549,6 +564,12 @@ void mm_workspace_destroy(mm_workspace_t *ws) {
     if (ws->batch_tiles) hipFree(ws->batch_tiles);
     if (ws->batch_offsets) hipFree(ws->batch_offsets);
     if (ws->h_batch) hipHostFree(ws->h_batch);
+    if (ws->seg_table) hipFree(ws->seg_table);
+    if (ws->seg_origin) hipFree(ws->seg_origin);
+    if (ws->seg_first) hipFree(ws->seg_first);
+    if (ws->seg_blk) hipFree(ws->seg_blk);
+    if (ws->seg_starts) hipFree(ws->seg_starts);
+    if (ws->seg_lens) hipFree(ws->seg_lens);
     if (ws->h_small) hipHostFree(ws->h_small);
     if (ws->d_amb) hipFree(ws->d_amb);
     if (ws->d_vals) hipFree(ws->d_vals);
@@ -629,6 +650,7 @@ int mm_workspace_kernel_time(mm_workspace_t *ws, double *total_ms, uint64_t *lau
 }
 
 int mm_workspace_last_path(const mm_workspace_t *ws) { return ws ? ws->last_path : 0; }
+int mm_workspace_last_lane_table(const mm_workspace_t *ws) { return ws && ws->last_lane_table ? 1 : 0; }
 
 // Diagnostics (no device needed when MM_TAPER_SLOTS names the workgroup slots): the launch plan of a run over
 // n_windows windows - single sequence: out7 = {blocks per lane, tiles, taper_first, taper_per_level, taper_min_nblk,
@@ -910,6 +932,58 @@ int mm_run_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d
                                  win_end, d_out_pos, d_out_sk, capacity, d_count, false);
 }
 
+// Lane-table launch (round 6; mm_lanes.hip): reads / sequences of ANY lengths in ONE launch of the reads-mode kernel at
+// full lane occupancy.  `a` is the filled ReadsArgs of the run (status words and epoch are set here), `total_bases` the
+// bases of all reads together.  Returns 0, a negative MM_ERR_* code, or 1 when no lane-table launch can be had
+// (no kernel, no lane length that fits): the caller keeps its other paths.
+// MM_LANE_TABLE=0 switches the launches off (A/B: the per-read lanes / per-sequence tiles of rounds 2-5), =1 takes them
+// for every reads / batch run; results are identical either way.
+static int lane_table_policy() {
+    const char *e = mm::mm_env("MM_LANE_TABLE");
+    return e ? (e[0] == '0' ? 0 : 1) : -1;
+}
+static int run_lane_table(mm_workspace_t *ws, mm::ReadsArgs &a, const mm::SegSource &src, uint64_t total_bases) {
+    mm::SegPlan plan;
+    const int pr = mm::fused_segments_plan(a, total_bases, ws->nblk, &plan);
+    if (pr) return 1;
+    int r = grow(ws->seg_table, ws->seg_table_n, plan.lanes_cap, sizeof(mm::LaneSeg));
+    if (r) return r;
+    r = grow(ws->seg_origin, ws->seg_origin_n, plan.tiles, sizeof(uint32_t));
+    if (r) return r;
+    r = grow(ws->seg_first, ws->seg_first_n, a.n_reads + 1, sizeof(uint32_t));
+    if (r) return r;
+    r = grow(ws->seg_blk, ws->seg_blk_n, mm::lane_table_blocks(a.n_reads) + 1, sizeof(uint32_t));
+    if (r) return r;
+    r = grow_status(ws, (plan.tiles + 8) * mm::fused_status_stride());
+    if (r) return r;
+    a.out.status = ws->status;
+    r = next_status_epoch(ws, &a.status_epoch);
+    if (r) return r;
+    mm::SegBuffers b{ws->seg_table, ws->seg_origin, ws->seg_first, ws->seg_blk};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    a.timing_start = a.timing_stop = nullptr;
+    if (ws->timing) {
+        MM_HIP(hipEventCreate(&e0));
+        MM_HIP(hipEventCreate(&e1));
+        a.timing_start = e0;
+        a.timing_stop = e1;
+    }
+    const int lr = mm::launch_fused_segments(a, src, plan, b, ws->stream);
+    if (lr != 0) {
+        if (e0) hipEventDestroy(e0);
+        if (e1) hipEventDestroy(e1);
+        if (lr == -1) {
+            g_last_error = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
+            return MM_ERR_HIP;
+        }
+        return 1;
+    }
+    if (ws->timing) ws->events.emplace_back(e0, e1);
+    ws->last_path = MM_PATH_FUSED;
+    ws->last_lane_table = true;
+    return MM_OK;
+}
+
 // Batch mode of the fused kernel: every sequence is cut into tiles, one launch covers all tiles of
 // all sequences (a tile reads its sequence from a device table), so a batch of thousands of contigs
 // costs one launch instead of one per sequence.  Returns MM_BATCH_FALLBACK when the plan has no
@@ -924,6 +998,8 @@ static const int MM_BATCH_REDO = 2;
 struct BatchIssue {
     std::vector<mm::BatchSeq> seqs;        // (host copies of the tables: alive until the uploads have been waited for)
     std::vector<mm::BatchTile> tile_seq;
+    std::vector<unsigned long long> starts;  // lane-table launches: where every sequence starts in the common span, its length
+    std::vector<uint32_t> lens;
     uint64_t n_seqs = 0;
     bool launched = false;                 // false: nothing was queued (no tile at all): every offset is 0
 };
@@ -984,6 +1060,93 @@ static int batch_issue(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_seq
     for (uint64_t s = 0; s < n_seqs; ++s) {
         if (n_bases[s] >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
         nws[s] = n_bases[s] >= l ? n_bases[s] - l + 1 : 0;
+    }
+    // Round 6: batches of SHORT sequences take a lane-table launch of the reads-mode kernel (mm_lanes.hip) - a tile's 256
+    // lanes are any 256 consecutive segments of the batch, where the tile table below gives every sequence tiles of its
+    // own (a 10 kbp contig fills 33 of 256 lanes).  Needs all sequences inside one span of < 2^32 bases from the lowest
+    // pointer (one allocation, the FASTA packer's buffer); long contigs keep their tiles (tapered tail, sequence kernel).
+    ws->last_lane_table = false;
+    if (nonempty && lane_table_policy() != 0) {
+        mm::RunArgs probe = a;
+        probe.work_windows = 0;
+        const uint64_t tile_w = mm::fused_tile_windows(probe);  // windows of a default tile
+        uint64_t total_w = 0;
+        for (uint64_t s = 0; s < n_seqs; ++s) total_w += nws[s];
+        const bool short_seqs = total_w / nonempty < 8 * tile_w;
+        if ((short_seqs || lane_table_policy() == 1) &&
+            mm::fused_reads_supported(plan->w, plan->canonical_windows, (int)plan->ht.canonical, d_out_sk ? 1u : plan->mode)) {
+            uintptr_t lo = ~(uintptr_t)0, hi = 0;
+            uint32_t max_len = 0;
+            for (uint64_t s = 0; s < n_seqs; ++s) {
+                if (nws[s] == 0) continue;
+                if (!d_packed[s]) return MM_ERR_NULL;
+                const uintptr_t p0 = reinterpret_cast<uintptr_t>(d_packed[s]);
+                if ((((base_offsets ? base_offsets[s] : 0) + n_bases[s] + 3) / 4) > packed_bytes[s]) return MM_ERR_CAPACITY;
+                lo = p0 < lo ? p0 : lo;
+                hi = p0 + packed_bytes[s] > hi ? p0 + packed_bytes[s] : hi;
+                if (n_bases[s] > max_len) max_len = (uint32_t)n_bases[s];
+            }
+            const uint64_t span_bytes = hi - lo;
+            if (span_bytes < (1ull << 30) - 64) {
+                bi->starts.assign(n_seqs + 1, 0);
+                bi->lens.assign(n_seqs, 0);
+                uint64_t total_bases = 0;
+                for (uint64_t s = 0; s < n_seqs; ++s) {
+                    if (nws[s] == 0) continue;  // (no window: an empty lane; its start is never read from)
+                    bi->starts[s] = (reinterpret_cast<uintptr_t>(d_packed[s]) - lo) * 4ull + (base_offsets ? base_offsets[s] : 0);
+                    bi->lens[s] = (uint32_t)n_bases[s];
+                    total_bases += n_bases[s];
+                }
+                mm::ReadsArgs ra;
+                int r = make_view(reinterpret_cast<const void *>(lo), span_bytes, 0, span_bytes * 4ull, &ra.seq);
+                if (r == MM_OK) {
+                    r = grow(ws->seg_starts, ws->seg_starts_n, n_seqs + 1, sizeof(unsigned long long));
+                    if (r) return r;
+                    r = grow(ws->seg_lens, ws->seg_lens_n, n_seqs, sizeof(uint32_t));
+                    if (r) return r;
+                    r = grow(ws->batch_offsets, ws->batch_offsets_n, n_seqs + 1, sizeof(unsigned long long));
+                    if (r) return r;
+                    if (ws->h_batch_n < n_seqs + 1) {
+                        if (ws->h_batch) hipHostFree(ws->h_batch);
+                        ws->h_batch = nullptr;
+                        ws->h_batch_n = 0;
+                        const uint64_t want = (n_seqs + 1) * 2;
+                        MM_HIP(hipHostMalloc(reinterpret_cast<void **>(&ws->h_batch), want * sizeof(unsigned long long), hipHostMallocDefault));
+                        ws->h_batch_n = want;
+                    }
+                    MM_HIP(hipMemcpyAsync(ws->seg_starts, bi->starts.data(), (n_seqs + 1) * sizeof(unsigned long long),
+                                          hipMemcpyHostToDevice, ws->stream));
+                    MM_HIP(hipMemcpyAsync(ws->seg_lens, bi->lens.data(), n_seqs * sizeof(uint32_t), hipMemcpyHostToDevice, ws->stream));
+                    ra.ht = plan->ht;
+                    ra.k = plan->k;
+                    ra.w = plan->w;
+                    ra.mode = plan->mode;
+                    ra.canonical_windows = plan->canonical_windows;
+                    ra.n_reads = n_seqs;
+                    ra.read_stride = 0;
+                    ra.read_len = max_len;
+                    ra.read_lens = nullptr;
+                    ra.read_starts = nullptr;
+                    ra.read_offsets = ws->batch_offsets;
+                    ra.wamb = nullptr;
+                    ra.wamb_dwords = 0;
+                    ra.out = a.out;
+                    ra.use_ticket = (ws->force_ticket || mm::mm_env("MM_FORCE_TICKET")) ? 1 : 0;
+                    ra.timing_start = ra.timing_stop = nullptr;
+                    MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
+                    const mm::SegSource src{ws->seg_starts, ws->seg_lens, 0, max_len};
+                    r = run_lane_table(ws, ra, src, total_bases);
+                    if (r < 0) return r;
+                    if (r == 0) {
+                        MM_HIP(hipMemcpyAsync(ws->h_batch, ws->batch_offsets, (n_seqs + 1) * sizeof(unsigned long long),
+                                              hipMemcpyDeviceToHost, ws->stream));
+                        MM_HIP(hipMemcpyAsync(ws->h_total, ws->total, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ws->stream));
+                        bi->launched = true;
+                        return MM_OK;
+                    }
+                }
+            }
+        }
     }
     {
         // the tile table (mm_fused.hip): whole tiles per sequence, lanes sized for whole rounds of resident
@@ -1074,6 +1237,8 @@ static int batch_finish(mm_workspace_t *ws, BatchIssue *bi, bool has_pos, uint64
     MM_HIP(hipStreamSynchronize(ws->stream));
     bi->seqs.clear();
     bi->tile_seq.clear();
+    bi->starts.clear();
+    bi->lens.clear();
     const int je = judge_run_error(ws);
     if (je < 0) return je;
     if (je == 1) return MM_BATCH_REDO;  // (the workspace is in ticket mode now)
@@ -1223,30 +1388,58 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
             if (r) return r;
             a.wamb = ws->wamb;
         }
-        r = grow_status(ws, mm::fused_reads_status_words(a));
-        if (r) return r;
-        a.out.status = ws->status;
-        r = next_status_epoch(ws, &a.status_epoch);
-        if (r) return r;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (ws->timing) {
-            MM_HIP(hipEventCreate(&e0));
-            MM_HIP(hipEventCreate(&e1));
-            a.timing_start = e0;
-            a.timing_stop = e1;
+        // One lane per read (rounds 2-5) while the longest read fits a default lane; the lane table (round 6) for
+        // longer ones - a lane per read then needs lists that leave a CU one or two workgroups, and above about 1.5 kbp
+        // none at all (the per-read loop below, 33 us per read, was what a HiFi / ONT batch got).
+        ws->last_lane_table = false;
+        const int policy = lane_table_policy();
+        bool lanes = policy == 1;
+        if (policy == -1) {
+            mm::SegPlan sp;
+            const uint64_t max_nw = read_len >= l ? read_len - l + 1 : 0;
+            lanes = mm::fused_segments_plan(a, span, ws->nblk, &sp) == 0 && max_nw > sp.S;
         }
-        const int lr = mm::launch_fused_reads(a, ws->stream);
-        if (lr == 0) {
-            if (ws->timing) ws->events.emplace_back(e0, e1);
-            ws->last_path = MM_PATH_FUSED;
-        } else {
-            if (e0) hipEventDestroy(e0);
-            if (e1) hipEventDestroy(e1);
-            if (lr == -1) {
-                g_last_error = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
-                return MM_ERR_HIP;
+        int lr = -3;
+        if (lanes) {
+            const mm::SegSource src{a.read_starts, a.read_starts ? nullptr : d_read_lens, read_stride, read_len};
+            r = run_lane_table(ws, a, src, span);
+            if (r < 0) return r;
+            lr = r == 0 ? 0 : -3;
+        }
+        if (lr != 0) {
+            r = grow_status(ws, mm::fused_reads_status_words(a));
+            if (r) return r;
+            a.out.status = ws->status;
+            r = next_status_epoch(ws, &a.status_epoch);
+            if (r) return r;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            a.timing_start = a.timing_stop = nullptr;
+            if (ws->timing) {
+                MM_HIP(hipEventCreate(&e0));
+                MM_HIP(hipEventCreate(&e1));
+                a.timing_start = e0;
+                a.timing_stop = e1;
             }
-            fast = false;  // reads too long for one lane each
+            lr = mm::launch_fused_reads(a, ws->stream);
+            if (lr == 0) {
+                if (ws->timing) ws->events.emplace_back(e0, e1);
+                ws->last_path = MM_PATH_FUSED;
+            } else {
+                if (e0) hipEventDestroy(e0);
+                if (e1) hipEventDestroy(e1);
+                if (lr == -1) {
+                    g_last_error = std::string("kernel launch failed: ") + hipGetErrorString(hipGetLastError());
+                    return MM_ERR_HIP;
+                }
+                // (reads too long for one lane each and no lane-table launch either - switched off, or no kernel)
+                if (lr == -3 && !lanes && policy != 0) {
+                    const mm::SegSource src{a.read_starts, a.read_starts ? nullptr : d_read_lens, read_stride, read_len};
+                    r = run_lane_table(ws, a, src, span);
+                    if (r < 0) return r;
+                    if (r == 0) lr = 0;
+                }
+                if (lr != 0) fast = false;
+            }
         }
     }
     if (!fast) {

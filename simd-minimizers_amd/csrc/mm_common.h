@@ -72,6 +72,19 @@ struct BatchTile {
     uint32_t pad;
 };
 
+// One lane of a lane-table launch (reads-mode kernels, round 6): the lane walks the windows [win0, win0 + count) of
+// read (sequence) `read`; `start` = base of the buffer span at which window win0 starts.  A tile = 256 consecutive
+// entries; a read longer than a lane takes consecutive lanes (the seam between two lanes of one read is the dedup
+// rule against the lane's predecessor window, as between the lanes of a single sequence), a read's FIRST lane
+// (win0 == 0) has no predecessor and stores the read's output offset.  Built on the device (mm_lanes.hip) from the
+// reads' starts and lengths; entries behind the last lane of the table carry count = 0 and win0 != 0.
+struct LaneSeg {
+    uint32_t start;
+    uint32_t win0;
+    uint32_t count;
+    uint32_t read;
+};
+
 struct OutParams {
     uint32_t *pos;
     uint32_t *sk;  // may be null

@@ -680,6 +680,8 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
     p.read_stride = p.read_len = 0;
     p.read_lens = nullptr;
     p.read_starts = nullptr;
+    p.lane_segs = nullptr;
+    p.seg_tile_origin = nullptr;
     p.read_offsets = nullptr;
     p.wamb = a.wamb;
     p.wamb_dwords = a.wamb_dwords;
@@ -817,6 +819,8 @@ int launch_split(const RunArgs &a, const SplitBuffers &b, hipStream_t stream) {
     p.read_stride = p.read_len = 0;
     p.read_lens = nullptr;
     p.read_starts = nullptr;
+    p.lane_segs = nullptr;
+    p.seg_tile_origin = nullptr;
     p.read_offsets = nullptr;
     p.land_bytes = 0;  // (plans that need the landing area were refused above)
     p.wamb = a.wamb;
@@ -938,6 +942,106 @@ uint64_t fused_reads_status_words(const ReadsArgs &a) {
 }
 uint64_t fused_status_stride() { return status_stride_host(); }
 
+namespace {
+KernelRef resolve_reads_kernel(const ReadsArgs &a) {
+    KernelRef kr;
+    const bool sk = a.out.sk != nullptr && a.mode == 0;
+    const FusedReadsInstance *inst =
+        (a.mode == 0 && !sk) ? find_reads_instance(a.w, a.canonical_windows, (int)a.ht.canonical) : nullptr;
+    if (inst)
+        kr.host = inst->fn;
+    else
+        kr.mod = jit_fused_kernel(a.w, a.canonical_windows != 0, a.ht.canonical != 0, (int)a.mode, sk, true,
+                                  &t_jit_error);
+    return kr;
+}
+}  // namespace
+
+// ---- lane-table launches (round 6; mm_lanes.hip, FusedParams::lane_segs)
+// Lane length: the default lanes of the sequence mode with 16-bit list entries (the reads-mode kernels keep 16 bits) -
+// the same trade of per-lane fixed cost against the L2 footprint of the resident lanes' spans.
+int fused_segments_plan(const ReadsArgs &a, uint64_t total_bases, uint32_t nblk_want, SegPlan *plan) {
+    if (a.n_reads == 0 || a.n_reads >= (1ull << 32) || a.mode > 2) return -3;
+    const bool sk = a.out.sk != nullptr && a.mode == 0;
+    uint32_t nblk = legal_nblk(a.w, a.mode, nblk_want, default_cap_limit(a.w, a.canonical_windows != 0, false));
+    if (sk) {  // packed (window, offset) list entries: S << shift <= 65536 (kSkShift, mm_fused_impl.h)
+        uint32_t sh = 1;
+        while ((1u << sh) <= a.w) ++sh;
+        while (nblk > 1u && ((uint64_t)a.w * nblk << sh) > 65536u) --nblk;
+        if (((uint64_t)a.w * nblk << sh) > 65536u) return -3;
+    }
+    // skip-ambiguous runs: the landing area of the walk's look-ahead loads in front of the lists
+    const uint32_t land_bytes = ambi_landing(a.w, a.wamb);
+    uint32_t cap = 0;
+    for (;;) {
+        cap = list_capacity(a.w, a.mode, a.w * nblk);
+        if (cap * kListStride + land_bytes <= kMaxLdsBytes || nblk == 1u) break;
+        nblk = nblk > 4u ? nblk * 7u / 8u : nblk - 1u;
+    }
+    if (cap * kListStride + land_bytes > kMaxLdsBytes || a.w * nblk + a.w > kFusedMaxLaneWindows) return -3;
+    plan->nblk = nblk;
+    plan->S = a.w * nblk;
+    plan->list_cap = cap;
+    plan->lds_bytes = cap * kListStride;
+    // every read owns at least one lane and ceil(windows / S) <= windows / S + 1 of them
+    const uint64_t lanes = a.n_reads + total_bases / plan->S + 1u;
+    plan->tiles = (lanes + kFusedThreads - 1) / kFusedThreads;
+    plan->lanes_cap = plan->tiles * kFusedThreads;
+    if (plan->lanes_cap >= (1ull << 32) || plan->tiles >= (1ull << 31)) return -3;
+    return 0;
+}
+
+int launch_fused_segments(const ReadsArgs &a, const SegSource &src, const SegPlan &plan, const SegBuffers &b,
+                          hipStream_t stream) {
+    const KernelRef kr = resolve_reads_kernel(a);
+    if (!kr) return -2;
+    if (launch_lane_table(src, a.n_reads, a.k + a.w - 1u, plan, b, stream)) return -1;
+    FusedParams p;
+    p.seq = a.seq;
+    p.ht = a.ht;
+    p.k = a.k;
+    p.nblk = plan.nblk;
+    p.win_begin = p.win_end = 0;
+    p.list_cap = plan.list_cap;
+    p.use_ticket = a.use_ticket ? 1u : 0u;
+    p.debug = 0;
+    p.epoch = a.status_epoch;
+    p.append = 0;
+    p.taper_first = 0xffffffffu;
+    p.taper_per_level = 1;
+    p.taper_min_nblk = 0;
+    p.taper_start = 0;
+    p.n_reads = (uint32_t)a.n_reads;
+    p.reads_per_lane = 1;
+    p.read_stride = a.read_stride;
+    p.read_len = a.read_len;
+    p.read_lens = nullptr;
+    p.read_starts = nullptr;
+    p.lane_segs = b.table;
+    p.seg_tile_origin = b.tile_origin;
+    p.read_offsets = a.read_offsets;
+    p.wamb = a.wamb;
+    p.wamb_dwords = a.wamb_dwords;
+    p.land_bytes = ambi_landing(a.w, a.wamb);
+    p.batch_seqs = nullptr;
+    p.batch_tile_seq = nullptr;
+    p.batch_offsets = nullptr;
+    p.batch_n = 0;
+    p.trace = nullptr;
+    p.dump = nullptr;
+    p.dump_stride = 0;
+    p.tile_status = nullptr;
+    p.redo_list = nullptr;
+    p.redo_n = nullptr;
+    p.out = a.out;
+    if (a.status_epoch == 0 &&
+        hipMemsetAsync(a.out.status, 0, sizeof(unsigned long long) * (plan.tiles + 8) * status_stride_host(), stream) != hipSuccess)
+        return -1;
+    if (a.use_ticket && hipMemsetAsync(a.out.ticket, 0, sizeof(uint32_t), stream) != hipSuccess) return -1;
+    if (const char *pad = mm_env("MM_LDS_PAD")) g_lds_pad = (uint32_t)atoi(pad);
+    return launch_kernel(kr, (uint32_t)plan.tiles, plan.lds_bytes + p.land_bytes + g_lds_pad, stream, p, a.timing_start, a.timing_stop);
+}
+
 int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     if (a.n_reads == 0) return 0;
     const uint32_t l = a.k + a.w - 1;
@@ -968,20 +1072,13 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     if (lds_bytes > 159u * 1024u) return -3;
     const uint64_t per_tile = (uint64_t)kFusedThreads * R;
     const uint64_t nblocks = (a.n_reads + per_tile - 1) / per_tile;
-    KernelRef kr;
     const bool sk = a.out.sk != nullptr && a.mode == 0;
     if (sk) {  // packed (window, offset) list entries bound the read length (kSkShift, mm_fused_impl.h)
         uint32_t sh = 1;
         while ((1u << sh) <= a.w) ++sh;
         if (((uint64_t)S << sh) > 65536u) return -3;
     }
-    const FusedReadsInstance *inst =
-        (a.mode == 0 && !sk) ? find_reads_instance(a.w, a.canonical_windows, (int)a.ht.canonical) : nullptr;
-    if (inst)
-        kr.host = inst->fn;
-    else
-        kr.mod = jit_fused_kernel(a.w, a.canonical_windows != 0, a.ht.canonical != 0, (int)a.mode, sk, true,
-                                  &t_jit_error);
+    const KernelRef kr = resolve_reads_kernel(a);
     if (!kr) return -2;
 
     FusedParams p;
@@ -1005,6 +1102,8 @@ int launch_fused_reads(const ReadsArgs &a, hipStream_t stream) {
     p.read_len = a.read_len;
     p.read_lens = a.read_lens;
     p.read_starts = a.read_starts;
+    p.lane_segs = nullptr;
+    p.seg_tile_origin = nullptr;
     p.read_offsets = a.read_offsets;
     p.wamb = a.wamb;
     p.wamb_dwords = a.wamb_dwords;

@@ -142,6 +142,12 @@ struct FusedParams {
     // FASTQ / FASTA packers write; null = reads at the fixed stride above.  n_reads + 1 entries (device).
     const unsigned long long *read_starts;
     unsigned long long *read_offsets;   // [n_reads + 1] first output slot of every read (device)
+    // (round 6) LANE TABLE: lane t of tile b walks lane_segs[256 b + t] (LaneSeg, mm_common.h) - reads of ANY lengths in one
+    // launch at full lane occupancy: a long read takes consecutive lanes, a short one a lane of its own; the blocks a
+    // wave walks are those of its longest lane.  seg_tile_origin[b] = the smallest `start` among tile b's lanes (the
+    // origin of the tile's buffer descriptor).  The table is padded to the grid.  null = one of the read layouts above.
+    const LaneSeg *lane_segs;
+    const uint32_t *seg_tile_origin;
     // skip-ambiguous windows (PackedNSeq, src/minimizers.rs:169-214): bit g set = the window that
     // starts at base g (relative to the first base of the sequence / buffer span) is skipped
     const uint32_t *wamb;               // null for a plain PackedSeq
@@ -1513,7 +1519,9 @@ __device__ __forceinline__ void copy_out_wave(const uint8_t *smem, const OutPara
                                               const int wave, const int lane, const uint32_t vbt, const uint32_t S,
                                               const uint32_t kSh, const unsigned long long run0,
                                               const uint32_t wave_total, const uint32_t my_count,
-                                              const uint32_t excl) {
+                                              const uint32_t excl, const uint32_t lane_vb = 0u) {
+    // lane_vb (READS): what the entries of THIS lane's list are relative to on top of vbt - the lane's first window
+    // inside its read in lane-table launches (LaneSeg::win0), 0 otherwise
     constexpr uint32_t kStride = list_stride(E8), kEB = E8 ? 1u : 2u;
     {
     // Copy the 64 lists of this wave's lanes, in lane order (= window order).  Entry c of
@@ -1599,7 +1607,7 @@ __device__ __forceinline__ void copy_out_wave(const uint8_t *smem, const OutPara
                 for (int u = 0; u < kBatch; ++u) {
                     const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
                     const uint32_t n = pkl & 511u, off = pkl >> 9;
-                    const uint32_t vbl = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
+                    const uint32_t vbl = READS ? vb0 + __builtin_amdgcn_readlane(lane_vb, L0 + u) : vb0 + (uint32_t)(L0 + u) * S;
                     const uint32_t iw = ent[u] >> kSh;
                     const uint32_t val = SK ? vbl + iw + (ent[u] & kRelMask) : vbl + ent[u];
                     // (round 2 experiment: storing every list as one or two full, aligned 128-byte lines
@@ -1646,7 +1654,7 @@ __device__ __forceinline__ void copy_out_wave(const uint8_t *smem, const OutPara
                 for (int u = 0; u < kBatch; ++u) {
                     const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
                     const uint32_t n = pkl & 511u, off = pkl >> 9;
-                    const uint32_t vbl = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
+                    const uint32_t vbl = READS ? vb0 + __builtin_amdgcn_readlane(lane_vb, L0 + u) : vb0 + (uint32_t)(L0 + u) * S;
                     const uint32_t iw = ent[u] >> kSh;
                     const uint32_t val = SK ? vbl + iw + (ent[u] & kRelMask) : vbl + ent[u];
                     const uint32_t val2 = vbl + 1u + iw;
@@ -1695,7 +1703,7 @@ __device__ __forceinline__ void copy_out_wave(const uint8_t *smem, const OutPara
                 for (int u = 0; u < kBatch; ++u) {
                     const uint32_t pkl = __builtin_amdgcn_readlane(pk, L0 + u);
                     const uint32_t n = pkl & 511u, off = pkl >> 9;
-                    const uint32_t vb = READS ? vb0 : vb0 + (uint32_t)(L0 + u) * S;
+                    const uint32_t vb = READS ? vb0 + __builtin_amdgcn_readlane(lane_vb, L0 + u) : vb0 + (uint32_t)(L0 + u) * S;
                     uint32_t voff = (uint32_t)lane < n ? (off + (uint32_t)lane) * 4u : 0xffffffffu;
                     voff |= ~store_mask;
                     const uint32_t iw = ent[u] >> kSh;
@@ -1712,7 +1720,7 @@ __device__ __forceinline__ void copy_out_wave(const uint8_t *smem, const OutPara
                 const uint32_t L = (uint32_t)__builtin_ctzll(longer);
                 const uint32_t pkl = __builtin_amdgcn_readlane(pk, L);
                 const uint32_t n = pkl & 511u, off = pkl >> 9;
-                const uint32_t vb = READS ? vb0 : vb0 + L * S;
+                const uint32_t vb = READS ? vb0 + __builtin_amdgcn_readlane(lane_vb, L) : vb0 + L * S;
                 for (uint32_t c = (uint32_t)kWave + lane; c < n; c += kWave) {
                     const uint8_t *q = rd + kEB * L + (c - lane) * kStride;
                     const uint32_t e1 = E8 ? (uint32_t)*q : (uint32_t)*reinterpret_cast<const uint16_t *>(q);
@@ -1918,12 +1926,31 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     bool lane_active = false;
     // READS: a lane walks reads_per_lane consecutive reads; read j of lane t is read
     // (bid * 256 + t) * R + j of the batch
-    const uint32_t R = READS ? p.reads_per_lane : 1u;
+    // (round 6) lane-table launches: lane t of the tile walks the segment lane_segs[256 * bid + t], one per lane
+    const bool segs = READS && p.lane_segs != nullptr;
+    const uint32_t R = READS ? (segs ? 1u : p.reads_per_lane) : 1u;
     const uint32_t tile_read0 = bid * kFusedThreads * R;          // first read of the tile
     const uint32_t lane_read0 = tile_read0 + (uint32_t)tid * R;   // first read of the lane
     ctx.list_used = 0;
     // sets ctx up for read j of the lane (READS); returns whether the lane has windows to walk
     auto setup_read = [&](uint32_t j) -> bool {
+        if (segs) {
+            const LaneSeg sg = p.lane_segs[(size_t)bid * kFusedThreads + (uint32_t)tid];
+            const uint32_t origin = __builtin_amdgcn_readfirstlane(p.seg_tile_origin[bid]);  // (tile-uniform: SGPR descriptor)
+            const uint32_t cnt = sg.count < S ? sg.count : S;  // (never more than the lists were sized for)
+            ctx.p0 = (long long)seq_base0 + (long long)origin - 1;
+            ctx.lane_bases = sg.start - origin;
+            ctx.wbase = sg.win0;
+            ctx.no_prev = sg.win0 == 0u;  // the read's first window: no predecessor, always emits
+            ctx.rem_valid = (int)cnt;
+            ctx.abase = sg.start;
+            // the wave walks the blocks of its longest lane (the others' windows past their count are masked)
+            uint32_t m = cnt;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, kWave));
+            ctx.nblk = (__builtin_amdgcn_readfirstlane(m) + (uint32_t)W - 1u) / (uint32_t)W;
+            return cnt != 0u;
+        }
         const uint32_t r = lane_read0 + j;
         const bool in = r < p.n_reads;
         uint32_t len, lane_bases, abase;
@@ -2050,7 +2077,13 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     const bool overflow = s_overflow != 0 && !(MM_DBG(p) & 16u);  // 16: timing experiment with half-size lists
     const unsigned long long run0 = s_excl + wave_base;  // first output slot of this wave
     const uint32_t excl = incl - my_count;
-    if (READS) {
+    uint32_t lane_vb = 0;  // (READS) what this lane's list entries are relative to: see copy_out_wave
+    if (READS && segs) {
+        // (loaded again rather than kept in registers across the walk)
+        const LaneSeg sg = p.lane_segs[(size_t)bid * kFusedThreads + (uint32_t)tid];
+        lane_vb = sg.win0;
+        if (sg.win0 == 0u && sg.read < p.n_reads) p.read_offsets[sg.read] = run0 + excl;
+    } else if (READS) {
         unsigned long long o = run0 + excl;
         for (uint32_t j = 0; j < R; ++j) {
             if (lane_read0 + j < p.n_reads) p.read_offsets[lane_read0 + j] = o;
@@ -2062,7 +2095,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     if (!overflow) {
         copy_out_wave<kE8, SK, READS>(lists, p.out, MM_DBG(p), wave, lane,
                                       (READS ? 0u : (uint32_t)bw0) - (MODE == 0 ? 1u : 0u), S, (uint32_t)kSkShift<W>,
-                                      run0, wave_total, my_count, excl);
+                                      run0, wave_total, my_count, excl, lane_vb);
     } else if (READS) {
         // some list overflowed: walk the lane's reads again, now storing straight to the output
         unsigned long long o = run0 + excl;

@@ -123,6 +123,34 @@ uint64_t fused_reads_status_words(const ReadsArgs &a);
 // returns 0, -1 (HIP failure), -2 (no instance), -3 (reads too long for the LDS lists)
 int launch_fused_reads(const ReadsArgs &a, hipStream_t stream);
 
+// ---- lane-table launches of the reads-mode kernels (round 6): reads / sequences of ANY lengths in one launch at full
+// lane occupancy.  mm_lanes.hip builds the table (LaneSeg, mm_common.h) on the device from the reads' starts and lengths.
+struct SegSource {  // where read r starts (bases from the first base of the span) and how long it is; device arrays
+    const unsigned long long *starts;  // null: r * stride
+    const uint32_t *lens;              // null: starts[r + 1] - starts[r] when `starts` is given, max_len otherwise
+    unsigned long long stride;
+    uint32_t max_len;                  // longer reads are cut to it
+};
+struct SegPlan {
+    uint32_t nblk, S, list_cap, lds_bytes;  // lane length (blocks, windows), entries and bytes of the lane lists
+    uint64_t lanes_cap, tiles;              // upper bound of the lanes (a multiple of 256) and the grid
+};
+struct SegBuffers {
+    LaneSeg *table;         // plan.tiles * 256 entries
+    uint32_t *tile_origin;  // plan.tiles
+    uint32_t *seg_first;    // n_reads + 1
+    uint32_t *blk_sums;     // lane_table_blocks(n_reads) + 1
+};
+uint64_t lane_table_blocks(uint64_t n_reads);
+int launch_lane_table(const SegSource &src, uint64_t n_reads, uint32_t l, const SegPlan &plan, const SegBuffers &b,
+                      hipStream_t stream);
+// lane length and grid of a lane-table launch over `n_reads` reads of `total_bases` bases in all (nblk_want: blocks per
+// lane, 0 = the default lanes of the plan).  Returns 0, -2 (no kernel) or -3 (no lane length fits).
+int fused_segments_plan(const ReadsArgs &a, uint64_t total_bases, uint32_t nblk_want, SegPlan *plan);
+// the table's kernels and the walk, on `stream`.  Returns 0, -1 (HIP failure) or -2 (no kernel for this plan).
+int launch_fused_segments(const ReadsArgs &a, const SegSource &src, const SegPlan &plan, const SegBuffers &b,
+                          hipStream_t stream);
+
 // ---- run-time specialisation (mm_jit.hip): window sizes without a prebuilt instance
 constexpr uint32_t kJitMaxW = 128;  // ring registers: 256 VGPRs + AGPRs still hold W = 128 without scratch
 bool jit_enabled();                 // MM_JIT=0 switches it off (then such w take the generic family)
