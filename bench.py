@@ -532,6 +532,10 @@ def main():
                 extras.append(workloads.measure(comp, ws, dev))
             except Exception as e:  # a component must never take the headline down
                 extras.append({"component": comp, "error": str(e)[:200]})
+        try:  # the reference's short-sequence ladder (round 6)
+            extras.append(workloads.ladder(ws, dev))
+        except Exception as e:
+            extras.append({"component": "LADDER", "error": str(e)[:200]})
 
     link_trace("after the secondary configurations")
     # ---------------------------------------------------------------- workload set-up

@@ -10,7 +10,13 @@ import ctypes as C
 
 from . import (Builder, _check, canonical_minimizers, lib, run_reads_device)
 
-COMPONENTS = ("READS", "READS_SK", "SKIP", "VALUES", "PACK", "FASTA", "FASTQ")
+COMPONENTS = ("READS", "READS_SK", "SKIP", "VALUES", "PACK", "FASTA", "FASTQ", "READS_VAR", "LONGREADS", "BATCH10K")
+
+# The reference's `short` experiment (bench/src/bin/paper.rs:62-115): sequences of random length in [n, 2n), one
+# Builder::run per sequence; its published forward (w=11, k=21) figures in ns per base (bench/results-neon.json, BASELINE.md
+# section 1 - ARM NEON, not measured here).
+LADDER_N = (16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192)
+LADDER_REF_NS_PER_BASE = (20.4, 20.5, 16.8, 9.5, 5.9, 3.9, 2.9, 2.5, 2.2, 2.1)
 
 
 def _generate(ws, dev, n, seed):
@@ -44,6 +50,73 @@ def component(name, ws, dev):
                 "what": f"reads mode: {n_reads} reads x {rl} bp, canonical minimizers k={k} w={w}"
                         + (" with super-k-mer indices" if sk is not None else "") + ", one launch (src/lib.rs:378 per read)",
                 "kernels": ["fused_kernel"]}
+    if name in ("READS_VAR", "LONGREADS") or name.startswith("LADDER_"):
+        # reads of MIXED lengths packed back to back (the FASTQ packer's layout), one call of mm_run_packed_reads_device:
+        #   READS_VAR   8 M reads of 100 .. 200 bp (one lane per read: every lane of a wave walks its longest read)
+        #   LONGREADS   200 k reads, lengths log-uniform in 1 .. 50 kbp - the HiFi / ONT regime; ONE lane-table launch (round 6)
+        #   LADDER_<n>_<F|C>  a rung of the reference's `short` experiment: lengths uniform in [n, 2n), 2^30 bases in all,
+        #               forward / canonical minimizers
+        g = torch.Generator(device=dev)
+        g.manual_seed(6)
+        canonical = True
+        if name == "READS_VAR":
+            lens = torch.randint(100, 201, (8_000_000,), device=dev, generator=g)
+            label = "8 M reads of 100 .. 200 bp"
+        elif name == "LONGREADS":
+            import math
+            u = torch.rand(200_000, device=dev, generator=g, dtype=torch.float64)
+            lens = torch.exp(math.log(1000.0) + u * (math.log(50_000.0) - math.log(1000.0))).to(torch.int64)
+            label = "200 k reads, lengths log-uniform in 1 .. 50 kbp (long reads)"
+        else:
+            _, ln, fl = name.split("_")
+            ln = int(ln)
+            canonical = fl == "C"
+            lens = torch.randint(ln, 2 * ln, ((1 << 30) * 2 // (3 * ln),), device=dev, generator=g)
+            label = f"{lens.numel()} sequences of {ln} .. {2 * ln - 1} bp (the reference's `short` experiment, bench/src/bin/paper.rs:62-115)"
+        n_reads = int(lens.numel())
+        starts = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+        starts[1:] = torch.cumsum(lens, 0)
+        n = int(starts[-1].item())
+        mx = int(lens.max().item())
+        del lens
+        b = Builder(k, w, canonical, 0).workspace(ws)
+        d = _generate(ws, dev, n, 7)
+        out = torch.empty(int(n * 0.19) + 4096, dtype=torch.int32, device=dev)
+        offs = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+
+        def step():
+            _check(L.mm_run_packed_reads_device_async(b.plan().h, ws.h, C.c_void_p(d.data_ptr()), d.numel(), 0, n_reads,
+                                                      C.c_void_p(starts.data_ptr()), n, mx, C.c_void_p(out.data_ptr()), None,
+                                                      out.numel(), C.c_void_p(offs.data_ptr()), C.c_void_p(cnt.data_ptr())))
+
+        def alg():  # the packed bases, the starts in, positions and offsets out
+            return (n + 3) // 4 + 4 * int(cnt.item()) + 16 * (n_reads + 1)
+        return {"step": step, "units": n, "unit": "bases", "alg_bytes": alg, "keep": (d, out, offs, cnt, starts),
+                "what": f"{label}, {'canonical' if canonical else 'forward'} minimizers k={k} w={w}, packed back to back, one call of "
+                        "mm_run_packed_reads_device (src/lib.rs:378 per read)",
+                "kernels": ["fused_kernel", "seg_"], "lane_table": lambda: ws.last_lane_table(), "reads": n_reads}
+    if name == "BATCH10K":
+        # 20 000 contigs of 10 kbp through mm_run_batch_device: one lane-table launch (round 6; before: every contig tiles of its own)
+        n_seqs, ln = 20_000, 10_000
+        n = n_seqs * ln
+        b = canonical_minimizers(k, w).workspace(ws)
+        d = _generate(ws, dev, n, 9)
+        out = torch.empty(int(n * 0.19) + 4096, dtype=torch.int32, device=dev)
+        ptrs = (C.c_void_p * n_seqs)(*[d.data_ptr() + (i * ln) // 4 for i in range(n_seqs)])
+        nbytes = (C.c_uint64 * n_seqs)(*[d.numel() - (i * ln) // 4 for i in range(n_seqs)])
+        lens = (C.c_uint64 * n_seqs)(*([ln] * n_seqs))
+        boffs = (C.c_uint64 * n_seqs)(*([0] * n_seqs))
+        out_offsets = (C.c_uint64 * (n_seqs + 1))()
+
+        def step():  # (synchronous: the offsets come back to the host)
+            _check(L.mm_run_batch_device(b.plan().h, ws.h, n_seqs, ptrs, nbytes, boffs, lens, C.c_void_p(out.data_ptr()), None,
+                                         out.numel(), out_offsets))
+        return {"step": step, "units": n, "unit": "bases", "alg_bytes": lambda: (n + 3) // 4 + 4 * int(out_offsets[n_seqs]) + 8 * (n_seqs + 1),
+                "keep": (d, out), "kernel_timing": True,
+                "what": f"{n_seqs} contigs x {ln} bp, canonical minimizers k={k} w={w}, one call of mm_run_batch_device (kernel time by HIP "
+                        "events; the call itself is synchronous and returns the offsets to the host)",
+                "kernels": ["fused_kernel", "seg_"], "lane_table": lambda: ws.last_lane_table(), "reads": n_seqs}
     if name == "SKIP" or name.startswith(("SKIP_W", "PLAIN_W")):
         # (SKIP: the bench row, k=21 w=11.  SKIP_W33 / _W51 and their PLAIN_ twins: tools/prof_head.py stalls:<name> - the dirty
         # walk of the large windows beside the plain walk on the same sequence, profiles/r05_skip_dirty_walk.txt)
@@ -184,6 +257,14 @@ def measure(name, ws, dev, warm=3, reps=5):
             break
     ms = []
     for _ in range(reps):
+        if c.get("kernel_timing"):  # (a synchronous entry point: the walk kernel's own time, HIP events on the workspace's stream)
+            ws.enable_timing(True)
+            ws.kernel_time(True)
+            c["step"]()
+            t, launches = ws.kernel_time(True)
+            ws.enable_timing(False)
+            ms.append(t)
+            continue
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         c["step"]()
@@ -196,6 +277,31 @@ def measure(name, ws, dev, warm=3, reps=5):
     rec = {"component": name, "what": c["what"], "ms": round(med, 4), "units": c["units"], "unit": c["unit"],
            "G_units_per_s": round(c["units"] / med / 1e6, 1), "algorithmic_bytes": alg,
            "GB_per_s": round(alg / med / 1e6, 1), "frac": round(alg / (med * 1e-3) / 8e12, 4)}
+    if "lane_table" in c:
+        rec["lane_table"] = bool(c["lane_table"]())
+        rec["reads"] = c["reads"]
     c.clear()
     torch.cuda.empty_cache()
     return rec
+
+
+def ladder(ws, dev):
+    """The reference's `short` experiment (bench/src/bin/paper.rs:62-115) as ONE call per rung: sequences of random length in
+    [n, 2n) for n = 16 .. 8192, 2^30 bases per rung (the reference: 2^20, one Builder::run per sequence), forward and canonical
+    minimizers k=21 w=11.  Whole-call device time (the lane table's kernels included), ns per base beside the reference's
+    published NEON figure."""
+    rows = []
+    for n, ref in zip(LADDER_N, LADDER_REF_NS_PER_BASE):
+        row = {"n": n, "lengths": f"{n}..{2 * n - 1}", "reference_neon_fwd_ns_per_base": ref}
+        for fl, key in (("F", "forward"), ("C", "canonical")):
+            try:
+                r = measure(f"LADDER_{n}_{fl}", ws, dev)
+                row[key] = {"ms": r["ms"], "Gbases_per_s": r["G_units_per_s"], "ns_per_base": round(r["ms"] * 1e6 / r["units"], 5),
+                            "frac": r["frac"], "lane_table": r["lane_table"], "sequences": r["reads"]}
+                row["bases"] = r["units"]
+            except Exception as e:  # a rung must never take the bench line down
+                row[key] = {"error": str(e)[:200]}
+        rows.append(row)
+    return {"component": "LADDER", "what": "the reference's short-sequence ladder (bench/src/bin/paper.rs:62-115; BASELINE.md section 1): "
+            "lengths uniform in [n, 2n), 2^30 bases per rung packed back to back, minimizers k=21 w=11, one call of "
+            "mm_run_packed_reads_device per rung (whole-call device time)", "rows": rows}

@@ -128,6 +128,10 @@ def test_fuzz_batch_reads_and_ambiguous(sm, oracle, gpu, seed):
         if mode == 0:
             n_reads = int(rng.integers(1, 700))
             read_len = int(rng.integers(k + w - 1, k + w + 260))
+            if it % 3 == 0:  # (round 6) reads across and far above a lane's length: the lane-table launch, mixed with short ones
+                n_reads = int(rng.integers(1, 70))
+                read_len = int(rng.integers(k + w + 200, 7000))
+                tally["long_read_batches"] = tally.get("long_read_batches", 0) + 1
             stride = read_len + int(rng.integers(0, 9))
             span = n_reads * stride + 64
             a = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=span)].copy()
@@ -141,6 +145,7 @@ def test_fuzz_batch_reads_and_ambiguous(sm, oracle, gpu, seed):
             offr = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
             tot = sm.run_reads_device(b, d_p, n_reads, stride, read_len, outr, offr, read_lens=d_lens,
                                       d_amb=d_m if canonical else None)
+            tally["lane_table_runs"] = tally.get("lane_table_runs", 0) + int(gpu.last_lane_table())
             ho = offr.cpu().numpy()
             hp = outr[:tot].cpu().numpy().view(np.uint32)
             for r in rng.integers(0, n_reads, size=min(n_reads, 40)):
@@ -171,3 +176,4 @@ def test_fuzz_batch_reads_and_ambiguous(sm, oracle, gpu, seed):
     print("fuzz tally", seed, tally)
     assert tally["batches"] == 60 and tally["batch_bases"] > 2_000_000
     assert tally["reads_checked"] > 300 and tally["ambiguous"] >= 15 and tally["ambiguous_bases"] > 500_000
+    assert tally.get("long_read_batches", 0) >= 5 and tally.get("lane_table_runs", 0) >= 5

@@ -1,0 +1,267 @@
+"""Round 6: lane-table launches (mm_lanes.hip, FusedParams::lane_segs) - reads / sequences of ANY lengths in ONE launch of the
+reads-mode kernel (the reference's operator is Builder::run per read / contig, src/lib.rs:378; its `short` experiment spans
+lengths 16 .. 16 384, bench/src/bin/paper.rs:62-115).  Everything through the C ABI, bit-exact against the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+class _Env:
+    """MM_LANE_TABLE for the duration of a block (tests/conftest.py makes the library read switches every time)."""
+
+    def __init__(self, value):
+        self.value = value
+
+    def __enter__(self):
+        self.old = os.environ.get("MM_LANE_TABLE")
+        if self.value is None:
+            os.environ.pop("MM_LANE_TABLE", None)
+        else:
+            os.environ["MM_LANE_TABLE"] = self.value
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("MM_LANE_TABLE", None)
+        else:
+            os.environ["MM_LANE_TABLE"] = self.old
+
+
+def _packed_reads(sm, lens, seed):
+    """reads of the given lengths back to back in one generated PackedSeq: (device bytes, host bytes, starts)"""
+    import torch
+    lens = np.asarray(lens, dtype=np.int64)
+    starts = np.zeros(len(lens) + 1, dtype=np.int64)
+    starts[1:] = np.cumsum(lens)
+    d = sm.generate_device(max(int(starts[-1]), 1), seed)
+    return d, d.cpu().numpy(), starts
+
+
+def _run_packed(sm, ws, b, d, starts, mx, sk=False):
+    import torch
+    n = len(starts) - 1
+    total = int(starts[-1])
+    ds = torch.from_numpy(starts).cuda()
+    out = torch.full((max(1, total) + 8,), -7, dtype=torch.int32, device="cuda")
+    osk = torch.zeros_like(out) if sk else None
+    offs = torch.full((n + 1,), -1, dtype=torch.int64, device="cuda")
+    cnt = C.c_uint64()
+    ws.enable_timing(True)
+    ws.kernel_time(True)
+    sm._check(sm.lib().mm_run_packed_reads_device(b.plan().h, ws.h, C.c_void_p(d.data_ptr()), d.numel(), 0, n,
+                                                  C.c_void_p(ds.data_ptr()), total, int(mx), C.c_void_p(out.data_ptr()),
+                                                  C.c_void_p(osk.data_ptr()) if sk else None, out.numel() - 8,
+                                                  C.c_void_p(offs.data_ptr()), C.byref(cnt)))
+    _, launches = ws.kernel_time(True)
+    ws.enable_timing(False)
+    tot = int(cnt.value)
+    ho = offs.cpu().numpy()
+    assert ho[0] == 0 and ho[-1] == tot and np.all(np.diff(ho) >= 0)
+    assert int(out[tot].item()) == -7  # nothing written past the count
+    return out[:tot].cpu().numpy().view(np.uint32), ho, (osk[:tot].cpu().numpy().view(np.uint32) if sk else None), launches
+
+
+def _check_reads(oracle, host, starts, lens, flat, ho, k, w, canonical, mode, fsk=None, sample=None, cut=None):
+    for r in (sample if sample is not None else range(len(lens))):
+        s0 = int(starts[r])
+        ln = int(lens[r]) if cut is None else min(int(lens[r]), cut)
+        res = oracle.run(host[s0 // 4:], ln, k, w, canonical=canonical, mode=mode, super_kmers=fsk is not None, base_offset=s0 % 4)
+        wp = res[0] if fsk is not None else res
+        assert np.array_equal(flat[ho[r]: ho[r + 1]], wp), (r, ln, k, w, canonical, mode)
+        if fsk is not None:
+            assert np.array_equal(fsk[ho[r]: ho[r + 1]], res[1]), (r, ln, "super-k-mer indices")
+
+
+def test_lane_table_reads_of_any_lengths(sm, oracle, gpu):
+    """Packed reads whose lengths straddle the old one-lane-per-read limit (about 1.5 kbp at w = 11; 70 001 bases is beyond
+    any lane) in ONE launch: lengths 0 .. 6000 with the corner cases in front, forward / canonical / super-k-mer indices /
+    closed and open syncmers / a large window; every read == the oracle.  Before round 6 a batch with one long read ran one
+    launch per read."""
+    rng = np.random.default_rng(601)
+    lens = rng.integers(0, 6000, 500)
+    lens[:10] = [0, 30, 31, 32, 70_001, 308, 309, 338, 339, 5999]
+    d, host, starts = _packed_reads(sm, lens, 5)
+    for (k, w, canonical, mode, sk, n) in ((21, 11, True, 0, False, 500), (21, 11, False, 0, False, 500), (21, 11, True, 0, True, 250),
+                                           (15, 17, True, 1, False, 200), (15, 17, False, 2, False, 200), (31, 51, True, 0, False, 300),
+                                           (5, 7, False, 0, True, 200), (1, 1, False, 0, False, 60), (32, 64, True, 0, False, 120)):
+        b = sm.Builder(k, w, canonical, mode)
+        flat, ho, fsk, launches = _run_packed(sm, gpu, b, d, starts[: n + 1], int(lens[:n].max()), sk=sk)
+        assert gpu.last_lane_table() and gpu.last_path() == sm.PATH_FUSED and launches == 1, (k, w, launches)
+        _check_reads(oracle, host, starts, lens[:n], flat, ho, k, w, canonical, mode, fsk=fsk)
+    # max_read_len below the longest read: longer reads are cut to it (like a read_lens entry above read_len)
+    b = sm.canonical_minimizers(21, 11)
+    flat, ho, _, launches = _run_packed(sm, gpu, b, d, starts[:201], 2500)
+    assert gpu.last_lane_table() and launches == 1
+    _check_reads(oracle, host, starts, lens[:200], flat, ho, 21, 11, True, 0, cut=2500)
+
+
+def test_lane_table_fastq_to_minimizers_on_the_device(sm, oracle, gpu):
+    """FASTQ text -> mm_fasta_pack_device -> mm_run_packed_reads_device with long reads: the reads pipeline stays on the device
+    (no per-read loop, no read-back of the starts) - one launch, every read == the oracle on the record's own text."""
+    import torch
+    rng = np.random.default_rng(602)
+    lens = [int(x) for x in np.exp(rng.uniform(np.log(200), np.log(40_000), 120))] + [0, 30, 31]
+    parts = []
+    for r, ln in enumerate(lens):
+        seq = ACGT[rng.integers(0, 4, ln)].tobytes()
+        parts.append(b"@r%d\n" % r + seq + b"\n+\n" + b"I" * ln + b"\n")
+    text = b"".join(parts)
+    rec = sm.fasta_pack_device(text, max_records=len(lens) + 1)
+    want = oracle.fastq_records(text)
+    assert rec.lengths() == lens
+    b = sm.canonical_minimizers(21, 11)
+    out = torch.zeros(sum(lens) + 8, dtype=torch.int32, device="cuda")
+    offs = torch.full((len(lens) + 1,), -1, dtype=torch.int64, device="cuda")
+    gpu.enable_timing(True)
+    gpu.kernel_time(True)
+    total = sm.run_packed_reads_device(b, rec, out, offs)
+    _, launches = gpu.kernel_time(True)
+    gpu.enable_timing(False)
+    assert gpu.last_lane_table() and launches == 1
+    ho = offs.cpu().numpy()
+    flat = out[:total].cpu().numpy().view(np.uint32)
+    for r, ln in enumerate(lens):
+        packed = np.concatenate([oracle.pack_ascii(want[r][2]), np.zeros(16, dtype=np.uint8)])
+        assert np.array_equal(flat[ho[r]: ho[r + 1]], oracle.run(packed, ln, 21, 11, canonical=True)), (r, ln)
+
+
+def test_lane_table_equals_one_lane_per_read(sm, oracle, gpu):
+    """Short reads through BOTH launches - the lane table forced (MM_LANE_TABLE=1) and switched off (=0) - give the same
+    positions and offsets, for pinned lane lengths of 1, 2, 5 blocks as well (many lanes per read: every seam)."""
+    rng = np.random.default_rng(603)
+    lens = rng.integers(0, 700, 4000)
+    d, host, starts = _packed_reads(sm, lens, 8)
+    for (k, w, canonical) in ((21, 11, True), (31, 19, False), (9, 5, True)):
+        b = sm.Builder(k, w, canonical, 0)
+        with _Env("0"):
+            ref, ro, _, _ = _run_packed(sm, gpu, b, d, starts, 700)
+            assert not gpu.last_lane_table()
+        for nblk in (0, 1, 2, 5):
+            gpu.set_blocks_per_lane(nblk)
+            try:
+                with _Env("1"):
+                    flat, ho, _, launches = _run_packed(sm, gpu, b, d, starts, 700)
+                    assert gpu.last_lane_table() and launches == 1
+            finally:
+                gpu.set_blocks_per_lane(0)
+            assert np.array_equal(ho, ro) and np.array_equal(flat, ref), (k, w, nblk)
+        _check_reads(oracle, host, starts, lens, ref, ro, k, w, canonical, 0, sample=range(0, 4000, 41))
+
+
+def test_lane_table_batch_of_short_contigs(sm, oracle, gpu):
+    """mm_run_batch_device over thousands of short contigs in one buffer: ONE lane-table launch (before: every contig tiles of
+    its own, 33 of 256 lanes busy at 10 kbp); same offsets and positions as the per-sequence tiles (MM_LANE_TABLE=0), sampled
+    contigs against the oracle; contigs in SEPARATE allocations far apart keep the tile table."""
+    import torch
+    rng = np.random.default_rng(604)
+    lens = [int(x) for x in rng.integers(0, 30_000, 1500)]
+    lens[:4] = [0, 30, 31, 100_000]
+    gaps = rng.integers(0, 9, len(lens))
+    starts = np.concatenate([[0], np.cumsum(np.array(lens) + gaps)])[: len(lens)]
+    big = sm.generate_device(int(starts[-1]) + lens[-1] + 64, 12)
+    host = big.cpu().numpy()
+    seqs = [big[int(s) // 4:] for s in starts]
+    boffs = [int(s) % 4 for s in starts]
+    out = torch.zeros(sum(lens) // 4 + 64, dtype=torch.int32, device="cuda")
+    for (k, w, canonical, mode, sk) in ((21, 11, True, 0, False), (21, 11, False, 0, True), (31, 51, True, 1, False)):
+        b = sm.Builder(k, w, canonical, mode)
+        osk = torch.zeros_like(out) if sk else None
+        with _Env("0"):
+            ro = sm.run_batch_device(b, seqs, lens, out, osk, base_offsets=boffs)
+            assert not gpu.last_lane_table()
+            ref = out[: ro[-1]].cpu().numpy().copy()
+            rsk = osk[: ro[-1]].cpu().numpy().copy() if sk else None
+        out.zero_()
+        gpu.enable_timing(True)
+        gpu.kernel_time(True)
+        offs = sm.run_batch_device(b, seqs, lens, out, osk, base_offsets=boffs)
+        _, launches = gpu.kernel_time(True)
+        gpu.enable_timing(False)
+        assert gpu.last_lane_table() and launches == 1
+        assert offs == ro and np.array_equal(out[: offs[-1]].cpu().numpy(), ref)
+        if sk:
+            assert np.array_equal(osk[: offs[-1]].cpu().numpy(), rsk)
+        flat = ref.view(np.uint32)
+        for s in list(range(0, 12)) + list(range(12, len(lens), 97)):
+            want = oracle.run(host, lens[s], k, w, canonical=canonical, mode=mode, base_offset=int(starts[s]), super_kmers=sk)
+            assert np.array_equal(flat[offs[s]: offs[s + 1]], want[0] if sk else want), (s, lens[s])
+    # long contigs keep their tiles (tapered tail, sequence kernel)
+    b = sm.canonical_minimizers(21, 11)
+    long_lens = [3_000_000, 2_500_000]
+    ld = [sm.generate_device(n, 20 + i) for i, n in enumerate(long_lens)]
+    lout = torch.zeros(1_200_000, dtype=torch.int32, device="cuda")
+    sm.run_batch_device(b, ld, long_lens, lout)
+    assert not gpu.last_lane_table()
+
+
+def test_lane_table_fixed_stride_reads_and_ambiguous(sm, oracle, gpu):
+    """mm_run_reads_device with per-read lengths above a lane, and the skip-ambiguous reads entry point on the same reads
+    (PackedNSeq, src/lib.rs:451-496): one lane-table launch each, every read == the oracle."""
+    import torch
+    rng = np.random.default_rng(605)
+    n_reads, read_len = 90, 9000
+    stride = read_len + 7
+    span = n_reads * stride + 64
+    a = ACGT[rng.integers(0, 4, size=span)].copy()
+    a[rng.integers(0, span, size=span // 700)] = ord("N")
+    for s0 in rng.integers(0, span - 400, 12):
+        a[s0: s0 + int(rng.integers(1, 300))] = ord("N")
+    packed, amb = oracle.pack_ascii_n(a.tobytes())
+    d_p, d_m = torch.from_numpy(packed).cuda(), torch.from_numpy(amb).cuda()
+    lens_r = rng.integers(0, read_len + 1, size=n_reads)
+    lens_r[:3] = [read_len, 0, 40]
+    d_lens = torch.from_numpy(lens_r.astype(np.int32)).cuda()
+    outr = torch.zeros(n_reads * read_len // 3, dtype=torch.int32, device="cuda")
+    offr = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
+    for (k, w) in ((21, 11), (31, 51), (31, 33)):
+        b = sm.canonical_minimizers(k, w)
+        for use_amb in (False, True):
+            tot = sm.run_reads_device(b, d_p, n_reads, stride, read_len, outr, offr, read_lens=d_lens, d_amb=d_m if use_amb else None)
+            assert gpu.last_lane_table(), (k, w, use_amb)
+            ho = offr.cpu().numpy()
+            hp = outr[:tot].cpu().numpy().view(np.uint32)
+            assert ho[0] == 0 and ho[-1] == tot
+            for r in range(n_reads):
+                m = int(lens_r[r])
+                if use_amb:
+                    want = oracle.run_skip_ambiguous(packed, amb, m, k, w, base_offset=r * stride, amb_offset=r * stride)
+                else:
+                    want = oracle.run(packed, m, k, w, canonical=True, base_offset=r * stride)
+                assert np.array_equal(hp[ho[r]: ho[r + 1]], want), (k, w, use_amb, r, m)
+
+
+def test_lane_table_dense_reads_overflow_their_lists(sm, oracle, gpu):
+    """Low-complexity long reads (homopolymers, a two-letter tandem repeat) emit at every window: the lane lists overflow and
+    the tile is walked again storing directly - in a lane-table launch as in any other."""
+    import torch
+    rng = np.random.default_rng(606)
+    reads = [b"A" * 5000, bytes(ACGT[rng.integers(0, 4, 3000)]), b"AC" * 2500, b"G" * 700, bytes(ACGT[rng.integers(0, 4, 8000)]), b"T" * 12_000]
+    lens = [len(r) for r in reads]
+    packed = np.concatenate([oracle.pack_ascii(b"".join(reads)), np.zeros(64, dtype=np.uint8)])
+    d = torch.from_numpy(packed).cuda()
+    starts = np.zeros(len(lens) + 1, dtype=np.int64)
+    starts[1:] = np.cumsum(lens)
+    for (k, w, canonical) in ((21, 11, False), (21, 11, True), (31, 51, True)):
+        b = sm.Builder(k, w, canonical, 0)
+        flat, ho, _, launches = _run_packed(sm, gpu, b, d, starts, max(lens))
+        assert gpu.last_lane_table() and launches == 1
+        _check_reads(oracle, packed, starts, lens, flat, ho, k, w, canonical, 0)
+
+
+def test_lane_table_long_read_batch(sm, oracle, gpu):
+    """8 000 reads with lengths log-uniform in 1 .. 50 kbp (100 Mbp, the HiFi / ONT regime of VERDICT r5 item 1a at 1/25 of its
+    size): ONE launch, EVERY read element by element against the oracle."""
+    rng = np.random.default_rng(607)
+    lens = np.exp(rng.uniform(np.log(1000), np.log(50_000), 8000)).astype(np.int64)
+    d, host, starts = _packed_reads(sm, lens, 13)
+    b = sm.canonical_minimizers(21, 11)
+    flat, ho, _, launches = _run_packed(sm, gpu, b, d, starts, int(lens.max()))
+    assert gpu.last_lane_table() and launches == 1
+    host = np.concatenate([host, np.zeros(64, dtype=np.uint8)])
+    _check_reads(oracle, host, starts, lens, flat, ho, 21, 11, True, 0)
+    assert len(flat) > 16_000_000
