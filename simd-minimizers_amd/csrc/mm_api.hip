@@ -1395,9 +1395,13 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
         const int policy = lane_table_policy();
         bool lanes = policy == 1;
         if (policy == -1) {
+            // (one lane per read stays while its lists leave a CU four workgroups - 40 KB: 1.3 x density x windows + 8
+            // entries of 516 bytes - and never below the lane table's own lane length)
             mm::SegPlan sp;
             const uint64_t max_nw = read_len >= l ? read_len - l + 1 : 0;
-            lanes = mm::fused_segments_plan(a, span, ws->nblk, &sp) == 0 && max_nw > sp.S;
+            const double dens = plan->mode == MM_OPEN_SYNCMERS ? 1.0 / plan->w : (plan->mode == MM_CLOSED_SYNCMERS ? 2.0 / plan->w : 2.0 / (plan->w + 1.0));
+            const uint64_t one_lane = (uint64_t)((40.0 * 1024.0 / 516.0 - 8.0) / (1.3 * dens));
+            lanes = mm::fused_segments_plan(a, span, ws->nblk, &sp) == 0 && max_nw > (sp.S > one_lane ? sp.S : one_lane);
         }
         int lr = -3;
         if (lanes) {

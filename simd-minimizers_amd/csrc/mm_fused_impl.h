@@ -1028,7 +1028,8 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
         // The W steps of the block.  FE (fast emit): the exec-masked append in inline assembly, legal
         // when every window of the block is inside the range and none is skipped.
         auto steps = [&](auto fe_tag) {
-        constexpr int FEK = (int)decltype(fe_tag)::value;  // 0 flag path, 1 fast emit, 2 fast emit that knows skipped windows
+        constexpr int FEK = (int)decltype(fe_tag)::value;  // 0 flag path, 1 fast emit, 2 fast emit that knows skipped windows,
+                                                           // 3 fast emit with the lane's range check (two-body walks, round 6)
         constexpr bool FE = FEK != 0;
         // the emit of step jj (window i = e0 + jj - W, which starts at element i + 1) with its decided minimum
         auto emit_step = [&](const int jj, uint32_t sel, const unsigned long long valid) {  // valid: kRangeFE walks only
@@ -1107,7 +1108,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                         : "vcc", "memory");
                     prev = sel;
 #endif
-                } else if (MODE == 0 && kRangeFE) {
+                } else if (MODE == 0 && (kRangeFE || FEK == 3)) {
                     // PARTIAL walks over larger windows (the last tile of a sequence or range, reads): the same append
                     // with the lane's range check in it - `valid`: the lanes whose window i is inside, i < rem_valid - instead of the flag
                     // path for the whole tile, which ran 1.7 x as long as a full tile's walk and held up the look-back
@@ -1226,7 +1227,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             // (Lanes past the end of their range read zeros - poly-A, every hash equal, the two minima different at every
             // step: without this test the last tile of a sequence walked 1.4 x as long as a full one and held up the
             // look-back of everything behind it, 24 contigs in one launch 1.82 ms against 1.65 for whole tiles.)
-            if (PARTIAL) {
+            if (PARTIAL && !(kTwoBodies<W> && FEK == 1)) {
                 differ &= __ballot((int)(e0 + (uint32_t)jj - (uint32_t)W) < ctx.rem_valid);
                 if (differ == 0ull) return sel;
             }
@@ -1265,9 +1266,13 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
             bool deferred = false;
             // (range-checked fast emit: the lanes whose window of this step is inside their range; lanes past it read
             // zeros - poly-A, every hash equal - and must not send the lazy vote down its slow path at every step)
+            // (round 6: a two-body walk takes the plain fast emit only in blocks that lie inside EVERY walking lane's range -
+            // `ok` below - so there is nothing to check per step there)
+            constexpr bool kAllValid = PARTIAL && kTwoBodies<W> && FEK == 1;
             const unsigned long long valid =
-                (kRangeFE || (PARTIAL && CANON && kLazyVote) || (PARTIAL && kAmbiFE)) ? __ballot((int)(e - (uint32_t)W) < ctx.rem_valid)
-                                                                                    : ~0ull;
+                (!kAllValid && (kRangeFE || FEK == 3 || (PARTIAL && CANON && kLazyVote) || (PARTIAL && kAmbiFE)))
+                    ? __ballot((int)(e - (uint32_t)W) < ctx.rem_valid)
+                    : ~0ull;
             if (CANON && MM_STAGE_GE(4)) {
                 const uint32_t selr = ring_step<W, true>(ring_r, pr_, kl ^ kmask, j);
                 if (!kLazyVote) {
@@ -1338,8 +1343,15 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
                 ok = __ballot(any != 0) == 0;
             }
             if (PARTIAL) ok = ok && (int)(b * (uint32_t)W) <= ctx.min_rem;  // windows < b * W all valid
+            // (round 6: the blocks of a partial walk that are not inside every lane's range - the last block of a read, of
+            // a lane-table segment, of a range - take the range-checked append instead of the flag path: MM_RANGE_BODY=0 is
+            // the A/B)
+#ifndef MM_RANGE_BODY
+#define MM_RANGE_BODY 1
+#endif
+            constexpr int kNotOk = kAmbiFE ? 2 : ((MM_RANGE_BODY && PARTIAL && MODE == 0 && !SK && !DIRECT) ? 3 : 0);
             if (ok) steps(IntTag<(kCanFast && kTwoBodies<W>) ? 1 : 0>{});
-            else steps(IntTag<kAmbiFE ? 2 : 0>{});  // (skipped windows and the range check in the append itself)
+            else steps(IntTag<kNotOk>{});  // (skipped windows and the range check in the append itself)
         } else {
             steps(IntTag<kAmbiFE ? 2 : 0>{});
         }
