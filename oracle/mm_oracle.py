@@ -236,17 +236,64 @@ def run(packed, n, k, w, hasher=None, canonical=False, mode=MINIMIZERS, flavour=
     return pos[:r].copy()
 
 
-def run_fast(packed, n, k, w, canonical=False, threads=1, hasher=None, base_offset=0, lib_=None):
+def run_fast(packed, n, k, w, canonical=False, threads=1, hasher=None, base_offset=0, lib_=None, cap=None):
     """One-pass (optionally threaded) port used for CPU timing; equals run(..., mode=MINIMIZERS)."""
     if hasher is None:
         hasher = default_hasher(canonical)
-    cap = max(1, n)
+    cap = max(1, n) if cap is None else cap
     pos = np.zeros(cap, dtype=np.uint32)
     r = (lib_ or lib()).mmo_run_fast(_p(packed, C.c_uint8), base_offset, n, k, w, C.byref(hasher),
                                      int(canonical), threads, _p(pos, C.c_uint32), cap)
     if r < 0:
         raise ValueError(f"oracle error {r}")
     return pos[:r].copy()
+
+
+def run_threads(packed, n, k, w, canonical=False, mode=MINIMIZERS, super_kmers=False, threads=None, hasher=None,
+                base_offset=0, chunk_windows=1 << 22):
+    """The whole path over a LONG sequence on all host cores (test infrastructure for the full-size element-by-element
+    checks): minimizer positions without indices through the threaded AVX2 port (run_fast); every other flavour - syncmer
+    modes, super-k-mer indices - through the streaming restatement (run) over window chunks on a thread pool (ctypes
+    releases the GIL), joined with the reference's own rule for its lanes: a chunk's first position is dropped when it
+    equals the previous chunk's last (src/collect.rs:265-271); syncmers have no such rule (src/syncmers.rs:166-169)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or os.cpu_count() or 1
+    if hasher is None:
+        hasher = default_hasher(canonical)
+    l = k + w - 1
+    if n < l:
+        e = np.zeros(0, dtype=np.uint32)
+        return (e, e.copy()) if super_kmers else e
+    if mode == MINIMIZERS and not super_kmers:
+        return run_fast(packed, n, k, w, canonical=canonical, threads=threads, hasher=hasher, base_offset=base_offset)
+    nw = n - l + 1
+    cuts = list(range(0, nw, chunk_windows)) + [nw]
+
+    def piece(i):
+        a, e = cuts[i], cuts[i + 1]
+        r = run(packed, e - a + l - 1, k, w, hasher=hasher, canonical=canonical, mode=mode, base_offset=base_offset + a,
+                super_kmers=super_kmers)
+        if super_kmers:
+            return r[0] + np.uint32(a), r[1] + np.uint32(a)
+        return r + np.uint32(a)
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        parts = list(ex.map(piece, range(len(cuts) - 1)))
+    pos, sks, last = [], [], None
+    for pt in parts:
+        p, q = (pt if super_kmers else (pt, None))
+        if mode == MINIMIZERS and last is not None and len(p) and p[0] == last:
+            p = p[1:]
+            q = q[1:] if q is not None else None
+        if len(p):
+            last = p[-1]
+        pos.append(p)
+        if q is not None:
+            sks.append(q)
+    out = np.concatenate(pos) if pos else np.zeros(0, dtype=np.uint32)
+    if super_kmers:
+        return out, (np.concatenate(sks) if sks else np.zeros(0, dtype=np.uint32))
+    return out
 
 
 def values_u64(packed, length, positions, canonical, base_offset=0) -> np.ndarray:

@@ -265,3 +265,55 @@ def test_lane_table_long_read_batch(sm, oracle, gpu):
     host = np.concatenate([host, np.zeros(64, dtype=np.uint8)])
     _check_reads(oracle, host, starts, lens, flat, ho, 21, 11, True, 0)
     assert len(flat) > 16_000_000
+
+
+# ------------------------------------------------------------------ full-size element-by-element parity
+@pytest.mark.parametrize("k,w,mode,sk", [(21, 11, 0, False), (31, 51, 0, False), (15, 17, 1, False), (21, 11, 0, True)])
+def test_full_size_element_by_element(sm, oracle, gpu, k, w, mode, sk):
+    """BASELINE's full size, EVERY output compared with the oracle (the reference's own test shape: naive == product,
+    src/test.rs:53-110): the 3.1 Gbp headline sequence (G seed 3) - C3 canonical k=21 w=11 (516 688 139 positions), the C4
+    window on one sequence, C5 canonical closed syncmers k=15 w=17, and the headline plan with super-k-mer indices.  The
+    oracle runs on all host cores: the threaded AVX2 port for plain minimizer positions, the streaming restatement over window
+    chunks otherwise (oracle.run_threads)."""
+    import torch
+    n = 3_100_000_000
+    d = sm.generate_device(n, 3)
+    host = d.cpu().numpy()
+    density = 2.0 / (w + 1) if mode == 0 else 2.0 / w
+    cap = int(n * density * 1.15)
+    out = torch.empty(cap, dtype=torch.int32, device="cuda")
+    osk = torch.empty(cap, dtype=torch.int32, device="cuda") if sk else None
+    b = sm.Builder(k, w, True, mode)
+    c = b.run_device(d, n, out, out_sk=osk)
+    assert gpu.last_path() == sm.PATH_FUSED
+    got = out[:c].cpu().numpy().view(np.uint32)
+    gsk = osk[:c].cpu().numpy().view(np.uint32) if sk else None
+    del out, osk, d
+    torch.cuda.empty_cache()
+    want = oracle.run_threads(host, n, k, w, canonical=True, mode=mode, super_kmers=sk)
+    wp = want[0] if sk else want
+    assert c == len(wp), (c, len(wp))
+    assert np.array_equal(got, wp)
+    if sk:
+        assert np.array_equal(gsk, want[1])
+    if (k, w, mode, sk) == (21, 11, 0, False):
+        assert c == 516_688_139  # (DESIGN.md section 3; SURVEY.md section 8's config sizes)
+
+
+def test_config4_contigs_element_by_element(sm, oracle, gpu):
+    """BASELINE config 4's concrete input - the 24 CHM13-like contigs, canonical k=31 w=51, ONE batch launch - with every
+    contig's positions compared one by one with the oracle's threaded port (bench/src/bin/paper.rs:425-431: one run per
+    contig, contig-local positions)."""
+    import torch
+    from simd_minimizers_amd import sharding
+    lens = list(sharding.CHM13_CONTIG_LENGTHS)
+    k, w = 31, 51
+    d = [sm.generate_device(m, sharding.CHM13_CONTIG_SEED0 + i) for i, m in enumerate(lens)]
+    out = torch.empty(int(sum(lens) * 2 / 52 * 1.15), dtype=torch.int32, device="cuda")
+    b = sm.canonical_minimizers(k, w)
+    offs = sm.run_batch_device(b, d, lens, out)
+    assert gpu.last_path() == sm.PATH_FUSED and len(offs) == 25
+    flat = out[: offs[-1]].cpu().numpy().view(np.uint32)
+    for i, m in enumerate(lens):
+        want = oracle.run_threads(d[i].cpu().numpy(), m, k, w, canonical=True)
+        assert np.array_equal(flat[offs[i]: offs[i + 1]], want), i
