@@ -12,6 +12,13 @@
  * Conventions: plain pointers and sizes, no C++/torch types; every function
  * returns 0 (MM_OK) or a negative MM_ERR_* code and never aborts.  The HIP
  * kernels are the only compute path: there is no CPU fallback.
+ *
+ * Current device: an entry point selects its workspace's device (a device
+ * group's entries one after the other) while it runs and RESTORES the calling
+ * thread's current device before it returns - a caller that works with several
+ * GPUs finds hipGetDevice() unchanged after every call (round 6).  Device
+ * pointers passed in must belong to the device the call works on: a
+ * workspace's device, the root entry's device for the gather calls.
  */
 #ifndef SIMD_MINIMIZERS_AMD_H
 #define SIMD_MINIMIZERS_AMD_H

@@ -22,6 +22,42 @@
 
 namespace {
 
+// Every exported function leaves the calling thread's CURRENT DEVICE as it found it (round 6): the entry
+// points select their workspace's device - a device group's entries one after the other - and a caller that works with
+// several devices must not find its own selection changed behind its back.  ApiScope marks an exported function's
+// extent; set_device() notes the device the thread had when the outermost scope first changes it, the outermost scope's
+// end puts it back.  (Threads the library starts itself - one per entry of the host-buffer group calls - have no scope and
+// keep what they select until they end.)
+struct ApiDeviceState {
+    int depth = 0;
+    int saved = -1;
+    bool changed = false;
+};
+thread_local ApiDeviceState t_api_dev;
+struct ApiScope {
+    ApiScope() { ++t_api_dev.depth; }
+    ~ApiScope() {
+        if (--t_api_dev.depth == 0 && t_api_dev.changed) {
+            (void)hipSetDevice(t_api_dev.saved);
+            t_api_dev.changed = false;
+        }
+    }
+    ApiScope(const ApiScope &) = delete;
+    ApiScope &operator=(const ApiScope &) = delete;
+};
+hipError_t set_device(int device) {
+    if (t_api_dev.depth > 0 && !t_api_dev.changed) {
+        int cur = 0;
+        if (hipGetDevice(&cur) == hipSuccess) {
+            t_api_dev.saved = cur;
+            t_api_dev.changed = true;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return hipSetDevice(device);
+}
+
 thread_local std::string g_last_error;
 
 int hip_fail(hipError_t e, const char *what) {
@@ -341,8 +377,9 @@ int judge_run_error(mm_workspace *ws) {
         return MM_ERR_ORDER;
     }
     char buf[96];
-    snprintf(buf, sizeof(buf), code == 2u ? "kernel error 2: dynamic LDS does not lie behind the static LDS"
-                                          : "kernel error 0x%x (bad batch table)", code);
+    snprintf(buf, sizeof(buf), code == 2u   ? "kernel error 2: dynamic LDS does not lie behind the static LDS"
+                               : code == 4u ? "kernel error 4: a skip-ambiguous launch without its LDS landing area"
+                                            : "kernel error 0x%x (bad batch table)", code);
     g_last_error = buf;
     return MM_ERR_HIP;
 }
@@ -352,6 +389,7 @@ int judge_run_error(mm_workspace *ws) {
 extern "C" {
 
 const char *mm_strerror(int code) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     switch (code) {
         case MM_OK: return "ok";
         case MM_ERR_W_ZERO: return "w must be > 0";
@@ -377,12 +415,14 @@ const char *mm_strerror(int code) {
 const char *mm_last_error(void) { return g_last_error.c_str(); }
 
 int mm_device_count(void) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
 
 int mm_default_hasher(mm_hasher_t *out, int canonical) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!out) return MM_ERR_NULL;
     for (int c = 0; c < 4; ++c) {
         out->fw[c] = kNtSeeds[c];
@@ -399,6 +439,7 @@ int mm_default_hasher(mm_hasher_t *out, int canonical) {
 // published idea - "multiplies each character value by a pseudo-random constant" (src/lib.rs:71-72) -
 // in NtHasher's rolling rot-xor form; constant and character offset are this engine's.
 int mm_mul_hasher(mm_hasher_t *out, int canonical) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!out) return MM_ERR_NULL;
     for (uint32_t c = 0; c < 4; ++c) {
         out->fw[c] = (c + 1u) * 0x9E3779B1u;
@@ -414,6 +455,7 @@ int mm_mul_hasher(mm_hasher_t *out, int canonical) {
 // PARITY UNPINNED: the k-mer read as a base-4 number, first base most significant and inverted
 // (anti-lexicographic order), left-aligned in 32 bits; the reverse strand likewise.
 int mm_antilex_hasher(mm_hasher_t *out, uint32_t k, int canonical) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!out) return MM_ERR_NULL;
     if (k == 0) return MM_ERR_K_ZERO;
     const uint32_t sh = (32u - ((2u * k) & 31u)) & 31u;
@@ -430,6 +472,7 @@ int mm_antilex_hasher(mm_hasher_t *out, uint32_t k, int canonical) {
 
 int mm_plan_create(mm_plan_t **out, uint32_t k, uint32_t w, int canonical_windows, mm_mode_t mode,
                    const mm_hasher_t *hasher) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!out) return MM_ERR_NULL;
     *out = nullptr;
     if (k == 0) return MM_ERR_K_ZERO;
@@ -459,11 +502,13 @@ int mm_plan_create(mm_plan_t **out, uint32_t k, uint32_t w, int canonical_window
 void mm_plan_destroy(mm_plan_t *plan) { delete plan; }
 
 uint32_t mm_plan_value_len(const mm_plan_t *plan) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!plan) return 0;
     return plan->mode == MM_MINIMIZERS ? plan->k : plan->k + plan->w - 1;
 }
 
 int mm_workspace_create(mm_workspace_t **out, int device, void *hip_stream) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!out) return MM_ERR_NULL;
     *out = nullptr;
     int n = 0;
@@ -472,7 +517,7 @@ int mm_workspace_create(mm_workspace_t **out, int device, void *hip_stream) {
         return MM_ERR_NO_DEVICE;
     }
     if (device < 0 || device >= n) return MM_ERR_NO_DEVICE;
-    MM_HIP(hipSetDevice(device));
+    MM_HIP(set_device(device));
     mm_workspace *ws = new (std::nothrow) mm_workspace;
     if (!ws) return MM_ERR_ALLOC;
     ws->device = device;
@@ -522,8 +567,9 @@ int mm_workspace_create(mm_workspace_t **out, int device, void *hip_stream) {
 }
 
 void mm_workspace_destroy(mm_workspace_t *ws) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return;
-    hipSetDevice(ws->device);
+    set_device(ws->device);
     if (ws->stream) hipStreamSynchronize(ws->stream);
     for (auto &ev : ws->events) {
         hipEventDestroy(ev.first);
@@ -578,14 +624,16 @@ void mm_workspace_destroy(mm_workspace_t *ws) {
 }
 
 int mm_workspace_sync(mm_workspace_t *ws) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return MM_ERR_NULL;
     MM_HIP(hipStreamSynchronize(ws->stream));
     return MM_OK;
 }
 
 int mm_workspace_check(mm_workspace_t *ws) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     MM_HIP(hipMemcpyAsync(ws->h_total + 2, ws->total + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                           ws->stream));
     MM_HIP(hipStreamSynchronize(ws->stream));
@@ -611,33 +659,38 @@ int mm_workspace_check(mm_workspace_t *ws) {
         return MM_ERR_ORDER;
     }
     char buf[96];
-    snprintf(buf, sizeof(buf), code == 2u ? "kernel error 2: dynamic LDS does not lie behind the static LDS"
-                                          : "kernel error 0x%x (bad batch table)", code);
+    snprintf(buf, sizeof(buf), code == 2u   ? "kernel error 2: dynamic LDS does not lie behind the static LDS"
+                               : code == 4u ? "kernel error 4: a skip-ambiguous launch without its LDS landing area"
+                                            : "kernel error 0x%x (bad batch table)", code);
     g_last_error = buf;
     return MM_ERR_HIP;
 }
 
 int mm_workspace_force_generic(mm_workspace_t *ws, int on) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return MM_ERR_NULL;
     ws->force_generic = on != 0;
     return MM_OK;
 }
 
 int mm_workspace_set_blocks_per_lane(mm_workspace_t *ws, uint32_t nblk) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return MM_ERR_NULL;
     ws->nblk = nblk;
     return MM_OK;
 }
 
 int mm_workspace_enable_timing(mm_workspace_t *ws, int on) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return MM_ERR_NULL;
     ws->timing = on != 0;
     return MM_OK;
 }
 
 int mm_workspace_kernel_time(mm_workspace_t *ws, double *total_ms, uint64_t *launches, int reset) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     int r = collect_timing(ws);
     if (r) return r;
     if (total_ms) *total_ms = ws->total_ms;
@@ -658,6 +711,7 @@ int mm_workspace_last_lane_table(const mm_workspace_t *ws) { return ws && ws->la
 // blocks per lane}.  The CPU test-suite checks that the tiles tile every sequence exactly.
 // the planner's view of a run: everything but the sizes is a placeholder (no device is touched)
 static mm::RunArgs debug_plan_args(uint32_t w, int canonical_windows, int mode, uint64_t n_seqs, uint64_t n_windows0) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     mm::RunArgs a;
     memset(&a.seq, 0, sizeof a.seq);
     memset(&a.ht, 0, sizeof a.ht);
@@ -690,6 +744,7 @@ static mm::RunArgs debug_plan_args(uint32_t w, int canonical_windows, int mode, 
 }
 
 int mm_debug_launch_lds(uint32_t w, int canonical_windows, int mode, uint64_t n_windows, uint64_t *out2) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!out2 || w == 0) return MM_ERR_NULL;
     const mm::RunArgs a = debug_plan_args(w, canonical_windows, mode, 0, n_windows);
     unsigned long long o[2];
@@ -702,6 +757,7 @@ int mm_debug_launch_lds(uint32_t w, int canonical_windows, int mode, uint64_t n_
 int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n_seqs, const uint64_t *n_windows,
                          uint64_t *out7, uint32_t *tile_seq, uint32_t *tile_win0, uint32_t *tile_nblk, uint64_t tile_capacity,
                          uint64_t *n_tiles) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!n_windows || w == 0) return MM_ERR_NULL;
     mm::RunArgs a = debug_plan_args(w, canonical_windows, mode, n_seqs, n_windows[0]);
     if (n_seqs == 0) {
@@ -729,6 +785,7 @@ int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n
 uint64_t mm_fused_overread_bytes(void) { return mm::fused_overread_bytes(); }
 
 int mm_prebuilt_window_sizes(int canonical_windows, int reads_mode, uint32_t *out, int capacity) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     return mm::fused_prebuilt_windows(canonical_windows != 0, reads_mode != 0, out, capacity < 0 ? 0 : capacity);
 }
 
@@ -792,7 +849,7 @@ static int run_device_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, cons
         if (d_out_sk) return MM_ERR_BAD_MODE;
     }
     if (!d_out_pos) capacity = 0;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     const uint64_t l = (uint64_t)plan->k + plan->w - 1;
     const uint64_t n_w = n_bases >= l ? n_bases - l + 1 : 0;
     if (win_end > n_w) win_end = n_w;
@@ -927,6 +984,7 @@ int mm_run_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const void *d
                         uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
                         uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
                         uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (ws) ws->async_unchecked = true;
     return run_device_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin,
                                  win_end, d_out_pos, d_out_sk, capacity, d_count, false);
@@ -1273,9 +1331,10 @@ int mm_run_batch_device(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_se
                         const uint64_t *base_offsets, const uint64_t *n_bases,
                         uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
                         uint64_t *out_offsets) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!plan || !ws || !out_offsets) return MM_ERR_NULL;
     if (n_seqs && (!d_packed || !packed_bytes || !n_bases)) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     {
         int r = run_batch_one_launch(plan, ws, n_seqs, d_packed, packed_bytes, base_offsets, n_bases,
                                      d_out_pos, d_out_sk, capacity, out_offsets);
@@ -1339,7 +1398,7 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
         capacity = 0;
         d_out_sk = nullptr;
     }
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     MM_HIP(hipMemsetAsync(ws->total, 0, 2 * sizeof(unsigned long long), ws->stream));
     if (n_reads == 0 || read_len == 0) {
         MM_HIP(hipMemsetAsync(d_out_offsets, 0, (n_reads + 1) * sizeof(uint64_t), ws->stream));
@@ -1489,6 +1548,7 @@ int mm_run_packed_reads_device_async(const mm_plan_t *plan, mm_workspace_t *ws, 
                                      const uint64_t *d_read_starts, uint64_t total_bases, uint32_t max_read_len,
                                      uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity, uint64_t *d_out_offsets,
                                      uint64_t *d_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!d_read_starts && n_reads) return MM_ERR_NULL;
     if (ws) ws->async_unchecked = true;
     return run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, 0, max_read_len, nullptr, d_out_pos,
@@ -1499,6 +1559,7 @@ int mm_run_packed_reads_device(const mm_plan_t *plan, mm_workspace_t *ws, const 
                                uint64_t base_offset, uint64_t n_reads, const uint64_t *d_read_starts, uint64_t total_bases,
                                uint32_t max_read_len, uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
                                uint64_t *d_out_offsets, uint64_t *out_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws || (!d_read_starts && n_reads)) return MM_ERR_NULL;
     for (int attempt = 0; attempt < 2; ++attempt) {
         int r = run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, 0, max_read_len, nullptr,
@@ -1520,6 +1581,7 @@ int mm_run_reads_device_async(const mm_plan_t *plan, mm_workspace_t *ws, const v
                               uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
                               uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
                               uint64_t *d_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (ws) ws->async_unchecked = true;
     return run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride,
                                 read_len, d_read_lens, d_out_pos, capacity, d_out_offsets, d_count);
@@ -1553,6 +1615,7 @@ int mm_run_reads_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d
                         uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
                         uint32_t *d_out_pos, uint64_t capacity, uint64_t *d_out_offsets,
                         uint64_t *out_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     return run_reads_sync(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride, read_len,
                           d_read_lens, d_out_pos, capacity, d_out_offsets, out_count, nullptr);
 }
@@ -1562,6 +1625,7 @@ int mm_run_reads_superkmers_device_async(const mm_plan_t *plan, mm_workspace_t *
                                          uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
                                          uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
                                          uint64_t *d_out_offsets, uint64_t *d_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (ws) ws->async_unchecked = true;
     if (!d_out_sk) return MM_ERR_NULL;
     return run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride,
@@ -1574,6 +1638,7 @@ int mm_run_reads_superkmers_device(const mm_plan_t *plan, mm_workspace_t *ws, co
                                    uint32_t read_stride, uint32_t read_len, const uint32_t *d_read_lens,
                                    uint32_t *d_out_pos, uint32_t *d_out_sk, uint64_t capacity,
                                    uint64_t *d_out_offsets, uint64_t *out_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!d_out_sk) return MM_ERR_NULL;
     return run_reads_sync(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride, read_len,
                           d_read_lens, d_out_pos, capacity, d_out_offsets, out_count, nullptr, d_out_sk);
@@ -1586,6 +1651,7 @@ int mm_run_reads_skip_ambiguous_device_async(const mm_plan_t *plan, mm_workspace
                                              uint32_t read_len, const uint32_t *d_read_lens,
                                              uint32_t *d_out_pos, uint64_t capacity,
                                              uint64_t *d_out_offsets, uint64_t *d_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (ws) ws->async_unchecked = true;
     const AmbArgs amb{d_amb, amb_bytes, amb_offset};
     return run_reads_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride,
@@ -1598,6 +1664,7 @@ int mm_run_reads_skip_ambiguous_device(const mm_plan_t *plan, mm_workspace_t *ws
                                        uint32_t read_stride, uint32_t read_len,
                                        const uint32_t *d_read_lens, uint32_t *d_out_pos,
                                        uint64_t capacity, uint64_t *d_out_offsets, uint64_t *out_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     const AmbArgs amb{d_amb, amb_bytes, amb_offset};
     return run_reads_sync(plan, ws, d_packed, packed_bytes, base_offset, n_reads, read_stride, read_len,
                           d_read_lens, d_out_pos, capacity, d_out_offsets, out_count, &amb);
@@ -1609,6 +1676,7 @@ int mm_run_skip_ambiguous_device_async(const mm_plan_t *plan, mm_workspace_t *ws
                                        uint64_t amb_bytes, uint64_t amb_offset, uint64_t n_bases,
                                        uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
                                        uint64_t capacity, uint64_t *d_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (ws) ws->async_unchecked = true;
     const AmbArgs amb{d_amb, amb_bytes, amb_offset};
     return run_device_async_impl(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin,
@@ -1658,6 +1726,7 @@ int mm_run_skip_ambiguous_device(const mm_plan_t *plan, mm_workspace_t *ws, cons
                                  uint64_t amb_bytes, uint64_t amb_offset, uint64_t n_bases,
                                  uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos,
                                  uint64_t capacity, uint64_t *out_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     const AmbArgs amb{d_amb, amb_bytes, amb_offset};
     return run_device_sync(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin, win_end,
                            d_out_pos, nullptr, capacity, out_count, &amb);
@@ -1667,6 +1736,7 @@ int mm_run_device(const mm_plan_t *plan, mm_workspace_t *ws, const void *d_packe
                   uint64_t packed_bytes, uint64_t base_offset, uint64_t n_bases,
                   uint64_t win_begin, uint64_t win_end, uint32_t *d_out_pos, uint32_t *d_out_sk,
                   uint64_t capacity, uint64_t *out_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     return run_device_sync(plan, ws, d_packed, packed_bytes, base_offset, n_bases, win_begin, win_end,
                            d_out_pos, d_out_sk, capacity, out_count, nullptr);
 }
@@ -1882,6 +1952,11 @@ static int run_host_pipelined(const mm_plan_t *plan, mm_workspace_t *ws, const u
     uint64_t done_total = 0;
     bool over = false, broken = false;
     uint32_t idle = 0;
+    // (the loop queues uploads, kernels and copy kernels that store into the CALLER's buffers; whatever
+    // ends it - a refused launch, a failed query or copy - the call must not return while any of that is still in flight,
+    // or a caller that frees its buffers on the error meets a device that still reads and writes them.  The loop's own
+    // result is therefore collected first, the three streams are waited for whatever it says, then it is judged.)
+    const int loop_rc = [&]() -> int {
     while (next_out < n_chunks && !broken) {
         bool progress = false;
         while (next_in < n_chunks && (lim_in == 0 || next_in - in_retired < lim_in)) {
@@ -1944,8 +2019,20 @@ static int run_host_pipelined(const mm_plan_t *plan, mm_workspace_t *ws, const u
         }
         if (!progress) __builtin_ia32_pause();
     }
-    MM_HIP(hipStreamSynchronize(ws->stream));
-    MM_HIP(hipStreamSynchronize(ws->copy_out));
+    return MM_OK;
+    }();
+    {
+        const hipError_t e0 = hipStreamSynchronize(ws->stream), e1 = hipStreamSynchronize(ws->copy_in),
+                         e2 = hipStreamSynchronize(ws->copy_out);
+        if (loop_rc) {
+            (void)hipGetLastError();
+            (void)judge_run_error(ws);  // (consumes the error words a chunk's kernel may have raised: the next call starts clean)
+            return loop_rc;
+        }
+        if (e0 != hipSuccess) return hip_fail(e0, "hipStreamSynchronize");
+        if (e1 != hipSuccess) return hip_fail(e1, "hipStreamSynchronize");
+        if (e2 != hipSuccess) return hip_fail(e2, "hipStreamSynchronize");
+    }
     if (tracing) {
         fprintf(stderr, "[mm pipe] %llu chunks, out=%d in=%d, in flight %llu / %llu, call %.2f ms\n", (unsigned long long)n_chunks,
                 out_mode, in_mode, (unsigned long long)lim_in, (unsigned long long)lim_out, now_ms());
@@ -1965,6 +2052,7 @@ static int run_host_pipelined(const mm_plan_t *plan, mm_workspace_t *ws, const u
 }
 
 int mm_host_alloc(void **out, uint64_t bytes) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!out) return MM_ERR_NULL;
     *out = nullptr;
     if (bytes == 0) return MM_OK;
@@ -1979,6 +2067,7 @@ int mm_host_alloc(void **out, uint64_t bytes) {
 }
 
 void mm_host_free(void *p) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (p) hipHostFree(p);
 }
 
@@ -2032,10 +2121,11 @@ static int run_host_small(const mm_plan_t *plan, mm_workspace_t *ws, const uint8
 int mm_run_host(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed,
                 uint64_t base_offset, uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk,
                 uint64_t capacity, uint64_t *out_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!plan || !ws) return MM_ERR_NULL;
     if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     if (out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     const uint64_t bytes = (base_offset + n_bases + 3) / 4;
     if (bytes && !packed) return MM_ERR_NULL;
     {
@@ -2062,11 +2152,12 @@ int mm_run_host(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed
 int mm_run_packed_reads_host(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *packed, uint64_t n_reads,
                              const uint64_t *read_starts, uint32_t max_read_len, uint32_t *out_pos, uint32_t *out_sk,
                              uint64_t capacity, uint64_t *out_offsets, uint64_t *out_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!plan || !ws || !out_offsets) return MM_ERR_NULL;
     if (n_reads && (!read_starts || !packed)) return MM_ERR_NULL;
     if (out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;
     if (out_count) *out_count = 0;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     const uint64_t total_bases = n_reads ? read_starts[n_reads] : 0;
     for (uint64_t r = 0; r < n_reads; ++r)
         if (read_starts[r] > read_starts[r + 1]) return MM_ERR_CAPACITY;  // (starts must not decrease)
@@ -2104,10 +2195,11 @@ int mm_run_packed_reads_host(const mm_plan_t *plan, mm_workspace_t *ws, const ui
 int mm_run_host_ascii(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *ascii,
                       uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk, uint64_t capacity,
                       uint64_t *out_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!plan || !ws) return MM_ERR_NULL;
     if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     if (out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     const uint64_t bytes = (n_bases + 3) / 4;
     uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
     int r = grow(din, ws->d_in_bytes, bytes + 16, 1);
@@ -2130,10 +2222,11 @@ int mm_run_skip_ambiguous_host(const mm_plan_t *plan, mm_workspace_t *ws, const 
                                uint64_t base_offset, const uint8_t *amb, uint64_t amb_offset,
                                uint64_t n_bases, uint32_t *out_pos, uint64_t capacity,
                                uint64_t *out_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!plan || !ws) return MM_ERR_NULL;
     if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     if (!plan->canonical_windows) return MM_ERR_HASHER_NOT_CANONICAL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     const uint64_t bytes = (base_offset + n_bases + 3) / 4;
     const uint64_t abytes = (amb_offset + n_bases + 7) / 8;
     uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
@@ -2157,10 +2250,11 @@ int mm_run_skip_ambiguous_host(const mm_plan_t *plan, mm_workspace_t *ws, const 
 int mm_run_skip_ambiguous_host_ascii(const mm_plan_t *plan, mm_workspace_t *ws, const uint8_t *ascii,
                                      uint64_t n_bases, uint32_t *out_pos, uint64_t capacity,
                                      uint64_t *out_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!plan || !ws) return MM_ERR_NULL;
     if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     if (!plan->canonical_windows) return MM_ERR_HASHER_NOT_CANONICAL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     const uint64_t bytes = (n_bases + 3) / 4, abytes = (n_bases + 7) / 8;
     uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
     int r = grow(din, ws->d_in_bytes, bytes + 16, 1);
@@ -2187,10 +2281,11 @@ int mm_run_skip_ambiguous_host_ascii(const mm_plan_t *plan, mm_workspace_t *ws, 
 
 int mm_pack_ascii_n_device_async(mm_workspace_t *ws, const uint8_t *d_ascii, uint64_t n_bases,
                                  uint8_t *d_packed, uint8_t *d_amb) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return MM_ERR_NULL;
     if (n_bases == 0) return MM_OK;
     if (!d_ascii || !d_packed || !d_amb) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     if (mm::launch_pack_ascii_n(d_ascii, n_bases, d_packed, d_amb, ws->stream))
         return hip_fail(hipGetLastError(), "pack_ascii_n");
     return MM_OK;
@@ -2200,11 +2295,12 @@ int mm_values_u64_device_async(mm_workspace_t *ws, const void *d_packed, uint64_
                                uint64_t base_offset, uint64_t n_bases, uint32_t len,
                                int canonical, const uint32_t *d_pos, uint64_t n_pos,
                                uint64_t *d_values) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return MM_ERR_NULL;
     if (len == 0 || len > 32) return MM_ERR_VALUE_LEN;
     if (n_pos == 0) return MM_OK;
     if (!d_packed || !d_pos || !d_values) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     mm::SeqView v;
     int r = make_view(d_packed, packed_bytes, base_offset, n_bases, &v);
     if (r) return r;
@@ -2217,11 +2313,12 @@ int mm_values_u64_device_async(mm_workspace_t *ws, const void *d_packed, uint64_
 int mm_values_u64_host(mm_workspace_t *ws, const uint8_t *packed, uint64_t base_offset,
                        uint64_t n_bases, uint32_t len, int canonical, const uint32_t *pos,
                        uint64_t n_pos, uint64_t *values) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return MM_ERR_NULL;
     if (len == 0 || len > 32) return MM_ERR_VALUE_LEN;
     if (n_pos == 0) return MM_OK;
     if (!packed || !pos || !values) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     const uint64_t bytes = (base_offset + n_bases + 3) / 4;
     uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
     int r = grow(din, ws->d_in_bytes, bytes + 16, 1);
@@ -2245,11 +2342,12 @@ int mm_values_u128_device_async(mm_workspace_t *ws, const void *d_packed, uint64
                                 uint64_t base_offset, uint64_t n_bases, uint32_t len,
                                 int canonical, const uint32_t *d_pos, uint64_t n_pos,
                                 uint64_t *d_values) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return MM_ERR_NULL;
     if (len == 0 || len > 64) return MM_ERR_VALUE_LEN;
     if (n_pos == 0) return MM_OK;
     if (!d_packed || !d_pos || !d_values) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     mm::SeqView v;
     int r = make_view(d_packed, packed_bytes, base_offset, n_bases, &v);
     if (r) return r;
@@ -2262,11 +2360,12 @@ int mm_values_u128_device_async(mm_workspace_t *ws, const void *d_packed, uint64
 int mm_values_u128_host(mm_workspace_t *ws, const uint8_t *packed, uint64_t base_offset,
                         uint64_t n_bases, uint32_t len, int canonical, const uint32_t *pos,
                         uint64_t n_pos, uint64_t *values) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return MM_ERR_NULL;
     if (len == 0 || len > 64) return MM_ERR_VALUE_LEN;
     if (n_pos == 0) return MM_OK;
     if (!packed || !pos || !values) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     const uint64_t bytes = (base_offset + n_bases + 3) / 4;
     uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
     int r = grow(din, ws->d_in_bytes, bytes + 32, 1);
@@ -2288,10 +2387,11 @@ int mm_values_u128_host(mm_workspace_t *ws, const uint8_t *packed, uint64_t base
 
 int mm_pack_ascii_device_async(mm_workspace_t *ws, const uint8_t *d_ascii, uint64_t n_bases,
                                uint8_t *d_packed) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return MM_ERR_NULL;
     if (n_bases == 0) return MM_OK;
     if (!d_ascii || !d_packed) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     if (mm::launch_pack_ascii(d_ascii, n_bases, d_packed, ws->stream))
         return hip_fail(hipGetLastError(), "pack_ascii");
     return MM_OK;
@@ -2318,11 +2418,12 @@ static int fasta_packer_choice(const mm_workspace_t *ws) {
 int mm_fasta_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes,
                                uint8_t *d_packed, uint64_t packed_capacity_bytes, uint64_t *d_rec_base,
                                uint64_t *d_rec_text_pos, uint64_t max_records, uint64_t *d_counts) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     // (the synchronous wrapper below checks the error word itself; a direct asynchronous caller asks mm_workspace_check)
     if (!ws || !d_counts || !d_rec_base) return MM_ERR_NULL;
     if (n_bytes >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     if (reinterpret_cast<uintptr_t>(d_packed) % 4 != 0) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     if (n_bytes == 0) {
         MM_HIP(hipMemsetAsync(d_counts, 0, 2 * sizeof(uint64_t), ws->stream));
         MM_HIP(hipMemsetAsync(d_rec_base, 0, sizeof(uint64_t), ws->stream));
@@ -2377,7 +2478,7 @@ static int fastq_pack_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t 
     if (!ws || !d_counts || !d_rec_base) return MM_ERR_NULL;
     if (n_bytes >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     if (reinterpret_cast<uintptr_t>(d_packed) % 4 != 0) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     if (n_bytes == 0) {
         MM_HIP(hipMemsetAsync(d_counts, 0, 2 * sizeof(uint64_t), ws->stream));
         MM_HIP(hipMemsetAsync(d_rec_base, 0, sizeof(uint64_t), ws->stream));
@@ -2399,6 +2500,7 @@ static int fastq_pack_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t 
 int mm_fastq_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
                                uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
                                uint64_t max_records, uint64_t *d_counts) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     return fastq_pack_async(ws, d_text, n_bytes, d_packed, packed_capacity_bytes, d_rec_base, d_rec_text_pos, max_records,
                             d_counts, 0);
 }
@@ -2406,6 +2508,7 @@ int mm_fastq_pack_device_async(mm_workspace_t *ws, const uint8_t *d_text, uint64
 int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_bytes, uint8_t *d_packed,
                          uint64_t packed_capacity_bytes, uint64_t *d_rec_base, uint64_t *d_rec_text_pos,
                          uint64_t max_records, uint64_t *d_counts, uint64_t *out_counts) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!out_counts || !ws) return MM_ERR_NULL;  // (a null workspace used to reach the error branch below)
     // whatever way this call ends, the per-call three-pass flag does not outlive it
     struct ClearOnce {
@@ -2416,7 +2519,7 @@ int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_b
         // FASTQ starts with '@' where FASTA starts with '>' (needletail tells them apart the same way)
         unsigned char head[256];
         const size_t nh = n_bytes < sizeof head ? (size_t)n_bytes : sizeof head;
-        MM_HIP(hipSetDevice(ws->device));
+        MM_HIP(set_device(ws->device));
         MM_HIP(hipMemcpyAsync(head, d_text, nh, hipMemcpyDeviceToHost, ws->stream));
         MM_HIP(hipStreamSynchronize(ws->stream));
         size_t i = 0;
@@ -2460,8 +2563,9 @@ int mm_fasta_pack_device(mm_workspace_t *ws, const uint8_t *d_text, uint64_t n_b
 static const uint32_t kProbeGroups = 16;
 
 int mm_clock_probe_begin(mm_workspace_t *ws, uint64_t duration_us) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     if (!ws->probe_stream) {
         MM_HIP(hipStreamCreateWithFlags(&ws->probe_stream, hipStreamNonBlocking));
         MM_HIP(hipMalloc(reinterpret_cast<void **>(&ws->probe_out), kProbeGroups * 2 * sizeof(unsigned long long)));
@@ -2473,8 +2577,9 @@ int mm_clock_probe_begin(mm_workspace_t *ws, uint64_t duration_us) {
 }
 
 int mm_clock_probe_end(mm_workspace_t *ws, double *ghz) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws || !ghz || !ws->probe_stream) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     unsigned long long h[kProbeGroups * 2];
     MM_HIP(hipMemcpyAsync(h, ws->probe_out, sizeof h, hipMemcpyDeviceToHost, ws->probe_stream));
     MM_HIP(hipStreamSynchronize(ws->probe_stream));
@@ -2493,8 +2598,9 @@ int mm_clock_probe_end(mm_workspace_t *ws, double *ghz) {
 // 57.6 + 57.1 GB/s on the boxes of round 5).  out_GBps[0] = host -> device alone, [1] = device -> host alone, [2] = the sum
 // of both while they run together.  host_in / host_out: `bytes` each, page-locked for meaningful figures.
 int mm_link_probe(mm_workspace_t *ws, const void *host_in, void *host_out, uint64_t bytes, double *out_GBps) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws || !host_in || !host_out || !out_GBps || bytes == 0) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     void *d_a = nullptr, *d_b = nullptr;
     hipStream_t s1 = nullptr, s2 = nullptr;
     int rc = MM_OK;
@@ -2589,10 +2695,11 @@ int mm_link_probe(mm_workspace_t *ws, const void *host_in, void *host_out, uint6
 
 int mm_generate_device_async(mm_workspace_t *ws, uint64_t seed, uint64_t first_base,
                              uint64_t n_bases, uint8_t *d_packed) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!ws) return MM_ERR_NULL;
     if (n_bases == 0) return MM_OK;
     if (!d_packed) return MM_ERR_NULL;
-    MM_HIP(hipSetDevice(ws->device));
+    MM_HIP(set_device(ws->device));
     if (mm::launch_generate(seed, first_base, n_bases, d_packed, ws->stream))
         return hip_fail(hipGetLastError(), "generate");
     return MM_OK;
@@ -2657,6 +2764,7 @@ int copy_shard_out(mm_workspace *ws, uint64_t from, uint64_t n, uint32_t *out_po
 }  // namespace
 
 int mm_device_group_create(mm_device_group_t **out, const int *devices, int n_devices) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!out) return MM_ERR_NULL;
     *out = nullptr;
     if (!devices || n_devices <= 0) return MM_ERR_NULL;
@@ -2681,7 +2789,7 @@ int mm_device_group_create(mm_device_group_t **out, const int *devices, int n_de
             if (g->ws[i]->device != g->ws[j]->device) {
                 int can = 0;
                 if (hipDeviceCanAccessPeer(&can, g->ws[i]->device, g->ws[j]->device) == hipSuccess && can &&
-                    hipSetDevice(g->ws[i]->device) == hipSuccess)
+                    set_device(g->ws[i]->device) == hipSuccess)
                     (void)hipDeviceEnablePeerAccess(g->ws[j]->device, 0);
                 (void)hipGetLastError();
             }
@@ -2692,7 +2800,7 @@ int mm_device_group_create(mm_device_group_t **out, const int *devices, int n_de
 static void group_drop_sequence(mm_device_group *g) {
     for (size_t i = 0; i < g->d_seq.size(); ++i)
         if (g->d_seq[i] && g->own_seq[i]) {
-            hipSetDevice(g->ws[i]->device);
+            set_device(g->ws[i]->device);
             hipFree(g->d_seq[i]);
         }
     g->d_seq.assign(g->ws.size(), nullptr);
@@ -2703,9 +2811,10 @@ static void group_drop_sequence(mm_device_group *g) {
 }
 
 void mm_device_group_destroy(mm_device_group_t *g) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!g) return;
     for (size_t i = 0; i < g->shard.size() && i < g->ws.size(); ++i) {
-        hipSetDevice(g->ws[i]->device);
+        set_device(g->ws[i]->device);
         hipStreamSynchronize(g->ws[i]->stream);
         if (g->shard[i].d_pos) hipFree(g->shard[i].d_pos);
         if (g->shard[i].d_sk) hipFree(g->shard[i].d_sk);
@@ -2713,7 +2822,7 @@ void mm_device_group_destroy(mm_device_group_t *g) {
     if (!g->d_seq.empty()) group_drop_sequence(g);
     for (size_t i = 0; i < g->batch.size() && i < g->ws.size(); ++i)
         if (g->batch[i].d_buf) {
-            hipSetDevice(g->ws[i]->device);
+            set_device(g->ws[i]->device);
             hipFree(g->batch[i].d_buf);
         }
     for (mm_workspace_t *ws : g->ws) mm_workspace_destroy(ws);
@@ -2721,11 +2830,12 @@ void mm_device_group_destroy(mm_device_group_t *g) {
 }
 
 int mm_device_group_upload(mm_device_group_t *g, const uint8_t *packed, uint64_t packed_bytes) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!g || g->ws.empty() || !packed || packed_bytes == 0) return MM_ERR_NULL;
     group_drop_sequence(g);
     // (+ 64 bytes of zeros: the walk's loads run a few dwords ahead of the last base)
     for (size_t i = 0; i < g->ws.size(); ++i) {
-        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(set_device(g->ws[i]->device));
         void *p = nullptr;
         hipError_t e = hipMalloc(&p, packed_bytes + 64);
         if (e != hipSuccess) {
@@ -2740,7 +2850,7 @@ int mm_device_group_upload(mm_device_group_t *g, const uint8_t *packed, uint64_t
         MM_HIP(hipMemcpyAsync(p, packed, packed_bytes, hipMemcpyHostToDevice, g->ws[i]->stream));
     }
     for (size_t i = 0; i < g->ws.size(); ++i) {
-        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(set_device(g->ws[i]->device));
         MM_HIP(hipStreamSynchronize(g->ws[i]->stream));
     }
     g->seq_bytes = packed_bytes;
@@ -2765,12 +2875,13 @@ static void resident_range(uint64_t base_offset, uint64_t n_bases, uint64_t N, u
 
 int mm_device_group_upload_range(mm_device_group_t *g, const uint8_t *packed, uint64_t packed_bytes, uint64_t base_offset,
                                  uint64_t n_bases) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!g || g->ws.empty() || !packed || packed_bytes == 0) return MM_ERR_NULL;
     if ((base_offset + n_bases + 3) / 4 > packed_bytes) return MM_ERR_CAPACITY;
     group_drop_sequence(g);
     const uint64_t N = g->ws.size();
     for (uint64_t i = 0; i < N; ++i) {
-        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(set_device(g->ws[i]->device));
         void *p = nullptr;
         // (the whole extent is ALLOCATED on every device so that offsets stay absolute; only the entry's range crosses
         // the host link.  What is not uploaded is filled with a pattern: a run can never depend on stale memory.)
@@ -2793,7 +2904,7 @@ int mm_device_group_upload_range(mm_device_group_t *g, const uint8_t *packed, ui
         MM_HIP(hipMemcpyAsync(d + lo, packed + lo, hi - lo, hipMemcpyHostToDevice, g->ws[i]->stream));
     }
     for (uint64_t i = 0; i < N; ++i) {
-        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(set_device(g->ws[i]->device));
         MM_HIP(hipStreamSynchronize(g->ws[i]->stream));
     }
     g->seq_bytes = packed_bytes;
@@ -2801,6 +2912,7 @@ int mm_device_group_upload_range(mm_device_group_t *g, const uint8_t *packed, ui
 }
 
 int mm_device_group_adopt(mm_device_group_t *g, const void *const *d_packed, uint64_t packed_bytes) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!g || g->ws.empty() || !d_packed || packed_bytes == 0) return MM_ERR_NULL;
     for (size_t i = 0; i < g->ws.size(); ++i)
         if (!d_packed[i]) return MM_ERR_NULL;
@@ -2816,6 +2928,7 @@ int mm_device_group_size(const mm_device_group_t *g) { return g ? (int)g->ws.siz
 int mm_run_sharded_host(const mm_plan_t *plan, mm_device_group_t *g, const uint8_t *packed, uint64_t base_offset,
                         uint64_t n_bases, uint32_t *out_pos, uint32_t *out_sk, uint64_t capacity,
                         uint64_t *out_count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!plan || !g || g->ws.empty()) return MM_ERR_NULL;
     if (n_bases >= (1ull << 32)) return MM_ERR_LEN_TOO_LARGE;
     if (out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;
@@ -2840,7 +2953,7 @@ int mm_run_sharded_host(const mm_plan_t *plan, mm_device_group_t *g, const uint8
             r.rc = rc;
             r.err = g_last_error;
         };
-        if (hipSetDevice(ws->device) != hipSuccess) return fail(MM_ERR_HIP);
+        if (set_device(ws->device) != hipSuccess) return fail(MM_ERR_HIP);
         uint8_t *din = reinterpret_cast<uint8_t *>(ws->d_in);
         int rc = grow(din, ws->d_in_bytes, bytes + 16, 1);  // (the whole extent, so that positions stay absolute;
         ws->d_in = din;                                     // only this shard's slice of it is filled)
@@ -2890,7 +3003,7 @@ int mm_run_sharded_host(const mm_plan_t *plan, mm_device_group_t *g, const uint8
     auto phase2 = [&](uint64_t i) {
         mm_workspace *ws = g->ws[i];
         if (res[i].count <= drop[i]) return;
-        if (hipSetDevice(ws->device) != hipSuccess ||
+        if (set_device(ws->device) != hipSuccess ||
             copy_shard_out(ws, drop[i], res[i].count - drop[i], out_pos, out_sk, off[i]) != MM_OK ||
             hipStreamSynchronize(ws->stream) != hipSuccess) {
             res[i].rc = MM_ERR_HIP;
@@ -2914,6 +3027,7 @@ int mm_run_sharded_host(const mm_plan_t *plan, mm_device_group_t *g, const uint8
 // ---- device-resident shards: one asynchronous launch per entry from the calling thread, results stay on the devices
 int mm_run_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, uint64_t base_offset, uint64_t n_bases,
                           int want_superkmers, uint64_t *counts, uint64_t *total) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!plan || !g || g->ws.empty()) return MM_ERR_NULL;
     if (g->seq_bytes == 0) {
         g_last_error = "mm_run_sharded_device: no resident sequence (mm_device_group_upload / _adopt first)";
@@ -2941,7 +3055,7 @@ int mm_run_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, uint64_t 
     auto issue = [&](uint64_t i) -> int {
         mm_device_group::Shard &s = g->shard[i];
         mm_workspace *ws = g->ws[i];
-        MM_HIP(hipSetDevice(ws->device));
+        MM_HIP(set_device(ws->device));
         bool hw = false;
         ws->h_total[0] = 0;
         ws->h_total[1] = 0;
@@ -2982,7 +3096,7 @@ int mm_run_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, uint64_t 
         const uint64_t nw = s.win_end - s.win_begin;
         uint64_t want = (uint64_t)(dens * 1.15 * (double)nw) + 4096;
         if (want > nw) want = nw;
-        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(set_device(g->ws[i]->device));
         int r = grow_shard(i, want);
         if (r) return r;
         r = issue(i);
@@ -2994,7 +3108,7 @@ int mm_run_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, uint64_t 
         mm_device_group::Shard &s = g->shard[i];
         mm_workspace *ws = g->ws[i];
         for (int attempt = 0; pending[i] && attempt < 4; ++attempt) {
-            MM_HIP(hipSetDevice(ws->device));
+            MM_HIP(set_device(ws->device));
             MM_HIP(hipStreamSynchronize(ws->stream));
             pending[i] = 0;
             const int je = judge_run_error(ws);
@@ -3025,6 +3139,7 @@ int mm_run_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, uint64_t 
 
 int mm_device_group_result(const mm_device_group_t *g, int entry, uint32_t **d_pos, uint32_t **d_sk, uint64_t *count,
                            uint64_t *win_begin, uint64_t *win_end) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!g || entry < 0 || (size_t)entry >= g->shard.size() || !g->ran) return MM_ERR_NULL;
     const mm_device_group::Shard &s = g->shard[(size_t)entry];
     if (d_pos) *d_pos = s.d_pos;
@@ -3037,6 +3152,7 @@ int mm_device_group_result(const mm_device_group_t *g, int entry, uint32_t **d_p
 
 int mm_device_group_gather(mm_device_group_t *g, int root, uint32_t *d_dst_pos, uint32_t *d_dst_sk, uint64_t capacity,
                            uint64_t *total) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!g || root < 0 || (size_t)root >= g->ws.size() || !g->ran) return MM_ERR_NULL;
     uint64_t sum = 0;
     for (const mm_device_group::Shard &s : g->shard) sum += s.count;
@@ -3051,7 +3167,7 @@ int mm_device_group_gather(mm_device_group_t *g, int root, uint32_t *d_dst_pos, 
         if (s.count) {
             if (d_dst_sk && !s.has_sk) return MM_ERR_BAD_MODE;
             // every copy on its SOURCE entry's stream: all of them in flight together, one link each
-            MM_HIP(hipSetDevice(ws->device));
+            MM_HIP(set_device(ws->device));
             MM_HIP(hipMemcpyPeerAsync(d_dst_pos + off, root_dev, s.d_pos, ws->device, s.count * sizeof(uint32_t), ws->stream));
             if (d_dst_sk)
                 MM_HIP(hipMemcpyPeerAsync(d_dst_sk + off, root_dev, s.d_sk, ws->device, s.count * sizeof(uint32_t), ws->stream));
@@ -3059,7 +3175,7 @@ int mm_device_group_gather(mm_device_group_t *g, int root, uint32_t *d_dst_pos, 
         off += s.count;
     }
     for (size_t i = 0; i < g->ws.size(); ++i) {
-        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(set_device(g->ws[i]->device));
         MM_HIP(hipStreamSynchronize(g->ws[i]->stream));
     }
     return MM_OK;
@@ -3068,6 +3184,7 @@ int mm_device_group_gather(mm_device_group_t *g, int root, uint32_t *d_dst_pos, 
 // ---- device-resident batches: independent sequences (contigs), each on ONE device of the group
 int mm_device_group_upload_batch(mm_device_group_t *g, uint64_t n_seqs, const uint8_t *const *packed,
                                  const uint64_t *packed_bytes) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!g || g->ws.empty() || (n_seqs && (!packed || !packed_bytes))) return MM_ERR_NULL;
     const uint64_t N = g->ws.size();
     // greedy placement, longest sequence first onto the least loaded entry (sharding.assign_contigs)
@@ -3104,7 +3221,7 @@ int mm_device_group_upload_batch(mm_device_group_t *g, uint64_t n_seqs, const ui
             b.nbytes.push_back(packed_bytes[s]);
             total += (packed_bytes[s] + 64 + 15) & ~15ull;  // (the walk's loads run a few dwords past the last base)
         }
-        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(set_device(g->ws[i]->device));
         int r = grow(b.d_buf, b.buf_bytes, total + 16, 1);
         if (r) return r;
         MM_HIP(hipMemsetAsync(b.d_buf, 0, b.buf_bytes, g->ws[i]->stream));
@@ -3115,7 +3232,7 @@ int mm_device_group_upload_batch(mm_device_group_t *g, uint64_t n_seqs, const ui
             }
     }
     for (uint64_t i = 0; i < N; ++i) {
-        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(set_device(g->ws[i]->device));
         MM_HIP(hipStreamSynchronize(g->ws[i]->stream));
     }
     return MM_OK;
@@ -3123,6 +3240,7 @@ int mm_device_group_upload_batch(mm_device_group_t *g, uint64_t n_seqs, const ui
 
 int mm_run_batch_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, const uint64_t *base_offsets,
                                 const uint64_t *n_bases, int want_superkmers, uint64_t *out_counts, uint64_t *total) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!plan || !g || g->ws.empty() || g->batch.size() != g->ws.size() || !n_bases) return MM_ERR_NULL;
     if (want_superkmers && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;
     const uint64_t N = g->ws.size(), n_seqs = g->seq_entry.size();
@@ -3144,6 +3262,22 @@ int mm_run_batch_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, con
     std::vector<Entry> ent(N);
     g->ran = false;  // (the result buffers now hold a batch: mm_device_group_result / _gather must not read them as shards)
     g->batch_ran = false;
+    // (an error on a later entry must not leave the earlier entries' launches - and their uploads out of `ent`'s
+    // host vectors - in flight when `ent` is destroyed: every issued entry is waited for and its error words consumed
+    // before the first error is returned)
+    auto drain = [&](int code) -> int {
+        for (uint64_t i = 0; i < N; ++i) {
+            if (!ent[i].issued) continue;
+            if (set_device(g->ws[i]->device) == hipSuccess) {
+                (void)hipStreamSynchronize(g->ws[i]->stream);
+                (void)judge_run_error(g->ws[i]);
+            }
+            (void)hipGetLastError();
+            ent[i].issued = false;
+        }
+        return code;
+    };
+    const int rc_all = [&]() -> int {
     auto grow_entry = [&](uint64_t i, uint64_t want) -> int {
         mm_device_group::Shard &sh = g->shard[i];
         int rc = grow(sh.d_pos, sh.cap_pos, want ? want : 1, sizeof(uint32_t));
@@ -3162,7 +3296,7 @@ int mm_run_batch_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, con
         sh.has_sk = want_superkmers != 0;
         b.offs.assign(b.seqs.size() + 1, 0);
         if (b.seqs.empty()) continue;
-        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(set_device(g->ws[i]->device));
         const size_t m = b.seqs.size();
         e.dptr.resize(m);
         e.dbytes.resize(m);
@@ -3193,11 +3327,12 @@ int mm_run_batch_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, con
         mm_device_group::Shard &sh = g->shard[i];
         Entry &e = ent[i];
         if (b.seqs.empty()) continue;
-        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(set_device(g->ws[i]->device));
         const size_t m = b.seqs.size();
         int rc = MM_OK;
         if (e.issued) {
             rc = batch_finish(g->ws[i], &e.bi, true, cap_of(i), b.offs.data());
+            e.issued = rc == MM_ERR_HIP;  // (anything but a failed wait: the entry's launch is over and its words are judged)
             if (rc == MM_BATCH_REDO) e.sync_path = true;
             else if (rc == MM_ERR_CAPACITY) {  // denser than expected: again with what it needs
                 e.want = b.offs[m];
@@ -3217,7 +3352,11 @@ int mm_run_batch_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, con
             break;
         }
         sh.count = b.offs[m];
+        e.issued = false;  // (waited for and judged)
     }
+    return MM_OK;
+    }();
+    if (rc_all) return drain(rc_all);
     uint64_t sum = 0;
     for (uint64_t s = 0; s < n_seqs; ++s) {
         const mm_device_group::BatchEntry &b = g->batch[(size_t)g->seq_entry[s]];
@@ -3232,6 +3371,7 @@ int mm_run_batch_sharded_device(const mm_plan_t *plan, mm_device_group_t *g, con
 
 int mm_device_group_batch_result(const mm_device_group_t *g, uint64_t seq, int *entry, uint32_t **d_pos, uint32_t **d_sk,
                                  uint64_t *count) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!g || !g->batch_ran || seq >= g->seq_entry.size()) return MM_ERR_NULL;
     const int e = g->seq_entry[seq];
     const mm_device_group::BatchEntry &b = g->batch[(size_t)e];
@@ -3246,6 +3386,7 @@ int mm_device_group_batch_result(const mm_device_group_t *g, uint64_t seq, int *
 
 int mm_device_group_gather_batch(mm_device_group_t *g, int root, uint32_t *d_dst_pos, uint32_t *d_dst_sk,
                                  uint64_t capacity, uint64_t *out_offsets) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!g || !g->batch_ran || root < 0 || (size_t)root >= g->ws.size() || !out_offsets) return MM_ERR_NULL;
     const uint64_t n_seqs = g->seq_entry.size();
     out_offsets[0] = 0;
@@ -3265,13 +3406,13 @@ int mm_device_group_gather_batch(mm_device_group_t *g, int root, uint32_t *d_dst
         if (!c) continue;
         if (d_dst_sk && !sh.has_sk) return MM_ERR_BAD_MODE;
         // every copy on its SOURCE entry's stream: the entries' copies run side by side
-        MM_HIP(hipSetDevice(ws->device));
+        MM_HIP(set_device(ws->device));
         MM_HIP(hipMemcpyPeerAsync(d_dst_pos + out_offsets[s], root_dev, sh.d_pos + b.offs[j], ws->device, c * sizeof(uint32_t), ws->stream));
         if (d_dst_sk)
             MM_HIP(hipMemcpyPeerAsync(d_dst_sk + out_offsets[s], root_dev, sh.d_sk + b.offs[j], ws->device, c * sizeof(uint32_t), ws->stream));
     }
     for (size_t i = 0; i < g->ws.size(); ++i) {
-        MM_HIP(hipSetDevice(g->ws[i]->device));
+        MM_HIP(set_device(g->ws[i]->device));
         MM_HIP(hipStreamSynchronize(g->ws[i]->stream));
     }
     return MM_OK;
@@ -3280,6 +3421,7 @@ int mm_device_group_gather_batch(mm_device_group_t *g, int root, uint32_t *d_dst
 int mm_run_batch_sharded_host(const mm_plan_t *plan, mm_device_group_t *g, uint64_t n_seqs,
                               const uint8_t *const *packed, const uint64_t *base_offsets, const uint64_t *n_bases,
                               uint32_t *out_pos, uint32_t *out_sk, uint64_t capacity, uint64_t *out_offsets) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
     if (!plan || !g || g->ws.empty() || !out_offsets) return MM_ERR_NULL;
     if (n_seqs && (!packed || !n_bases)) return MM_ERR_NULL;
     if (out_sk && plan->mode != MM_MINIMIZERS) return MM_ERR_BAD_MODE;
@@ -3311,7 +3453,7 @@ int mm_run_batch_sharded_host(const mm_plan_t *plan, mm_device_group_t *g, uint6
             r.rc = rc;
             r.err = g_last_error;
         };
-        if (hipSetDevice(ws->device) != hipSuccess) return fail(MM_ERR_HIP);
+        if (set_device(ws->device) != hipSuccess) return fail(MM_ERR_HIP);
         // the shard's sequences back to back in one device buffer, each at a 16-byte boundary
         std::vector<uint64_t> at(my.size()), nbytes(my.size());
         uint64_t total = 0, windows = 0;
@@ -3377,7 +3519,7 @@ int mm_run_batch_sharded_host(const mm_plan_t *plan, mm_device_group_t *g, uint6
     auto phase2 = [&](uint64_t i) {
         mm_workspace *ws = g->ws[i];
         if (mine[i].empty()) return;
-        bool bad = hipSetDevice(ws->device) != hipSuccess;
+        bool bad = set_device(ws->device) != hipSuccess;
         // (runs of sequences that are neighbours in the input are neighbours in both buffers: one copy per run)
         for (size_t j = 0; j < mine[i].size() && !bad;) {
             size_t e = j + 1;

@@ -189,8 +189,9 @@ Geometry geometry(const RunArgs &a) {
         const uint32_t cap = list_capacity(a.w, a.mode, g.S);
         g.list_cap = cap;
         g.lds_bytes = cap * stride_of(a);
-        // large w (run-time specialised kernels): shorten the lanes until the lists fit the LDS
-        if (g.lds_bytes <= kMaxLdsBytes || g.nblk == 1) break;
+        // large w (run-time specialised kernels): shorten the lanes until the lists - and the skip-ambiguous walk's landing
+        // area in front of them - fit the LDS
+        if (g.lds_bytes + ambi_landing(a.w, a.wamb) <= kMaxLdsBytes || g.nblk == 1) break;
         g.nblk = g.nblk > 4 ? g.nblk * 7 / 8 : g.nblk - 1;
     }
     g.NB = kFusedThreads * g.S;
@@ -382,11 +383,14 @@ static uint32_t whole_rounds_nblk(const RunArgs &a, const KernelRef &kr, const G
     static const bool off = getenv("MM_NO_ROUNDS") != nullptr;
     if (off || a.nblk != 0 || g.nblocks <= 512) return g.nblk;
     int per_cu = 0, cus = 0;
-    if (!resident_slots(kr, g.lds_bytes, &per_cu, &cus)) return g.nblk;
+    // (the launch's dynamic LDS is lists + landing area: both decide how many workgroups a CU holds - ADVICE r5)
+    const uint32_t land = ambi_landing(a.w, a.wamb);
+    if (!resident_slots(kr, g.lds_bytes + land, &per_cu, &cus)) return g.nblk;
     const double slots = 0.98 * per_cu * cus;  // (a round that is 99 % full spills into the next one)
     const double kOverheadBlocks = 2.4;  // warm-up, look-back and copy-out of a tile, in W-blocks of walking
     if ((double)g.nblocks / slots >= 24.0 || (double)g.nblocks / slots <= 1.0) return g.nblk;
-    const uint32_t lds_limit = (kMaxLdsBytes - (uint32_t)per_cu * 512u) / (uint32_t)per_cu;
+    const uint32_t lds_share = (kMaxLdsBytes - (uint32_t)per_cu * 512u) / (uint32_t)per_cu;
+    const uint32_t lds_limit = lds_share > land ? lds_share - land : 0u;
     uint32_t sh = 0;
     if (a.out.sk && a.mode == 0)
         for (sh = 1; (1u << sh) <= a.w;) ++sh;
@@ -485,7 +489,7 @@ static Taper plan_taper(const RunArgs &a, const KernelRef &kr, const Geometry &g
     if (const char *e = mm_env("MM_TAPER_SLOTS")) slots = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : 0;
     if (!slots) {
         int per_cu = 0, cus = 0;
-        if (!resident_slots(kr, g.lds_bytes, &per_cu, &cus)) return t;
+        if (!resident_slots(kr, g.lds_bytes + ambi_landing(a.w, a.wamb), &per_cu, &cus)) return t;
         slots = (uint64_t)per_cu * cus;
     }
     const uint64_t nwin = a.win_end - a.win_begin;
@@ -643,7 +647,7 @@ int launch_fused(const RunArgs &a, hipStream_t stream) {
         int per_cu = 0, cus = 0;
         uint64_t slots = 0;
         if (const char *e = mm_env("MM_TAPER_SLOTS")) slots = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : 0;  // (tests)
-        if (!slots && resident_slots(kr, gd.lds_bytes, &per_cu, &cus)) slots = (uint64_t)per_cu * cus;
+        if (!slots && resident_slots(kr, gd.lds_bytes + ambi_landing(a.w, a.wamb), &per_cu, &cus)) slots = (uint64_t)per_cu * cus;
         if (slots) one_round_geometry(a, slots, gd, &g);
     }
     const bool tapers = !small_run && plan_taper(a, kr, g).first != 0xffffffffu && !mm_env("MM_TUNE_ALWAYS");

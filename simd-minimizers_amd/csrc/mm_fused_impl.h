@@ -1930,7 +1930,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
     ctx.land = 0;
     if (kAmbi && ambi_land_rule(W) && p.wamb) {
         if (p.land_bytes < ambi_land_bytes(W)) {  // (a launcher that did not allocate it: never walk with a null landing area)
-            if (tid == 0) flag_error(p.out.error, 2u);
+            if (tid == 0) flag_error(p.out.error, 4u);
             return;
         }
         ctx.land = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(smem) + (uint32_t)wave * land_wave_bytes(W));

@@ -435,6 +435,27 @@ def test_values_u64_four_per_thread(sm, oracle, gpu):
     assert checked == 9 * 2 * 12
 
 
+def _group_device_lists():
+    """Entries that share GPU 0 - what a one-GPU box can run - and, when the box has more GPUs, one entry per GPU and the
+    pair (1, 0): hipMemcpyPeerAsync between distinct devices and a root that is not device 0."""
+    import torch
+    ngpu = torch.cuda.device_count()
+    return [[0], [0, 0], [0, 0, 0]] + ([list(range(ngpu)), [1, 0]] if ngpu > 1 else [])
+
+
+class _SameDevice:
+    """Every exported function restores the calling thread's current device (ApiScope, mm_api.hip): checked around a block."""
+
+    def __enter__(self):
+        import torch
+        self.dev = torch.cuda.current_device()
+        return self
+
+    def __exit__(self, *a):
+        import torch
+        assert torch.cuda.current_device() == self.dev, (torch.cuda.current_device(), self.dev)
+
+
 def test_device_resident_shards(sm, oracle, gpu):
     """mm_device_group_upload / _adopt, mm_run_sharded_device, mm_device_group_result, mm_device_group_gather: the
     sequence resident on every entry's device, one asynchronous launch per entry, the positions left on the devices
@@ -444,9 +465,11 @@ def test_device_resident_shards(sm, oracle, gpu):
     import torch
     n = 5_000_037
     host = oracle.gen_packed(31, n + 64)
-    for devices in ([0], [0, 0], [0, 0, 0]):
-        g = sm.DeviceGroup(devices)
-        g.upload(host[: (n + 3) // 4 + 1])
+    for devices in _group_device_lists():
+        root = f"cuda:{devices[0]}"  # (gather's destination lives on the root entry's device)
+        with _SameDevice():
+            g = sm.DeviceGroup(devices)
+            g.upload(host[: (n + 3) // 4 + 1])
         for (k, w, canonical, mode, sk, off) in ((21, 11, True, 0, False, 0), (21, 11, False, 0, True, 3), (31, 51, True, 0, False, 1),
                                                  (15, 17, True, 1, False, 2), (15, 17, True, 2, False, 0)):
             m = n - off
@@ -454,15 +477,18 @@ def test_device_resident_shards(sm, oracle, gpu):
             sk_list = []
             if sk:
                 b = b.super_kmers(sk_list)
-            counts = g.run_device(b, m, base_offset=off)
+            with _SameDevice():
+                counts = g.run_device(b, m, base_offset=off)
             if sk:
                 want, wsk = oracle.run(host, m, k, w, canonical=canonical, mode=mode, base_offset=off, super_kmers=True)
             else:
                 want = oracle.run(host, m, k, w, canonical=canonical, mode=mode, base_offset=off)
             assert sum(counts) == len(want), (devices, k, w, mode)
-            dst = torch.full((len(want) + 8,), -3, dtype=torch.int32, device="cuda")
-            dsk = torch.full((len(want) + 8,), -3, dtype=torch.int32, device="cuda") if sk else None
-            tot = g.gather(0, dst, dsk)
+            dst = torch.full((len(want) + 8,), -3, dtype=torch.int32, device=root)
+            dsk = torch.full((len(want) + 8,), -3, dtype=torch.int32, device=root) if sk else None
+            torch.cuda.synchronize(root)
+            with _SameDevice():
+                tot = g.gather(0, dst, dsk)
             assert tot == len(want) and np.array_equal(_dev(dst, tot), want), (devices, k, w, mode)
             assert int(dst[tot].item()) == -3
             if sk:
@@ -594,8 +620,17 @@ def test_device_resident_shares(sm, oracle, gpu):
     import torch
     n, off = 40_000_003, 3
     host = oracle.gen_packed(17, n + off + 64)
-    g = sm.DeviceGroup([0, 0, 0, 0])
-    g.upload_range(host[: (n + off + 3) // 4 + 1], n, base_offset=off)
+    ngpu = torch.cuda.device_count()
+    for devices in [[0, 0, 0, 0]] + ([list(range(ngpu))] if ngpu > 1 else []):
+        _shares_on(sm, oracle, devices, host, n, off)
+
+
+def _shares_on(sm, oracle, devices, host, n, off):
+    import torch
+    with _SameDevice():
+        g = sm.DeviceGroup(devices)
+        g.upload_range(host[: (n + off + 3) // 4 + 1], n, base_offset=off)
+    root = f"cuda:{devices[0]}"
     for (k, w, canonical, mode, sk) in ((21, 11, True, 0, False), (31, 51, True, 0, False), (21, 11, False, 0, True),
                                         (15, 17, True, 1, False), (5, 3, False, 0, False)):
         b = sm.Builder(k, w, canonical, mode)
@@ -608,9 +643,11 @@ def test_device_resident_shares(sm, oracle, gpu):
         else:
             want = oracle.run(host, n, k, w, canonical=canonical, mode=mode, base_offset=off)
         assert sum(counts) == len(want), (k, w, mode)
-        dst = torch.zeros(len(want) + 1, dtype=torch.int32, device="cuda")
-        dsk = torch.zeros(len(want) + 1, dtype=torch.int32, device="cuda") if sk else None
-        assert g.gather(0, dst, dsk) == len(want)
+        dst = torch.zeros(len(want) + 1, dtype=torch.int32, device=root)
+        dsk = torch.zeros(len(want) + 1, dtype=torch.int32, device=root) if sk else None
+        torch.cuda.synchronize(root)
+        with _SameDevice():
+            assert g.gather(0, dst, dsk) == len(want)
         assert np.array_equal(_dev(dst, len(want)), want), (k, w, mode)
         if sk:
             assert np.array_equal(_dev(dsk, len(want)), wsk)
@@ -674,20 +711,25 @@ def test_device_resident_batches(sm, oracle, gpu):
     seqs = [oracle.gen_packed(300 + i, o + n + 64) for i, (n, o) in enumerate(zip(lens, offs))]
     # a dense one: poly-A emits at every window, far above the expected density of its entry
     seqs[5] = np.zeros_like(seqs[5])
-    for devices in ([0], [0, 0], [0, 0, 0]):
-        g = sm.DeviceGroup(devices)
-        g.upload_batch([s[: (o + n + 3) // 4 + 1] for s, n, o in zip(seqs, lens, offs)])
+    for devices in _group_device_lists():
+        root = f"cuda:{devices[0]}"
+        with _SameDevice():
+            g = sm.DeviceGroup(devices)
+            g.upload_batch([s[: (o + n + 3) // 4 + 1] for s, n, o in zip(seqs, lens, offs)])
         for (k, w, canonical, mode, sk) in ((21, 11, True, 0, False), (31, 51, True, 0, False), (5, 3, False, 0, True), (15, 17, True, 1, False)):
             b = sm.Builder(k, w, canonical, mode)
             if sk:
                 b = b.super_kmers([])
-            counts = g.run_batch_device(b, lens, base_offsets=offs)
+            with _SameDevice():
+                counts = g.run_batch_device(b, lens, base_offsets=offs)
             wants = [oracle.run(s, n, k, w, canonical=canonical, mode=mode, base_offset=o, super_kmers=sk) for s, n, o in zip(seqs, lens, offs)]
             wpos = [x[0] if sk else x for x in wants]
             assert counts == [len(x) for x in wpos], (devices, k, w, mode)
-            dst = torch.full((sum(counts) + 4,), -3, dtype=torch.int32, device="cuda")
-            dsk = torch.full((sum(counts) + 4,), -3, dtype=torch.int32, device="cuda") if sk else None
-            o = g.gather_batch(0, dst, dsk)
+            dst = torch.full((sum(counts) + 4,), -3, dtype=torch.int32, device=root)
+            dsk = torch.full((sum(counts) + 4,), -3, dtype=torch.int32, device=root) if sk else None
+            torch.cuda.synchronize(root)
+            with _SameDevice():
+                o = g.gather_batch(0, dst, dsk)
             assert o[-1] == sum(counts) and int(dst[o[-1]].item()) == -3
             flat = _dev(dst, o[-1])
             for i in range(len(lens)):

@@ -317,3 +317,52 @@ def test_config4_contigs_element_by_element(sm, oracle, gpu):
     for i, m in enumerate(lens):
         want = oracle.run_threads(d[i].cpu().numpy(), m, k, w, canonical=True)
         assert np.array_equal(flat[offs[i]: offs[i + 1]], want), i
+
+
+def test_short_host_calls_at_their_boundaries(sm, oracle, gpu):
+    """mm_run_host up to 64 K bases runs through a page-locked staging area the kernel reads and writes directly
+    (run_host_small, round 5; ADVICE r5: no direct test).  Lengths either side of its limit and of a window, every base
+    offset, with and without super-k-mer indices, a capacity that is too small: the same answers as the runtime's copies
+    (MM_NO_SMALL_HOST=1) and as the oracle."""
+    L = sm.lib()
+    k, w = 21, 11
+    l = k + w - 1
+    data = oracle.gen_packed(77, 70_000)
+    plan = sm.canonical_minimizers(k, w).plan()
+
+    def call(n, off, sk, cap):
+        pos = np.full(cap + 2, 0xABCDABCD, dtype=np.uint32)
+        skv = np.full(cap + 2, 0xABCDABCD, dtype=np.uint32) if sk else None
+        cnt = C.c_uint64(0)
+        code = L.mm_run_host(plan.h, gpu.h, data.ctypes.data_as(C.POINTER(C.c_uint8)), off, n,
+                             pos.ctypes.data_as(C.POINTER(C.c_uint32)),
+                             skv.ctypes.data_as(C.POINTER(C.c_uint32)) if sk else None, cap, C.byref(cnt))
+        return code, int(cnt.value), pos, skv
+    checked = 0
+    for n in (l - 1, l, 150, 65_535, 65_536, 65_537):
+        for off in range(4):
+            for sk in (False, True):
+                res = oracle.run(data, n, k, w, canonical=True, base_offset=off, super_kmers=sk)
+                wp = res[0] if sk else res
+                outs = []
+                for small in (True, False):
+                    if small:
+                        os.environ.pop("MM_NO_SMALL_HOST", None)
+                    else:
+                        os.environ["MM_NO_SMALL_HOST"] = "1"
+                    try:
+                        code, c, pos, skv = call(n, off, sk, len(wp) + 3)
+                    finally:
+                        os.environ.pop("MM_NO_SMALL_HOST", None)
+                    assert code == 0 and c == len(wp), (n, off, sk, small, code, c)
+                    assert np.array_equal(pos[:c], wp) and pos[c] == 0xABCDABCD, (n, off, sk, small)
+                    if sk:
+                        assert np.array_equal(skv[:c], res[1]), (n, off, small)
+                    outs.append(pos[:c].copy())
+                assert np.array_equal(outs[0], outs[1])
+                checked += 1
+            if len(wp) > 4:  # too small a capacity: MM_ERR_CAPACITY, the true count reported, nothing written past the capacity
+                code, c, pos, _ = call(n, off, False, len(wp) // 2)
+                assert code == sm.ERR["CAPACITY"] and c == len(wp), (n, off, code, c)
+                assert pos[len(wp) // 2] == 0xABCDABCD  # (what the buffer holds below the capacity is unspecified)
+    assert checked == 6 * 4 * 2
