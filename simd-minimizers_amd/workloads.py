@@ -7,6 +7,7 @@ must be torch's current stream), ``units`` / ``unit`` (what one step processes),
 bytes of one step, callable after a step has run: inputs read once + outputs written once), ``what`` and
 ``kernels`` (substrings of the kernel names one step launches, for the profiler summaries)."""
 import ctypes as C
+import os
 
 from . import (Builder, _check, canonical_minimizers, lib, run_reads_device)
 
@@ -248,6 +249,14 @@ def measure(name, ws, dev, warm=3, reps=5):
     # warm-up by TIME as well as by count (round 5): a component's set-up - allocation, synthetic input - leaves the chip
     # idle long enough for its clocks to drop, and three steps of a 0.7 ms kernel do not bring them back: the driver read
     # READS_SK at 0.884 ms in rounds 3 and 4 where a warmed-up run reads 0.74 (profiles/r05_reads_sk.txt)
+    # (round 6: the FIRST step of a component may compile its kernel - READS_SK, the syncmer and lane-table flavours are
+    # specialised at first use, 4-10 s with a cold code-object cache, i.e. on every fresh box - and that time used to count
+    # as warm-up: the loop below ended after three steps with the chip idle for seconds, and the five timed steps ran on
+    # cold clocks.  That was the driver's 0.88-0.90 ms for READS_SK in rounds 3-5 against 0.73-0.76 on boxes whose cache was
+    # warm: profiles/r06_reads_sk_fresh.txt.  The first step now runs before the clock starts; MM_BENCH_OLD_WARMUP=1 is the A/B.)
+    if not os.environ.get("MM_BENCH_OLD_WARMUP"):
+        c["step"]()
+        torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     while True:
         for _ in range(warm):
