@@ -19,6 +19,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dev = torch.device("cuda:0")
 ws = sm.Workspace(0, torch.cuda.current_stream(dev).cuda_stream)
+if os.environ.get("MM_RUN_NBLK"):  # (A/B runs: blocks per lane pinned, uniform tiles)
+    ws.set_blocks_per_lane(int(os.environ["MM_RUN_NBLK"]))
 
 
 def gen(n, seed):
