@@ -376,9 +376,10 @@ int judge_run_error(mm_workspace *ws) {
                        "repeat the call (three-pass kernels from now on)";
         return MM_ERR_ORDER;
     }
-    char buf[96];
+    char buf[128];
     snprintf(buf, sizeof(buf), code == 2u   ? "kernel error 2: dynamic LDS does not lie behind the static LDS"
                                : code == 4u ? "kernel error 4: a skip-ambiguous launch without its LDS landing area"
+                               : code == 5u ? "kernel error 5: the reads need more lanes than total_bases allows for"
                                             : "kernel error 0x%x (bad batch table)", code);
     g_last_error = buf;
     return MM_ERR_HIP;
@@ -658,9 +659,10 @@ int mm_workspace_check(mm_workspace_t *ws) {
                        "repeat the call (three-pass kernels from now on)";
         return MM_ERR_ORDER;
     }
-    char buf[96];
+    char buf[128];
     snprintf(buf, sizeof(buf), code == 2u   ? "kernel error 2: dynamic LDS does not lie behind the static LDS"
                                : code == 4u ? "kernel error 4: a skip-ambiguous launch without its LDS landing area"
+                               : code == 5u ? "kernel error 5: the reads need more lanes than total_bases allows for"
                                             : "kernel error 0x%x (bad batch table)", code);
     g_last_error = buf;
     return MM_ERR_HIP;

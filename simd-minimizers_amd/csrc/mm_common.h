@@ -93,7 +93,7 @@ struct OutParams {
     unsigned long long *status;  // decoupled look-back words, one per block, zeroed per launch
     uint32_t *ticket;            // dynamic block id counter, zeroed per launch
     uint32_t *error;             // error[0]: flag of this launch (1 = a look-back spin ran out, see
-                                 // lookback_exclusive; 2 = LDS layout violated; 4 = skip-ambiguous launch without its landing area; 0xbad..... = bad batch
+                                 // lookback_exclusive; 2 = LDS layout violated; 4 = skip-ambiguous launch without its landing area; 5 = lane table too small for the reads (mm_lanes.hip); 0xbad..... = bad batch
                                  // table), cleared by the entry point that reads it; error[2]: the same, sticky
                                  // until mm_workspace_check() reads it (asynchronous callers); error[4..5]: 0 or the
                                  // device address of a page-locked HOST word that receives the code as well

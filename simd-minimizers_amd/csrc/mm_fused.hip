@@ -999,7 +999,7 @@ int launch_fused_segments(const ReadsArgs &a, const SegSource &src, const SegPla
                           hipStream_t stream) {
     const KernelRef kr = resolve_reads_kernel(a);
     if (!kr) return -2;
-    if (launch_lane_table(src, a.n_reads, a.k + a.w - 1u, plan, b, stream)) return -1;
+    if (launch_lane_table(src, a.n_reads, a.k + a.w - 1u, plan, b, a.out.error, stream)) return -1;
     FusedParams p;
     p.seq = a.seq;
     p.ht = a.ht;

@@ -125,10 +125,13 @@ __global__ __launch_bounds__(kBlockThreads) void seg_first_kernel(const SegGeom 
 }
 
 __global__ __launch_bounds__(kFusedThreads) void seg_fill_kernel(const SegGeom g, const uint32_t *seg_first, LaneSeg *table,
-                                                                 uint32_t *tile_origin) {
+                                                                 uint32_t *tile_origin, uint32_t *error) {
     __shared__ uint32_t wmin[kFusedWaves];
     const uint32_t lane_id = blockIdx.x * kFusedThreads + threadIdx.x;
     const uint32_t total = seg_first[g.n_reads];
+    // more lanes than the grid was sized for: the caller's total_bases understates its reads (the bound is n_reads +
+    // total_bases / S).  The run fails with error code 5 instead of dropping the reads behind the table.
+    if (lane_id == 0 && total > gridDim.x * kFusedThreads) flag_error(error, 5u);
     LaneSeg sg{0u, 1u, 0u, 0xffffffffu};  // (behind the table: no window, not a read's first lane)
     if (lane_id < total) {
         // the read this lane belongs to: the last r with seg_first[r] <= lane_id (strictly increasing: every read owns a lane)
@@ -168,7 +171,7 @@ uint64_t lane_table_blocks(uint64_t n_reads) { return (n_reads + kSegBlock - 1) 
 // Queues the four kernels.  b.blk_sums holds lane_table_blocks(n_reads) + 1 words, b.seg_first n_reads + 1, b.table
 // plan.tiles * 256 entries, b.tile_origin plan.tiles.  Returns 0 or -1.
 int launch_lane_table(const SegSource &src, uint64_t n_reads, uint32_t l, const SegPlan &plan, const SegBuffers &b,
-                      hipStream_t stream) {
+                      uint32_t *error, hipStream_t stream) {
     if (n_reads == 0 || n_reads >= (1ull << 32) || plan.tiles == 0) return -1;
     SegGeom g;
     g.src = src;
@@ -180,7 +183,7 @@ int launch_lane_table(const SegSource &src, uint64_t n_reads, uint32_t l, const 
     hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, stream, b.blk_sums, nb);
     hipLaunchKernelGGL(seg_first_kernel, dim3(nb), dim3(kBlockThreads), 0, stream, g, b.blk_sums, nb, b.seg_first);
     hipLaunchKernelGGL(seg_fill_kernel, dim3((uint32_t)plan.tiles), dim3(kFusedThreads), 0, stream, g, b.seg_first, b.table,
-                       b.tile_origin);
+                       b.tile_origin, error);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -142,8 +142,9 @@ struct SegBuffers {
     uint32_t *blk_sums;     // lane_table_blocks(n_reads) + 1
 };
 uint64_t lane_table_blocks(uint64_t n_reads);
+// (`error`: the run's error words, OutParams::error - code 5 when the reads need more lanes than plan.lanes_cap)
 int launch_lane_table(const SegSource &src, uint64_t n_reads, uint32_t l, const SegPlan &plan, const SegBuffers &b,
-                      hipStream_t stream);
+                      uint32_t *error, hipStream_t stream);
 // lane length and grid of a lane-table launch over `n_reads` reads of `total_bases` bases in all (nblk_want: blocks per
 // lane, 0 = the default lanes of the plan).  Returns 0, -2 (no kernel) or -3 (no lane length fits).
 int fused_segments_plan(const ReadsArgs &a, uint64_t total_bases, uint32_t nblk_want, SegPlan *plan);

@@ -366,3 +366,24 @@ def test_short_host_calls_at_their_boundaries(sm, oracle, gpu):
                 assert code == sm.ERR["CAPACITY"] and c == len(wp), (n, off, code, c)
                 assert pos[len(wp) // 2] == 0xABCDABCD  # (what the buffer holds below the capacity is unspecified)
     assert checked == 6 * 4 * 2
+
+
+def test_lane_table_refuses_understated_total(sm, oracle, gpu):
+    """The lane table's grid is sized from n_reads + total_bases / S without reading anything back; a caller whose total_bases
+    understates its reads gets MM_ERR_HIP ("kernel error 5") instead of silently losing the reads behind the table - and the
+    workspace works again afterwards."""
+    import torch
+    lens = np.full(300, 20_000, dtype=np.int64)
+    d, host, starts = _packed_reads(sm, lens, 3)
+    b = sm.canonical_minimizers(21, 11)
+    ds = torch.from_numpy(starts).cuda()
+    out = torch.zeros(int(starts[-1]) // 4, dtype=torch.int32, device="cuda")
+    offs = torch.zeros(len(lens) + 1, dtype=torch.int64, device="cuda")
+    cnt = C.c_uint64()
+    code = sm.lib().mm_run_packed_reads_device(b.plan().h, gpu.h, C.c_void_p(d.data_ptr()), d.numel(), 0, len(lens),
+                                               C.c_void_p(ds.data_ptr()), int(starts[-1]) // 16, 20_000, C.c_void_p(out.data_ptr()), None,
+                                               out.numel(), C.c_void_p(offs.data_ptr()), C.byref(cnt))
+    assert code == sm.ERR["HIP"] and "kernel error 5" in sm.lib().mm_last_error().decode(), (code, sm.lib().mm_last_error())
+    flat, ho, _, launches = _run_packed(sm, gpu, b, d, starts, 20_000)
+    assert gpu.last_lane_table() and launches == 1
+    _check_reads(oracle, host, starts, lens, flat, ho, 21, 11, True, 0, sample=range(0, 300, 37))

@@ -164,6 +164,26 @@ b51 = sm.canonical_minimizers(31, 51)
 got = b51.run_skip_ambiguous_windows_once(sm.PackedNSeqVec.from_ascii(a.tobytes()))
 packed, amb = oracle.pack_ascii_n(a.tobytes())
 assert np.array_equal(np.asarray(got, dtype=np.uint32), oracle.run_skip_ambiguous(packed, amb, len(a), 31, 51))
+# round 6: lane-table launches - packed reads above a lane's length, a batch of short contigs in one buffer, the fixed-stride
+# entry with per-read lengths (host side: plan, workspace tables, the batch's uploaded starts and lengths)
+lens6 = [int(x) for x in rng.integers(0, 9000, 200)] + [70_001, 0, 31]
+st6 = np.zeros(len(lens6) + 1, dtype=np.int64); st6[1:] = np.cumsum(lens6)
+d6 = sm.generate_device(int(st6[-1]), 41)
+h6 = d6.cpu().numpy()
+out6 = torch.zeros(int(st6[-1]) // 3 + 8, dtype=torch.int32, device="cuda")
+off6 = torch.zeros(len(lens6) + 1, dtype=torch.int64, device="cuda")
+c6 = C.c_uint64()
+ds6 = torch.from_numpy(st6).cuda()
+sm._check(sm.lib().mm_run_packed_reads_device(b.plan().h, ws.h, C.c_void_p(d6.data_ptr()), d6.numel(), 0, len(lens6), C.c_void_p(ds6.data_ptr()),
+                                              int(st6[-1]), max(lens6), C.c_void_p(out6.data_ptr()), None, out6.numel(), C.c_void_p(off6.data_ptr()), C.byref(c6)))
+assert ws.last_lane_table()
+ho6 = off6.cpu().numpy()
+for r_ in (0, 57, 200):
+    s0 = int(st6[r_])
+    assert np.array_equal(out6[ho6[r_]: ho6[r_ + 1]].cpu().numpy().view(np.uint32), oracle.run(h6[s0 // 4:], lens6[r_], k, w, canonical=True, base_offset=s0 % 4)), r_
+seqs6 = [d6[int(s_) // 4:] for s_ in st6[:-1]]
+bo6 = sm.run_batch_device(b, seqs6, lens6, out6, None, base_offsets=[int(s_) % 4 for s_ in st6[:-1]])
+assert ws.last_lane_table() and bo6[-1] == int(c6.value)
 print("host paths ok")
 """
 
