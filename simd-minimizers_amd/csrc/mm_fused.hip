@@ -950,8 +950,9 @@ namespace {
 KernelRef resolve_reads_kernel(const ReadsArgs &a) {
     KernelRef kr;
     const bool sk = a.out.sk != nullptr && a.mode == 0;
+    // (experiments build: MM_JIT_FORCE / MM_DEBUG route the reads-mode launches through the run-time specialisation too)
     const FusedReadsInstance *inst =
-        (a.mode == 0 && !sk) ? find_reads_instance(a.w, a.canonical_windows, (int)a.ht.canonical) : nullptr;
+        (a.mode == 0 && !sk && !force_jit_wanted()) ? find_reads_instance(a.w, a.canonical_windows, (int)a.ht.canonical) : nullptr;
     if (inst)
         kr.host = inst->fn;
     else

@@ -821,7 +821,13 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
 #ifndef MM_GROUP_UNROLL
 #define MM_GROUP_UNROLL 1
 #endif
-    constexpr bool kGroupUnroll = MM_GROUP_UNROLL && MG > 1 && !PARTIAL && !AMBI && !DIRECT;
+    // (round 6: also in the two-body partial walks - reads, lane-table segments: READS 8 M x 150 bp 0.680 -> 0.659 ms, LONGREADS
+    // 1.549 -> 1.487, BATCH10K 0.142 -> 0.135, profiles/r06_group_unroll_partial.txt; -DMM_GROUP_UNROLL_PARTIAL=0 is the A/B)
+#ifndef MM_GROUP_UNROLL_PARTIAL
+#define MM_GROUP_UNROLL_PARTIAL 1
+#endif
+    constexpr bool kGroupUnroll = MM_GROUP_UNROLL && MG > 1 && !AMBI && !DIRECT &&
+                                  (!PARTIAL || (MM_GROUP_UNROLL_PARTIAL && kTwoBodies<W> && MODE == 0 && !SK));
     auto block = [&](const uint32_t b, auto kn_tag) {
         constexpr int KN = decltype(kn_tag)::value;  // block b + 1's index within its load group, or -1: in `kn`
         uint32_t me[NSUB], mo[NSUB];
