@@ -827,7 +827,7 @@ __device__ __forceinline__ uint32_t lane_walk(const FusedParams &p, const LaneCt
 #define MM_GROUP_UNROLL_PARTIAL 1
 #endif
     constexpr bool kGroupUnroll = MM_GROUP_UNROLL && MG > 1 && !AMBI && !DIRECT &&
-                                  (!PARTIAL || (MM_GROUP_UNROLL_PARTIAL && kTwoBodies<W> && MODE == 0 && !SK));
+                                  (!PARTIAL || (MM_GROUP_UNROLL_PARTIAL && (kTwoBodies<W> || MM_GROUP_UNROLL_PARTIAL > 1) && MODE == 0 && !SK));
     auto block = [&](const uint32_t b, auto kn_tag) {
         constexpr int KN = decltype(kn_tag)::value;  // block b + 1's index within its load group, or -1: in `kn`
         uint32_t me[NSUB], mo[NSUB];

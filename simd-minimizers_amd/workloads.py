@@ -30,7 +30,7 @@ def _generate(ws, dev, n, seed):
 def component(name, ws, dev):
     import torch
     L = lib()
-    k, w = 21, 11
+    k, w = int(os.environ.get("MM_WL_K", "21")), int(os.environ.get("MM_WL_W", "11"))  # (the bench rows: k=21 w=11; tools override)
     if name in ("READS", "READS_SK"):
         n_reads, rl = 8_000_000, 150
         n = n_reads * rl

@@ -184,7 +184,9 @@ def component(tag, cfg):
     import importlib.util
     spec = importlib.util.spec_from_file_location("wl", os.path.join(ROOT, "simd-minimizers_amd", "workloads.py"))
     likes = {"READS": ["fused_kernel"], "READS_SK": ["fused_kernel"], "SKIP": ["window_ambiguity_kernel", "fused_kernel"],
-             "VALUES": ["values_u64_kernel"], "PACK": ["pack_ascii"], "FASTA": ["fasta"], "FASTQ": ["fastq"]}[cfg]
+             "VALUES": ["values_u64_kernel"], "PACK": ["pack_ascii"], "FASTA": ["fasta"], "FASTQ": ["fastq"],
+             # (round 6: the lane-table rows - the table's four kernels are part of the step)
+             "READS_VAR": ["fused_kernel", "seg_"], "LONGREADS": ["fused_kernel", "seg_"], "BATCH10K": ["fused_kernel", "seg_"]}[cfg]
     lines = []
     db = rocprof(f"{tag}_{cfg}_stats", None, ["python3", "tools/run_config.py", cfg, "5", "3"])
     lines.append(f"== rocprofv3 --kernel-trace --stats -- python3 tools/run_config.py {cfg} 5 3\n")
@@ -241,7 +243,7 @@ if __name__ == "__main__":
             headline(tag)
         elif what.startswith("stalls:"):
             stalls(tag, *what[7:].split(":"))
-        elif what in ("READS", "READS_SK", "SKIP", "VALUES", "PACK", "FASTA", "FASTQ"):
+        elif what in ("READS", "READS_SK", "SKIP", "VALUES", "PACK", "FASTA", "FASTQ", "READS_VAR", "LONGREADS", "BATCH10K"):
             component(tag, what)
         else:
             config(tag, what)
