@@ -100,8 +100,10 @@ __global__ __launch_bounds__(1024) void seg_scan_kernel(uint32_t *blk_sums, uint
     if (tid == 0) blk_sums[n] = carry_s;
 }
 
+// (also: tile_r0[b] = the read that owns lane 256 b, the first lane of tile b - written by the read's own thread, so that
+// seg_fill_kernel starts without a search of the whole array; a read that spans many tiles loops over them)
 __global__ __launch_bounds__(kBlockThreads) void seg_first_kernel(const SegGeom g, const uint32_t *blk_sums, uint32_t n_blocks,
-                                                                  uint32_t *seg_first) {
+                                                                  uint32_t *seg_first, uint32_t *tile_r0, uint32_t n_tiles) {
     __shared__ uint32_t wsum[kWavesPerBlock];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const uint32_t r0 = (blockIdx.x * kBlockThreads + tid) * kSegItems;
@@ -118,7 +120,10 @@ __global__ __launch_bounds__(kBlockThreads) void seg_first_kernel(const SegGeom 
     for (uint32_t q = 0; q < wave; ++q) at += wsum[q];
 #pragma unroll
     for (uint32_t i = 0; i < kSegItems; ++i) {
-        if (r0 + i < g.n_reads) seg_first[r0 + i] = at;
+        if (r0 + i < g.n_reads) {
+            seg_first[r0 + i] = at;
+            for (uint32_t b = (at + kFusedThreads - 1u) / kFusedThreads; b < n_tiles && b * kFusedThreads < at + c[i]; ++b) tile_r0[b] = r0 + i;
+        }
         at += c[i];
     }
     if (blockIdx.x == 0 && tid == 0) seg_first[g.n_reads] = blk_sums[n_blocks];
@@ -133,15 +138,29 @@ __global__ __launch_bounds__(kFusedThreads) void seg_fill_kernel(const SegGeom g
     // total_bases / S).  The run fails with error code 5 instead of dropping the reads behind the table.
     if (lane_id == 0 && total > gridDim.x * kFusedThreads) flag_error(error, 5u);
     LaneSeg sg{0u, 1u, 0u, 0xffffffffu};  // (behind the table: no window, not a read's first lane)
+    // The read a lane belongs to is the last r with seg_first[r] <= lane_id (strictly increasing: every read owns a lane).
+    // The read r0 of the tile's first lane comes from seg_first_kernel (tile_origin[b] holds it until this kernel stores the
+    // origin there); the tile's other lanes belong to reads r0 .. r0 + 255 at most, whose entries go to LDS in one coalesced
+    // load and are searched there.  (A search of the whole array per lane - or per tile, by one thread - is a chain of 18
+    // dependent loads per workgroup: 100 us per 8 M lanes, 7 % of the long-read row, profiles/r06_f_LONGREADS.txt.)
+    __shared__ uint32_t s_first[kFusedThreads + 1];
+    const uint32_t lane0 = blockIdx.x * kFusedThreads;
+    uint32_t r0 = lane0 < total ? tile_origin[blockIdx.x] : 0u;
+    r0 = r0 < g.n_reads ? r0 : g.n_reads - 1u;
+    {
+        const uint32_t i0 = r0 + threadIdx.x;
+        s_first[threadIdx.x] = seg_first[i0 < g.n_reads ? i0 : g.n_reads];  // (behind the last read: the total, above every lane)
+        if (threadIdx.x == 0) s_first[kFusedThreads] = seg_first[r0 + kFusedThreads < g.n_reads ? r0 + kFusedThreads : g.n_reads];
+    }
+    __syncthreads();
     if (lane_id < total) {
-        // the read this lane belongs to: the last r with seg_first[r] <= lane_id (strictly increasing: every read owns a lane)
-        uint32_t lo = 0, hi = g.n_reads - 1u;
+        uint32_t lo = 0, hi = kFusedThreads;
         while (lo < hi) {
             const uint32_t mid = lo + (hi - lo + 1u) / 2u;
-            if (seg_first[mid] <= lane_id) lo = mid;
+            if (s_first[mid] <= lane_id) lo = mid;
             else hi = mid - 1u;
         }
-        const uint32_t r = lo, f = seg_first[r], ns = seg_first[r + 1] - f, j = lane_id - f;
+        const uint32_t r = r0 + lo, f = s_first[lo], ns = s_first[lo + 1 <= kFusedThreads ? lo + 1 : kFusedThreads] - f, j = lane_id - f;
         const uint32_t nw = seg_windows(g, r);
         // the read's windows in ns shares of (almost) equal length: share j = base + (j < rem) windows
         const uint32_t base = nw / ns, rem = nw % ns;
@@ -181,7 +200,8 @@ int launch_lane_table(const SegSource &src, uint64_t n_reads, uint32_t l, const 
     const uint32_t nb = (uint32_t)lane_table_blocks(n_reads);
     hipLaunchKernelGGL(seg_count_kernel, dim3(nb), dim3(kBlockThreads), 0, stream, g, b.blk_sums);
     hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, stream, b.blk_sums, nb);
-    hipLaunchKernelGGL(seg_first_kernel, dim3(nb), dim3(kBlockThreads), 0, stream, g, b.blk_sums, nb, b.seg_first);
+    hipLaunchKernelGGL(seg_first_kernel, dim3(nb), dim3(kBlockThreads), 0, stream, g, b.blk_sums, nb, b.seg_first, b.tile_origin,
+                       (uint32_t)plan.tiles);
     hipLaunchKernelGGL(seg_fill_kernel, dim3((uint32_t)plan.tiles), dim3(kFusedThreads), 0, stream, g, b.seg_first, b.table,
                        b.tile_origin, error);
     return hipGetLastError() == hipSuccess ? 0 : -1;
