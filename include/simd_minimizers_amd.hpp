@@ -238,6 +238,41 @@ class Builder {  // src/lib.rs:225-230
         return pos;
     }
 
+    // MANY sequences in ONE call (round 6) - what a caller that loops `run` over its reads does instead (src/lib.rs:378
+    // per read; the reference's `short` experiment, bench/src/bin/paper.rs:62-115): the reads are packed back to back on
+    // the host, one upload, ONE launch whatever their lengths (a read longer than a lane takes consecutive lanes of the
+    // device-built lane table), one download.  Positions are read-local; read r's are pos[offsets[r] .. offsets[r + 1]).
+    // With .super_kmers(&sk) the indices come back the same way.  pos / offsets / sk are OVERWRITTEN.
+    void run_many(const std::vector<PackedSeq> &reads, std::vector<uint32_t> &pos, std::vector<uint64_t> &offsets) const {
+        Workspace &ws = ws_ ? *ws_ : Workspace::thread_default();
+        std::vector<uint64_t> starts(reads.size() + 1, 0);
+        uint32_t longest = 0;
+        for (size_t r = 0; r < reads.size(); ++r) {
+            starts[r + 1] = starts[r] + reads[r].len;
+            if (reads[r].len > longest) longest = (uint32_t)reads[r].len;
+        }
+        const uint64_t total = starts.back();
+        std::vector<uint8_t> packed((total + 3) / 4 + 16, 0);
+        for (size_t r = 0; r < reads.size(); ++r)  // (base by base: any source offset to any destination offset)
+            for (uint64_t i = 0; i < reads[r].len; ++i) {
+                const uint64_t s = reads[r].offset + i, d = starts[r] + i;
+                packed[d >> 2] |= (uint8_t)(((reads[r].data[s >> 2] >> (2 * (s & 3))) & 3u) << (2 * (d & 3)));
+            }
+        mm_plan_t *plan = nullptr;
+        check(mm_plan_create(&plan, k_, w_, CANONICAL, (mm_mode_t)SYNCMER, has_hasher_ ? &hasher_ : nullptr));
+        const uint64_t cap = total ? total : 1;
+        pos.assign(cap, 0);
+        std::vector<uint32_t> sk(sk_ ? cap : 0);
+        offsets.assign(reads.size() + 1, 0);
+        uint64_t n = 0;
+        const int r = mm_run_packed_reads_host(plan, ws.get(), packed.data(), reads.size(), starts.data(), longest, pos.data(),
+                                               sk_ ? sk.data() : nullptr, cap, offsets.data(), &n);
+        mm_plan_destroy(plan);
+        check(r);
+        pos.resize(n);
+        if (sk_) sk_->assign(sk.begin(), sk.begin() + n);
+    }
+
     // the immutable plan of this builder (caller destroys it); k and w
     mm_plan_t *make_plan() const {
         mm_plan_t *plan = nullptr;

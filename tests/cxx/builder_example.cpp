@@ -144,6 +144,35 @@ int main() {
         for (size_t i = 0; i < parts.size(); ++i)
             if (cc[i] != offs[i + 1] - offs[i]) return 32;
     }
+    // round 6: many reads of ANY lengths in one call (Builder::run_many -> mm_run_packed_reads_host -> one lane-table
+    // launch): every read equals its own run_once, super-k-mer indices too, at odd source offsets
+    {
+        std::string big;
+        uint64_t x = 99;
+        for (int i = 0; i < 120000; ++i) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            big.push_back("ACGT"[(x >> 33) & 3]);
+        }
+        auto pb = pack(big.c_str());
+        const std::vector<PackedSeq> reads = {PackedSeq{pb.data(), 0, 150},     PackedSeq{pb.data() + 50, 1, 40001}, PackedSeq{pb.data(), 3, 0},
+                                              PackedSeq{pb.data() + 7, 2, 30},  PackedSeq{pb.data() + 9000, 3, 7003}, PackedSeq{pb.data() + 20000, 0, 31},
+                                              PackedSeq{pb.data() + 100, 2, 900}};
+        std::vector<uint32_t> pos, sk;
+        std::vector<uint64_t> offs;
+        canonical_minimizers(21, 11).super_kmers(&sk).run_many(reads, pos, offs);
+        if (offs.size() != reads.size() + 1 || offs.back() != pos.size() || sk.size() != pos.size()) return 40;
+        for (size_t i = 0; i < reads.size(); ++i) {
+            std::vector<uint32_t> wsk;
+            std::vector<uint32_t> want;
+            canonical_minimizers(21, 11).super_kmers(&wsk).run(reads[i], want);
+            if (std::vector<uint32_t>(pos.begin() + offs[i], pos.begin() + offs[i + 1]) != want) return 41 + (int)i;
+            if (std::vector<uint32_t>(sk.begin() + offs[i], sk.begin() + offs[i + 1]) != wsk) return 51 + (int)i;
+        }
+        std::vector<uint32_t> p2;
+        closed_syncmers(15, 17).run_many(reads, p2, offs);
+        for (size_t i = 0; i < reads.size(); ++i)
+            if (std::vector<uint32_t>(p2.begin() + offs[i], p2.begin() + offs[i + 1]) != closed_syncmers(15, 17).run_once(reads[i])) return 61 + (int)i;
+    }
     printf("builder_example ok\n");
     return 0;
 }
