@@ -1996,6 +1996,16 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         ctx.no_prev = true;
         ctx.rem_valid = (int)(nw < S ? nw : S);
         ctx.abase = abase;
+        // (round 6) a wave walks the blocks of ITS longest read, not of the batch's: reads shorter than the declared maximum -
+        // trimmed reads, a max_read_len above the actual lengths - no longer pay for blocks in which every window is masked
+        // (8 M reads of 150 bp declared as "up to 200": 0.97 -> ms; tools/gpu_reads_var_bound.py)
+        {
+            uint32_t m = (uint32_t)ctx.rem_valid;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, kWave));
+            const uint32_t nb = (__builtin_amdgcn_readfirstlane(m) + (uint32_t)W - 1u) / (uint32_t)W;
+            ctx.nblk = nb < nblk_t ? nb : nblk_t;
+        }
         return nw != 0u;
     };
     // wave-uniform minimum of rem_valid over the lanes that walk (all lanes take part)
