@@ -1998,7 +1998,7 @@ __global__ __launch_bounds__(kFusedThreads, MM_MIN_BLOCKS) void fused_kernel(con
         ctx.abase = abase;
         // (round 6) a wave walks the blocks of ITS longest read, not of the batch's: reads shorter than the declared maximum -
         // trimmed reads, a max_read_len above the actual lengths - no longer pay for blocks in which every window is masked
-        // (8 M reads of 150 bp declared as "up to 200": 0.97 -> ms; tools/gpu_reads_var_bound.py)
+        // (8 M reads of 150 bp declared as "up to 200": 0.97 -> 0.82 ms; tools/gpu_reads_var_bound.py)
         {
             uint32_t m = (uint32_t)ctx.rem_valid;
 #pragma unroll
