@@ -387,3 +387,49 @@ def test_lane_table_refuses_understated_total(sm, oracle, gpu):
     flat, ho, _, launches = _run_packed(sm, gpu, b, d, starts, 20_000)
     assert gpu.last_lane_table() and launches == 1
     _check_reads(oracle, host, starts, lens, flat, ho, 21, 11, True, 0, sample=range(0, 300, 37))
+
+
+def test_lane_table_ticket_mode_async_and_superkmer_entry(sm, oracle, gpu):
+    """The lane-table launch under the workspace's other regimes: tile ids from an atomic ticket (MM_FORCE_TICKET=1), the
+    asynchronous entry point with mm_workspace_check afterwards, and the fixed-stride super-k-mer entry point
+    (mm_run_reads_superkmers_device) with reads far above a lane - all equal to the oracle."""
+    import torch
+    rng = np.random.default_rng(608)
+    lens = rng.integers(0, 12_000, 150)
+    lens[:3] = [11_999, 0, 31]
+    d, host, starts = _packed_reads(sm, lens, 17)
+    b = sm.canonical_minimizers(21, 11)
+    os.environ["MM_FORCE_TICKET"] = "1"
+    try:
+        flat, ho, _, launches = _run_packed(sm, gpu, b, d, starts, 12_000)
+    finally:
+        os.environ.pop("MM_FORCE_TICKET", None)
+    assert gpu.last_lane_table() and launches == 1
+    _check_reads(oracle, host, starts, lens, flat, ho, 21, 11, True, 0, sample=range(0, 150, 7))
+    # asynchronous entry point + completion check
+    ds = torch.from_numpy(starts).cuda()
+    out = torch.zeros(int(starts[-1]) // 4, dtype=torch.int32, device="cuda")
+    offs = torch.zeros(len(lens) + 1, dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    sm._check(sm.lib().mm_run_packed_reads_device_async(b.plan().h, gpu.h, C.c_void_p(d.data_ptr()), d.numel(), 0, len(lens),
+                                                        C.c_void_p(ds.data_ptr()), int(starts[-1]), 12_000, C.c_void_p(out.data_ptr()), None,
+                                                        out.numel(), C.c_void_p(offs.data_ptr()), C.c_void_p(cnt.data_ptr())))
+    gpu.check()
+    assert int(cnt.item()) == len(flat) and np.array_equal(out[: len(flat)].cpu().numpy().view(np.uint32), flat)
+    assert np.array_equal(offs.cpu().numpy(), ho)
+    # fixed stride + super-k-mer indices, reads of 9 kbp (forward plan)
+    n_reads, read_len, stride = 40, 9000, 9013
+    data = oracle.gen_packed(91, n_reads * stride + 64)
+    dp = torch.from_numpy(data).cuda()
+    bf = sm.minimizers(21, 11)
+    outr = torch.zeros(n_reads * read_len // 4, dtype=torch.int32, device="cuda")
+    outs = torch.zeros_like(outr)
+    offr = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
+    tot = sm.run_reads_device(bf, dp, n_reads, stride, read_len, outr, offr, out_sk=outs)
+    assert gpu.last_lane_table()
+    hr = offr.cpu().numpy()
+    for r in range(n_reads):
+        wp, wsk = oracle.run(data, read_len, 21, 11, canonical=False, base_offset=r * stride, super_kmers=True)
+        assert np.array_equal(outr[hr[r]: hr[r + 1]].cpu().numpy().view(np.uint32), wp), r
+        assert np.array_equal(outs[hr[r]: hr[r + 1]].cpu().numpy().view(np.uint32), wsk), r
+    assert hr[-1] == tot
