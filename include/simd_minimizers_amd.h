@@ -512,6 +512,16 @@ int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n
                          uint64_t *out7, uint32_t *tile_seq, uint32_t *tile_win0, uint32_t *tile_nblk,
                          uint64_t tile_capacity, uint64_t *n_tiles);
 int mm_debug_launch_lds(uint32_t w, int canonical_windows, int mode, uint64_t n_windows, uint64_t *out2);
+/* Diagnostics of the lane-table launches (round 6).  mm_debug_lane_plan: the lane length and grid the host
+ * chooses for n_reads reads of total_bases bases - out6 = {blocks per lane, windows per lane S, entries per lane list, bytes of
+ * the lane lists, upper bound of the lanes (a multiple of 256), tiles}; mode as in mm_debug_launch_plan (3: with super-k-mer
+ * indices, whose packed 16-bit entries bound S; 4: over a PackedNSeq); blocks_per_lane 0 = the default.  No device needed.
+ * mm_debug_last_lane_table: copies the table the workspace's LAST lane-table run built to the host - lane i =
+ * {start, win0, count, read} in out4[4 i .. 4 i + 3] - up to `capacity` lanes; *n_lanes = lanes of the (padded) table.  The
+ * GPU test-suite checks with it that the lanes tile every read's windows exactly. */
+int mm_debug_lane_plan(uint32_t k, uint32_t w, int canonical_windows, int mode, uint64_t n_reads, uint64_t total_bases,
+                       uint32_t blocks_per_lane, uint64_t *out6);
+int mm_debug_last_lane_table(mm_workspace_t *ws, uint32_t *out4, uint64_t capacity, uint64_t *n_lanes);
 /* Diagnostics: the shader clock while other work runs on the device.  _begin starts a handful of sleeping
  * single-wave workgroups on a stream of the workspace's own that sample the shader cycle counter against the
  * 100 MHz real-time counter for duration_us; _end waits for them and returns the mean clock in GHz (bench.py

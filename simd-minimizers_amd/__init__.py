@@ -121,6 +121,8 @@ def lib():
         L.mm_clock_probe_end.argtypes = [vp, C.POINTER(C.c_double)]
         L.mm_link_probe.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(C.c_double)]
         L.mm_debug_launch_lds.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_uint64, u64p]
+        L.mm_debug_lane_plan.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, u64p]
+        L.mm_debug_last_lane_table.argtypes = [vp, u32p, C.c_uint64, u64p]
         L.mm_fused_overread_bytes.argtypes = []
         L.mm_fused_overread_bytes.restype = C.c_uint64
         L.mm_workspace_force_generic.argtypes = [vp, C.c_int]
@@ -203,7 +205,8 @@ EXPORTED_SYMBOLS = [
     "mm_device_group_upload", "mm_device_group_upload_range", "mm_device_group_adopt", "mm_run_sharded_device", "mm_device_group_result",
     "mm_device_group_gather",
     "mm_device_group_upload_batch", "mm_run_batch_sharded_device", "mm_device_group_batch_result",
-    "mm_device_group_gather_batch", "mm_debug_launch_plan", "mm_debug_launch_lds",
+    "mm_device_group_gather_batch", "mm_debug_launch_plan", "mm_debug_launch_lds", "mm_debug_lane_plan",
+    "mm_debug_last_lane_table",
     "mm_run_packed_reads_device_async", "mm_run_packed_reads_device", "mm_run_packed_reads_host",
 ]
 

@@ -206,6 +206,7 @@ struct mm_workspace {
     uint32_t *seg_lens = nullptr;
     uint64_t seg_lens_n = 0;
     bool last_lane_table = false;  // the last reads / batch run was a lane-table launch (diagnostics)
+    uint64_t last_lanes = 0;       // ... and the lanes of its (padded) table
     uint8_t *h_small = nullptr;             // page-locked staging of short host calls (run_host_small): bytes in, positions, indices
     uint8_t *h_small_dev = nullptr;         // ... as the device addresses it
     uint64_t h_batch_n = 0;
@@ -784,6 +785,51 @@ int mm_debug_launch_plan(uint32_t w, int canonical_windows, int mode, uint64_t n
     return tiles.size() > tile_capacity ? MM_ERR_CAPACITY : MM_OK;
 }
 
+int mm_debug_lane_plan(uint32_t k, uint32_t w, int canonical_windows, int mode, uint64_t n_reads, uint64_t total_bases,
+                       uint32_t blocks_per_lane, uint64_t *out6) {
+    if (!out6 || w == 0 || k == 0) return MM_ERR_NULL;
+    mm::ReadsArgs a;
+    memset(&a.seq, 0, sizeof a.seq);
+    memset(&a.ht, 0, sizeof a.ht);
+    memset(&a.out, 0, sizeof a.out);
+    a.k = k;
+    a.w = w;
+    a.mode = (mode == 3 || mode == 4) ? 0u : (uint32_t)mode;
+    a.canonical_windows = canonical_windows;
+    a.n_reads = n_reads;
+    a.read_stride = a.read_len = 0;
+    a.read_lens = nullptr;
+    a.read_offsets = nullptr;
+    static uint32_t sk_marker, amb_marker;  // (only their being non-null matters to the planner)
+    if (mode == 3) a.out.sk = &sk_marker;
+    a.wamb = mode == 4 ? &amb_marker : nullptr;
+    a.wamb_dwords = 0;
+    a.use_ticket = 0;
+    a.timing_start = a.timing_stop = nullptr;
+    mm::SegPlan plan;
+    const int r = mm::fused_segments_plan(a, total_bases, blocks_per_lane, &plan);
+    if (r) return MM_ERR_LEN_TOO_LARGE;
+    out6[0] = plan.nblk;
+    out6[1] = plan.S;
+    out6[2] = plan.list_cap;
+    out6[3] = plan.lds_bytes;
+    out6[4] = plan.lanes_cap;
+    out6[5] = plan.tiles;
+    return MM_OK;
+}
+
+int mm_debug_last_lane_table(mm_workspace_t *ws, uint32_t *out4, uint64_t capacity, uint64_t *n_lanes) {
+    ApiScope api_scope;  // (restores the calling thread's current device on return)
+    if (!ws || !n_lanes) return MM_ERR_NULL;
+    *n_lanes = ws->last_lane_table ? ws->last_lanes : 0;
+    if (!ws->last_lane_table || !out4 || capacity == 0) return MM_OK;
+    MM_HIP(set_device(ws->device));
+    const uint64_t m = capacity < ws->last_lanes ? capacity : ws->last_lanes;
+    MM_HIP(hipMemcpyAsync(out4, ws->seg_table, m * sizeof(mm::LaneSeg), hipMemcpyDeviceToHost, ws->stream));
+    MM_HIP(hipStreamSynchronize(ws->stream));
+    return MM_OK;
+}
+
 uint64_t mm_fused_overread_bytes(void) { return mm::fused_overread_bytes(); }
 
 int mm_prebuilt_window_sizes(int canonical_windows, int reads_mode, uint32_t *out, int capacity) {
@@ -1041,6 +1087,7 @@ static int run_lane_table(mm_workspace_t *ws, mm::ReadsArgs &a, const mm::SegSou
     if (ws->timing) ws->events.emplace_back(e0, e1);
     ws->last_path = MM_PATH_FUSED;
     ws->last_lane_table = true;
+    ws->last_lanes = plan.lanes_cap;
     return MM_OK;
 }
 

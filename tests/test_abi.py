@@ -299,3 +299,44 @@ def test_skip_ambiguous_launches_fit_the_cu(sm):
             assert nblk == nblk_plain, (w, nblk, nblk_plain)
         checked += 1
     assert checked >= 50
+
+
+def test_lane_plan_keeps_every_bound(sm):
+    """The lane-table launch's plan (round 6; mm_debug_lane_plan, no device): for every window size up to 128 and every
+    flavour - minimizers, closed / open syncmers, super-k-mer indices, PackedNSeq - the lists (and the skip-ambiguous walk's
+    landing area) fit a CU's LDS, a lane's element positions fit 16 bits (and the packed (window, offset) entry of the
+    super-k-mer flavour), the list holds the expected entries with head-room, and the lane bound covers every read owning a
+    lane plus ceil(windows / S) lanes per read."""
+    import ctypes as C
+    L = sm.lib()
+    out = (C.c_uint64 * 6)()
+    lds2 = (C.c_uint64 * 2)()
+    checked = 0
+    for w in range(1, 129):
+        for canonical in (0, 1):
+            for mode in (0, 1, 2, 3, 4):
+                if mode == 2 and w % 2 == 0:
+                    continue
+                if mode == 4 and not canonical:
+                    continue
+                k = 21 if (21 + w - 1) % 2 == 1 else 22
+                for (n_reads, total, nb) in ((200_000, 2_500_000_000, 0), (1, 50_000, 0), (8_000_000, 1_200_000_000, 0), (1000, 10_000_000, 3)):
+                    assert L.mm_debug_lane_plan(k, w, canonical, mode, n_reads, total, nb, out) == 0, (w, canonical, mode)
+                    nblk, S, cap, lds, lanes_cap, tiles = (int(x) for x in out)
+                    assert S == w * nblk and nblk >= 1 and S + w <= 60_000
+                    land = 0
+                    if mode == 4:
+                        assert L.mm_debug_launch_lds(w, canonical, 4, 10**9, lds2) == 0
+                        land = int(lds2[1])
+                    assert lds == cap * 516 and lds + land <= 159 * 1024, (w, mode, lds, land)
+                    if mode == 3:
+                        shift = max(1, w.bit_length())
+                        assert (S << shift) <= 65536, (w, S, shift)
+                    dens = 1.0 / w if mode == 2 else (2.0 / w if mode == 1 else 2.0 / (w + 1))
+                    assert cap >= min(S + w, int(1.3 * dens * S) + 8), (w, mode, cap, S)
+                    assert lanes_cap % 256 == 0 and tiles * 256 == lanes_cap
+                    assert lanes_cap >= n_reads + total // S, (w, mode, lanes_cap)
+                    if nb:
+                        assert nblk <= nb
+                    checked += 1
+    assert checked > 4000

@@ -433,3 +433,47 @@ def test_lane_table_ticket_mode_async_and_superkmer_entry(sm, oracle, gpu):
         assert np.array_equal(outr[hr[r]: hr[r + 1]].cpu().numpy().view(np.uint32), wp), r
         assert np.array_equal(outs[hr[r]: hr[r + 1]].cpu().numpy().view(np.uint32), wsk), r
     assert hr[-1] == tot
+
+
+def test_lane_table_tiles_every_read_exactly(sm, oracle, gpu):
+    """The table itself (mm_debug_last_lane_table), not only what the walk makes of it: every read's lanes are consecutive, start
+    at window 0, advance by their counts, sum to the read's windows, differ by at most one window and never exceed the plan's lane
+    length; a read without a window owns exactly one empty first lane; `start` is the read's start + win0; the lanes behind the
+    table are empty and are no read's first lane."""
+    rng = np.random.default_rng(609)
+    lens = np.concatenate([rng.integers(0, 50, 300), rng.integers(0, 5000, 500), [70_001, 0, 30, 31, 32, 339, 338]])
+    rng.shuffle(lens)
+    d, host, starts = _packed_reads(sm, lens, 23)
+    L = sm.lib()
+    for (k, w, canonical, nb) in ((21, 11, True, 0), (21, 11, True, 2), (31, 51, True, 0), (5, 3, False, 0), (15, 28, False, 0)):
+        b = sm.Builder(k, w, canonical, 0)
+        gpu.set_blocks_per_lane(nb)
+        try:
+            with _Env("1"):
+                _run_packed(sm, gpu, b, d, starts, int(lens.max()))
+        finally:
+            gpu.set_blocks_per_lane(0)
+        assert gpu.last_lane_table()
+        plan = (C.c_uint64 * 6)()
+        assert L.mm_debug_lane_plan(k, w, int(canonical), 0, len(lens), int(starts[-1]), nb, plan) == 0
+        S, lanes_cap = int(plan[1]), int(plan[4])
+        n = C.c_uint64()
+        tab = np.zeros((lanes_cap, 4), dtype=np.uint32)
+        sm._check(L.mm_debug_last_lane_table(gpu.h, tab.ctypes.data_as(C.POINTER(C.c_uint32)), lanes_cap, C.byref(n)))
+        assert int(n.value) == lanes_cap
+        l = k + w - 1
+        nw = np.maximum(lens - l + 1, 0)
+        want_lanes = np.where(nw > 0, -(-nw // S), 1)
+        real = int(want_lanes.sum())
+        assert real <= lanes_cap
+        first = np.concatenate([[0], np.cumsum(want_lanes)])
+        for r in range(len(lens)):
+            rows = tab[first[r]: first[r + 1]]
+            assert np.all(rows[:, 3] == r), r
+            assert rows[0, 1] == 0 and int(rows[:, 2].sum()) == int(nw[r]), (r, rows[:3])
+            assert np.array_equal(rows[:, 1], np.concatenate([[0], np.cumsum(rows[:-1, 2])])), r
+            assert int(rows[:, 2].max()) <= S and int(rows[:, 2].max()) - int(rows[:, 2].min()) <= 1, r
+            if nw[r]:
+                assert np.array_equal(rows[:, 0].astype(np.int64), starts[r] + rows[:, 1].astype(np.int64)), r
+        pad = tab[real:]
+        assert np.all(pad[:, 2] == 0) and np.all(pad[:, 1] != 0)
