@@ -1179,7 +1179,11 @@ static int batch_issue(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_seq
         const uint64_t tile_w = mm::fused_tile_windows(probe);  // windows of a default tile
         uint64_t total_w = 0;
         for (uint64_t s = 0; s < n_seqs; ++s) total_w += nws[s];
-        const bool short_seqs = total_w / nonempty < 8 * tile_w;
+        // (the crossover, measured on 1 Gbp of equal contigs - tools/gpu_batch_crossover.py, profiles/r06_batch_crossover.txt: the
+        // lane table wins up to 500 kbp per contig and the per-sequence tiles from 1 Mbp on, at w = 11 - 6 and 13 tiles per
+        // contig - as at w = 51 - 1.4 and 2.8: eight tiles or 750 k windows, whichever is less)
+        const uint64_t per_seq_limit = 8 * tile_w < 750000ull ? 8 * tile_w : 750000ull;
+        const bool short_seqs = total_w / nonempty < per_seq_limit;
         if ((short_seqs || lane_table_policy() == 1) &&
             mm::fused_reads_supported(plan->w, plan->canonical_windows, (int)plan->ht.canonical, d_out_sk ? 1u : plan->mode)) {
             uintptr_t lo = ~(uintptr_t)0, hi = 0;
