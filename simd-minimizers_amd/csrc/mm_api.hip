@@ -1507,12 +1507,14 @@ static int run_reads_async_impl(const mm_plan_t *plan, mm_workspace_t *ws, const
         const int policy = lane_table_policy();
         bool lanes = policy == 1;
         if (policy == -1) {
-            // (one lane per read stays while its lists leave a CU four workgroups - 40 KB: 1.3 x density x windows + 8
-            // entries of 516 bytes - and never below the lane table's own lane length)
+            // (one lane per read stays while its lists leave a CU three workgroups - 48 KB: 1.3 x density x windows + 8 entries
+            // of 516 bytes - and never below the lane table's own lane length.  Measured on the ladder's rungs, k=21 w=11,
+            // tools/gpu_reads_crossover.py, profiles/r06_reads_crossover.txt: reads of up to 353 windows 0.68 / 0.87 ms one lane
+            // each against 0.79 / 1.00 through the table (forward / canonical); up to 481 windows 0.92 / 1.18 against 0.74 / 0.95)
             mm::SegPlan sp;
             const uint64_t max_nw = read_len >= l ? read_len - l + 1 : 0;
             const double dens = plan->mode == MM_OPEN_SYNCMERS ? 1.0 / plan->w : (plan->mode == MM_CLOSED_SYNCMERS ? 2.0 / plan->w : 2.0 / (plan->w + 1.0));
-            const uint64_t one_lane = (uint64_t)((40.0 * 1024.0 / 516.0 - 8.0) / (1.3 * dens));
+            const uint64_t one_lane = (uint64_t)((48.0 * 1024.0 / 516.0 - 8.0) / (1.3 * dens));
             lanes = mm::fused_segments_plan(a, span, ws->nblk, &sp) == 0 && max_nw > (sp.S > one_lane ? sp.S : one_lane);
         }
         int lr = -3;
