@@ -477,3 +477,34 @@ def test_lane_table_tiles_every_read_exactly(sm, oracle, gpu):
                 assert np.array_equal(rows[:, 0].astype(np.int64), starts[r] + rows[:, 1].astype(np.int64)), r
         pad = tab[real:]
         assert np.all(pad[:, 2] == 0) and np.all(pad[:, 1] != 0)
+
+
+def test_lane_table_base_offset_and_unaligned_pointer(sm, oracle, gpu):
+    """Packed reads whose buffer starts at an odd byte address and at base offsets 1 .. 3 inside it (PackedSeq slices,
+    src/test.rs:42-45), long enough for the lane table: every read == the oracle."""
+    import torch
+    rng = np.random.default_rng(610)
+    lens = rng.integers(0, 4000, 120)
+    lens[:2] = [3999, 0]
+    starts = np.zeros(len(lens) + 1, dtype=np.int64)
+    starts[1:] = np.cumsum(lens)
+    total = int(starts[-1])
+    b = sm.canonical_minimizers(21, 11)
+    for shift, off in ((1, 3), (3, 1), (2, 2), (0, 3)):
+        data = oracle.gen_packed(700 + shift, off + total + 64)
+        dev = torch.zeros(len(data) + 8, dtype=torch.uint8, device="cuda")
+        dev[shift: shift + len(data)] = torch.from_numpy(data).cuda()
+        d = dev[shift:]
+        ds = torch.from_numpy(starts).cuda()
+        out = torch.zeros(total // 3 + 8, dtype=torch.int32, device="cuda")
+        offs = torch.zeros(len(lens) + 1, dtype=torch.int64, device="cuda")
+        cnt = C.c_uint64()
+        sm._check(sm.lib().mm_run_packed_reads_device(b.plan().h, gpu.h, C.c_void_p(d.data_ptr()), d.numel(), off, len(lens),
+                                                      C.c_void_p(ds.data_ptr()), total, 3999, C.c_void_p(out.data_ptr()), None,
+                                                      out.numel(), C.c_void_p(offs.data_ptr()), C.byref(cnt)))
+        assert gpu.last_lane_table()
+        ho = offs.cpu().numpy()
+        flat = out[: int(cnt.value)].cpu().numpy().view(np.uint32)
+        for r in range(len(lens)):
+            want = oracle.run(data, int(lens[r]), 21, 11, canonical=True, base_offset=off + int(starts[r]))
+            assert np.array_equal(flat[ho[r]: ho[r + 1]], want), (shift, off, r)
