@@ -6,7 +6,7 @@
 // and the batch mode gave every contig tiles of its own, so a 10 kbp contig filled 33 of a tile's 256 lanes.  With a lane
 // table (LaneSeg, mm_common.h) a tile's 256 lanes are ANY 256 consecutive segments: a read of n_w windows takes
 // ceil(n_w / S) consecutive lanes of (almost) equal length, a short read one lane, a read without a window one empty
-// lane (it stores the read's output offset).  Four small kernels on the run's stream, no host round trip:
+// lane (it stores the read's output offset).  Four small kernels on the run's stream (two for up to 2048 reads), no host round trip:
 //   seg_count_kernel   segments per read, summed per block of 2048 reads
 //   seg_scan_kernel    exclusive scan of the block sums (one workgroup)
 //   seg_first_kernel   first lane of every read (seg_first[r], n_reads + 1 entries)
@@ -116,7 +116,9 @@ __global__ __launch_bounds__(kBlockThreads) void seg_first_kernel(const SegGeom 
     const uint32_t incl = wave_inclusive_sum(v);
     if (lane == kWave - 1) wsum[wave] = incl;
     __syncthreads();
-    uint32_t at = blk_sums[blockIdx.x] + incl - v;
+    // (n_blocks == 1 - up to 2048 reads: this workgroup is the whole scan, the counting and scanning kernels are not launched -
+    // two launches less on a small batch's stream, 84 -> 78 us for 100 reads of 10 kbp, tools/gpu_lanes_small.py)
+    uint32_t at = (n_blocks == 1u ? 0u : blk_sums[blockIdx.x]) + incl - v;
     for (uint32_t q = 0; q < wave; ++q) at += wsum[q];
 #pragma unroll
     for (uint32_t i = 0; i < kSegItems; ++i) {
@@ -126,7 +128,16 @@ __global__ __launch_bounds__(kBlockThreads) void seg_first_kernel(const SegGeom 
         }
         at += c[i];
     }
-    if (blockIdx.x == 0 && tid == 0) seg_first[g.n_reads] = blk_sums[n_blocks];
+    if (blockIdx.x == 0 && tid == 0) {
+        uint32_t total = 0;
+        if (n_blocks == 1u) {
+#pragma unroll
+            for (int q = 0; q < kWavesPerBlock; ++q) total += wsum[q];
+        } else {
+            total = blk_sums[n_blocks];
+        }
+        seg_first[g.n_reads] = total;
+    }
 }
 
 __global__ __launch_bounds__(kFusedThreads) void seg_fill_kernel(const SegGeom g, const uint32_t *seg_first, LaneSeg *table,
@@ -198,8 +209,10 @@ int launch_lane_table(const SegSource &src, uint64_t n_reads, uint32_t l, const 
     g.l = l;
     g.S = plan.S;
     const uint32_t nb = (uint32_t)lane_table_blocks(n_reads);
-    hipLaunchKernelGGL(seg_count_kernel, dim3(nb), dim3(kBlockThreads), 0, stream, g, b.blk_sums);
-    hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, stream, b.blk_sums, nb);
+    if (nb > 1) {
+        hipLaunchKernelGGL(seg_count_kernel, dim3(nb), dim3(kBlockThreads), 0, stream, g, b.blk_sums);
+        hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, stream, b.blk_sums, nb);
+    }
     hipLaunchKernelGGL(seg_first_kernel, dim3(nb), dim3(kBlockThreads), 0, stream, g, b.blk_sums, nb, b.seg_first, b.tile_origin,
                        (uint32_t)plan.tiles);
     hipLaunchKernelGGL(seg_fill_kernel, dim3((uint32_t)plan.tiles), dim3(kFusedThreads), 0, stream, g, b.seg_first, b.table,
