@@ -151,8 +151,10 @@ int mm_workspace_last_path(const mm_workspace_t *ws);
  * kernel whose lanes are segments of the reads - a read longer than a lane takes consecutive lanes - so reads and
  * sequences of any lengths (Builder::run per read / contig, src/lib.rs:378; the reference's `short` experiment spans
  * lengths 16 .. 16 384, bench/src/bin/paper.rs:62-115) fill every tile.  mm_run_reads_device*, mm_run_packed_reads_*
- * take it when the longest read exceeds a default lane, mm_run_batch_device for batches of short sequences that lie
- * within 2^32 bases of one another; diagnostics only, results are the same on every path. */
+ * take it when the longest read exceeds a default lane, mm_run_batch_device for batches of short sequences that lie in
+ * ONE device allocation within 2^32 bases of one another (one descriptor then covers them all; sequences in separate
+ * allocations keep tiles of their own, whose loads are clamped to each sequence's bytes); diagnostics only, results are
+ * the same on every path. */
 int mm_workspace_last_lane_table(const mm_workspace_t *ws);
 /* Window sizes w for which the library carries a PREBUILT fused kernel (every other w <= 128 is specialised at
  * first use, larger ones take the generic family): canonical_windows 0 / 1 selects the forward / canonical

@@ -1170,7 +1170,7 @@ static int batch_issue(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_seq
     }
     // Round 6: batches of SHORT sequences take a lane-table launch of the reads-mode kernel (mm_lanes.hip) - a tile's 256
     // lanes are any 256 consecutive segments of the batch, where the tile table below gives every sequence tiles of its
-    // own (a 10 kbp contig fills 33 of 256 lanes).  Needs all sequences inside one span of < 2^32 bases from the lowest
+    // own (a 10 kbp contig fills 33 of 256 lanes).  Needs all sequences inside ONE ALLOCATION and one span of < 2^32 bases from the lowest
     // pointer (one allocation, the FASTA packer's buffer); long contigs keep their tiles (tapered tail, sequence kernel).
     ws->last_lane_table = false;
     if (nonempty && lane_table_policy() != 0) {
@@ -1198,7 +1198,22 @@ static int batch_issue(const mm_plan_t *plan, mm_workspace_t *ws, uint64_t n_seq
                 if (n_bases[s] > max_len) max_len = (uint32_t)n_bases[s];
             }
             const uint64_t span_bytes = hi - lo;
-            if (span_bytes < (1ull << 30) - 64) {
+            // ONE descriptor covers the span from the lowest sequence to the end of the highest, and a lane's loads run a few
+            // KB past its sequence's end (fused_overread_bytes): everything between the sequences has to be mapped memory - true
+            // inside one allocation (the FASTA / FASTQ packer's buffer, slices of one tensor), not between allocations.  The
+            // per-sequence tiles below clamp every load to its own sequence's bytes and need no such thing.
+            bool one_allocation = false;
+            {
+                hipDeviceptr_t abase = nullptr;
+                size_t asize = 0;
+                if (hipMemGetAddressRange(&abase, &asize, reinterpret_cast<hipDeviceptr_t>(lo)) == hipSuccess) {
+                    const uintptr_t a0 = reinterpret_cast<uintptr_t>(abase);
+                    one_allocation = lo >= a0 && hi <= a0 + asize;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+            if (one_allocation && span_bytes < (1ull << 30) - 64) {
                 bi->starts.assign(n_seqs + 1, 0);
                 bi->lens.assign(n_seqs, 0);
                 uint64_t total_bases = 0;
