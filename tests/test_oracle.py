@@ -336,3 +336,29 @@ def test_embedded_kernel_source_is_stripped():
     stripped = m.strip(header)
     assert "MM_DEBUG" not in stripped and stripped.count("\n") == header.count("\n")
     assert "fused_kernel" in stripped and "v_cmpx_ne_u32_sdwa" in stripped
+
+
+def test_run_threads_equals_the_streaming_oracle(oracle):
+    """oracle.run_threads - the all-cores oracle of the full-size element-by-element GPU tests (round 6) - equals the plain
+    streaming restatement: minimizers through the threaded AVX2 port, syncmer modes and super-k-mer indices through window
+    chunks joined by the reference's lane rule (src/collect.rs:265-271; none for syncmers, src/syncmers.rs:166-169), with chunk
+    sizes that put seams everywhere, on random and on tie-heavy (two-letter) sequences, at a base offset."""
+    n = 600_000
+    rnd = oracle.gen_packed(5, n + 8)
+    two = np.frombuffer(b"AC", dtype=np.uint8)[np.random.default_rng(3).integers(0, 2, n + 8)].tobytes()
+    tie = np.concatenate([oracle.pack_ascii(two), np.zeros(8, dtype=np.uint8)])
+    for data in (rnd, tie):
+        for (k, w, canonical, mode, sk) in ((21, 11, True, 0, False), (21, 11, False, 0, True), (15, 17, True, 1, False),
+                                            (15, 17, False, 2, False), (31, 51, True, 0, True), (5, 3, True, 0, True)):
+            for off, chunk in ((0, 1 << 22), (3, 9973), (1, 257)):
+                m = n - off - (0 if chunk > 1000 else 500_000)  # (tiny chunks: a shorter run)
+                want = oracle.run(data, m, k, w, canonical=canonical, mode=mode, base_offset=off, super_kmers=sk)
+                got = oracle.run_threads(data, m, k, w, canonical=canonical, mode=mode, super_kmers=sk, threads=4, base_offset=off,
+                                         chunk_windows=chunk)
+                if sk:
+                    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (k, w, mode, off, chunk)
+                else:
+                    assert np.array_equal(got, want), (k, w, canonical, mode, off, chunk)
+    # shorter than a window: empty
+    e = oracle.run_threads(rnd, 20, 21, 11, canonical=True, mode=1)
+    assert len(e) == 0
