@@ -508,3 +508,27 @@ def test_lane_table_base_offset_and_unaligned_pointer(sm, oracle, gpu):
         for r in range(len(lens)):
             want = oracle.run(data, int(lens[r]), 21, 11, canonical=True, base_offset=off + int(starts[r]))
             assert np.array_equal(flat[ho[r]: ho[r + 1]], want), (shift, off, r)
+
+
+def test_lane_table_capacity_too_small(sm, oracle, gpu):
+    """A lane-table launch whose output capacity is too small: MM_ERR_CAPACITY, the true count reported, nothing written past the
+    capacity, the offsets still those of the full result - and the same call with room succeeds right after."""
+    import torch
+    lens = np.full(64, 9000, dtype=np.int64)
+    d, host, starts = _packed_reads(sm, lens, 29)
+    b = sm.canonical_minimizers(21, 11)
+    flat, ho, _, _ = _run_packed(sm, gpu, b, d, starts, 9000)
+    ds = torch.from_numpy(starts).cuda()
+    for cap in (0, 1, len(flat) // 2, len(flat) - 1):
+        out = torch.full((len(flat) + 8,), -7, dtype=torch.int32, device="cuda")
+        offs = torch.zeros(len(lens) + 1, dtype=torch.int64, device="cuda")
+        cnt = C.c_uint64()
+        code = sm.lib().mm_run_packed_reads_device(b.plan().h, gpu.h, C.c_void_p(d.data_ptr()), d.numel(), 0, len(lens), C.c_void_p(ds.data_ptr()),
+                                                   int(starts[-1]), 9000, C.c_void_p(out.data_ptr()), None, cap, C.c_void_p(offs.data_ptr()), C.byref(cnt))
+        assert code == sm.ERR["CAPACITY"] and int(cnt.value) == len(flat), (cap, code, cnt.value)
+        assert gpu.last_lane_table()
+        got = out.cpu().numpy()
+        assert np.all(got[cap:] == -7) and np.array_equal(got[:cap].view(np.uint32), flat[:cap]), cap
+        assert np.array_equal(offs.cpu().numpy(), ho)
+    again, ho2, _, _ = _run_packed(sm, gpu, b, d, starts, 9000)
+    assert np.array_equal(again, flat) and np.array_equal(ho2, ho)
