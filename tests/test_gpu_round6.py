@@ -530,5 +530,11 @@ def test_lane_table_capacity_too_small(sm, oracle, gpu):
         got = out.cpu().numpy()
         assert np.all(got[cap:] == -7) and np.array_equal(got[:cap].view(np.uint32), flat[:cap]), cap
         assert np.array_equal(offs.cpu().numpy(), ho)
+    # count-only run (no output array): the count and the offsets, MM_OK
+    offs = torch.zeros(len(lens) + 1, dtype=torch.int64, device="cuda")
+    cnt = C.c_uint64()
+    code = sm.lib().mm_run_packed_reads_device(b.plan().h, gpu.h, C.c_void_p(d.data_ptr()), d.numel(), 0, len(lens), C.c_void_p(ds.data_ptr()),
+                                               int(starts[-1]), 9000, None, None, 0, C.c_void_p(offs.data_ptr()), C.byref(cnt))
+    assert code == 0 and int(cnt.value) == len(flat) and np.array_equal(offs.cpu().numpy(), ho)
     again, ho2, _, _ = _run_packed(sm, gpu, b, d, starts, 9000)
     assert np.array_equal(again, flat) and np.array_equal(ho2, ho)
